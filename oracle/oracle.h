@@ -1,0 +1,192 @@
+/* oracle.h -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A literal, single-precision CPU restatement of the reference's hot path
+ *   RF ingest -> [Reshape] -> Decode -> Filter/Demodulate -> DAS -> CoherencyWeighting
+ * written by reading shaders/{reshape,decode,filter,das,coherency_weighting}.glsl,
+ * beamformer_core.c:553-1013 (planner), :1289-1400 + :1519-1626 (executor), math.c and
+ * lib/ogl_beamformer_lib.c:491-570 of rnpnr/ogl_beamforming.  Each function cites the
+ * lines it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call
+ * this code, and only as the checker.  The product (libogl_beamformer_lib.so) never
+ * links it and has no CPU fallback.
+ *
+ * PARITY STATUS: the host math (Hadamard, Kaiser, chirps, windows, filter moments,
+ * DAS transforms) is pinned against the compiled reference (oracle/_ref/libref_math.so,
+ * fixtures under tests/golden/).  The shader restatements are PARITY UNPINNED by the
+ * reference: its tests/ hold no expected outputs for this path and its GLSL cannot be
+ * built or run here (no Vulkan loader/ICD, empty glslang submodule).  They are pinned
+ * only by physics known-answer tests and a float64 twin (oracle_das_f64).
+ *
+ * Documented departures from the reference's text (each has a test):
+ *   Q1  Hadamard orders 12*2^k and 20*2^k are produced (math.c:96 returns NULL for them).
+ *   Q2  Float16 data is IEEE half in Reshape (reshape.glsl:7-10 reads it as int16).
+ *   Q3  IQ rotation arguments are range-reduced (turns = frac(f*t)) before sin/cos;
+ *       the reference feeds ~1e3..1e4 rad to the driver's sin/cos.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+#include "../include/ogl_beamformer_lib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- host math (oracle_math.c) ---------------- */
+/* math.c:35-134; out[dim*dim] of +-1 as float.  Returns 0 if no construction exists. */
+int    oracle_hadamard_transpose(int dim, float *out);
+double oracle_bessel_i0(double x);                                   /* external/cephes.c:24-103 */
+void   oracle_kaiser_low_pass(float cutoff, float fs, float beta, int length, float *out); /* math.c:750-767 */
+float  oracle_tukey_window(float t, float tapering);                 /* math.c:739-747 */
+void   oracle_rf_chirp(float fmin, float fmax, float fs, int length, int reverse, float *out);      /* math.c:769-781 */
+void   oracle_baseband_chirp(float fmin, float fmax, float fs, int length, int reverse,
+                             float scale, float *out /* 2*length */);                             /* math.c:783-797 */
+float  oracle_real_filter_first_moment(const float *h, int length, float fs);                      /* math.c:726-737 */
+float  oracle_complex_filter_first_moment(const float *h, int length, float fs);                   /* math.c:713-724 */
+void   oracle_m4_mul(const float *a, const float *b, float *out);                                  /* math.c:448-458 */
+void   oracle_das_transform(const float *min3, const float *max3, int *points3, float *out16);     /* math.c:799-920 */
+void   oracle_das_transform_2d(int plane, const float *min2, const float *max2, float offset, float *out16);
+void   oracle_das_transform_3d(const float *min3, const float *max3, float *out16);
+
+/* beamformer_core.c:366-398.  coefficients: length (real) or 2*length (complex) floats.
+ * Returns length, writes time_delay. */
+int    oracle_filter_create(const BeamformerFilterParameters *fp, float *coefficients, int cap,
+                            float *time_delay);
+
+/* ---------------- stages (oracle_stages.c) ---------------- */
+/* lib/ogl_beamformer_lib.c:491-570: dst[ch][a*S+s] = raw[channel_mapping[ch]][...],
+ * A1S2 contrast reduction a-b-c per sample.  dst holds C*A*S elements of data_kind. */
+void oracle_channel_map(const void *raw, void *dst, const BeamformerParameters *bp, int data_kind,
+                        const int16_t *channel_mapping);
+
+typedef struct {
+	int   size[3];            /* x = samples, y = channels, z = transmits (reshape.glsl:61-65) */
+	int   in_stride[3], out_stride[3];
+	int   in_kind, out_kind;  /* BeamformerDataKind */
+	int   interleave;         /* reshape.glsl:71-75 */
+} OracleReshape;
+void oracle_reshape(const OracleReshape *r, const void *left, const void *right, void *out);
+
+typedef struct {
+	int   transmit_count, chunk_channel_count, sample_count; /* sample_count = dispatch extent */
+	int   out_stride[3];      /* sample, channel, transmit */
+	int   in_kind, out_kind;
+	const float *hadamard;    /* transmit_count^2, as uploaded (f16-exact +-1) */
+} OracleDecode;
+/* decode.glsl:24-73 / :119-150 (both produce the same sums; order j ascending) */
+void oracle_decode(const OracleDecode *d, const void *in, void *out);
+
+typedef struct {
+	int   filter_length, complex_filter, demodulate;
+	float sampling_frequency, demodulation_frequency;  /* only read when demodulate */
+	int   decimation_rate;
+	int   sample_count;       /* FilterBake.SampleCount (already /2D when demodulating) */
+	int   batch_sample_count; /* != 0: deinterleave */
+	int   in_stride[3], out_stride[3];
+	int   in_kind, out_kind;
+	int   channels, transmits;
+	int64_t in_elements;      /* elements of in_kind readable from `in` (reads beyond give 0) */
+	int   workgroup;          /* gl_WorkGroupSize.x (64): fixes the LDS-local phase index */
+	const float *coefficients;
+} OracleFilter;
+/* filter.glsl:68-135 */
+void oracle_filter(const OracleFilter *f, const void *in, void *out, uint32_t output_element_offset);
+
+/* coherency_weighting.glsl:28-37 */
+void oracle_coherency_weighting(float *coherent, const float *incoherent, uint32_t voxels,
+                                int complex_data, float scale);
+
+/* build-defined reduction (shaders/min_max.glsl is dead code in the reference):
+ * min and max over voxels of |v| (complex) or v (real).  PARITY UNPINNED. */
+void oracle_min_max(const float *frame, uint64_t voxels, int complex_data, float *out2);
+
+/* ---------------- DAS (oracle_das.c) ---------------- */
+typedef struct {
+	/* BeamformerDASBakeParameters (generated/beamformer.c:206-231) */
+	uint32_t acquisition_kind;
+	int32_t  sparse;
+	int32_t  acquisition_count, channel_count, chunk_channel_count, sample_count;
+	float    sampling_frequency, demodulation_frequency, speed_of_sound, time_offset;
+	uint32_t interpolation_mode;
+	float    f_number;
+	int32_t  single_orientation;
+	uint32_t transmit_receive_orientation;
+	int32_t  single_focus;
+	float    focus_depth, transmit_angle;
+	uint32_t output_size[3];
+	uint32_t readi_group_count;
+	int32_t  coherency_weighting;
+	int32_t  complex_data;        /* InputDataKind == Float32Complex */
+	/* BeamformerDASPushConstants (generated/beamformer.c:261-269) */
+	float    xdc_transform[16], voxel_transform[16], xdc_element_pitch[2];
+	uint32_t rf_element_offset;
+	int32_t  channel_offset;
+	uint32_t readi_group;
+	/* BeamformerComputeArrayParameters (generated/beamformer.c:463-467) */
+	const float   *focal_vectors;                /* [256][2] */
+	const int16_t *sparse_elements;              /* [256] */
+	const uint8_t *transmit_receive_orientations;/* [256] */
+	const float   *readi_hadamard;               /* readi_group_count^2 or NULL */
+	/* build extension: z-slab of the output grid (whole grid when z_count == 0) */
+	uint32_t z_first, z_count;
+	int32_t  threads;             /* OpenMP threads, 0 = default */
+} OracleDAS;
+/* das.glsl:368-407: output[...] += sum, incoherent[...] += |.| sums.
+ * rf: elements (float or float pair); output: float or float pair per voxel.
+ * Returns the number of (voxel, channel, transmit) triples that passed the
+ * apodization test (G of BASELINE.md section 4). */
+uint64_t oracle_das(const OracleDAS *p, const float *rf, float *output, float *incoherent);
+/* float64 twin of the same loops (truth for tolerance budgeting); outputs double */
+uint64_t oracle_das_f64(const OracleDAS *p, const float *rf, double *output, double *incoherent);
+
+/* ---------------- planner + executor (oracle_plan.c) ---------------- */
+typedef struct {
+	int kind;                       /* BeamformerShaderKind */
+	int in_kind, out_kind;
+	int in_stride[3], out_stride[3];
+	int filter_slot;
+	int user_index;
+} OracleStage;
+
+typedef struct {
+	int          stage_count;
+	OracleStage  stages[BeamformerMaxComputeShaderStages];
+	int          first_image_stage;
+	int          iq_pipeline;
+	int          chunk_channel_count;
+	int          input_sample_count;     /* samples entering DAS */
+	float        das_sampling_frequency;
+	float        das_time_offset;
+	uint32_t     rf_size;                /* bytes of one ping-pong slot */
+	int          pipeline_data_kind;
+	int          output_points[3];
+	float        das_voxel_transform[16];
+	int          das_sparse;
+} OraclePlan;
+
+typedef struct {
+	BeamformerParameters        parameters;
+	int32_t                     shaders[BeamformerMaxComputeShaderStages];
+	uint8_t                     filter_slots[BeamformerMaxComputeShaderStages];
+	uint32_t                    shader_count;
+	int32_t                     data_kind;
+	int16_t                     channel_mapping[BeamformerMaxChannelCount];
+	int16_t                     sparse_elements[BeamformerMaxChannelCount];
+	uint8_t                     transmit_receive_orientations[BeamformerMaxChannelCount];
+	float                       focal_vectors[BeamformerMaxChannelCount][2];
+	BeamformerFilterParameters  filters[BeamformerFilterSlots];
+} OracleParameterBlock;
+
+/* beamformer_core.c:553-1013 with cooperative_matrix = 0, subgroup 64 */
+int  oracle_plan(const OracleParameterBlock *pb, OraclePlan *plan);
+/* beamformer_core.c:1519-1626 (+ lib .c:491-570 ingest): one whole frame, 16-channel
+ * chunks, ping-pong slots.  out: X*Y*Z float or float pair.  Returns 1 on success. */
+int  oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out,
+                     uint64_t *pairs_out, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
