@@ -1,0 +1,97 @@
+/* ogl_beamformer_hip.h -- MI355X-specific additions to the C ABI of ogl_beamformer_lib.h.
+ *
+ * Nothing here exists in the reference library.  These entry points expose what an
+ * in-process HIP backend can offer and the reference's shared-memory client cannot:
+ * device selection, running on the caller's stream, RF that is already on the device
+ * (e.g. landed by an RCCL broadcast over xGMI), sharding the output voxel grid across the
+ * GPUs of a node (one process per GPU), device-side access to frames,
+ * and per-stage timings taken with HIP events on the compute stream.
+ *
+ * Same conventions as ogl_beamformer_lib.h: returns 1 on success, 0 on failure with the
+ * reason in beamformer_get_last_error().
+ */
+#ifndef OGL_BEAMFORMER_HIP_H
+#define OGL_BEAMFORMER_HIP_H
+
+#include "ogl_beamformer_lib.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Select the HIP device the library owns.  Must precede the first call that touches the
+ * device; afterwards it only succeeds for the device already in use.  Default: the value
+ * of BEAMFORMER_HIP_DEVICE, else LOCAL_RANK, else 0. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_device(int32_t device_index);
+BEAMFORMER_LIB_EXPORT int32_t  beamformer_hip_get_device(void);
+
+/* Run all work on the caller's stream (a hipStream_t; 0 restores the library's own
+ * stream).  Lets a host framework order its own device work (an RCCL broadcast of the RF
+ * frame, a consumer of the image) against the beamformer without host synchronisation. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_stream(void *hip_stream);
+
+/* Restrict the frames computed from a parameter block to the z-planes
+ * [z_first, z_first + z_count) of its output grid; z_count == 0 restores the whole grid.
+ * Voxel coordinates are still normalised by the WHOLE grid (das.glsl:374-376), so the planes
+ * of a shard are bit-identical to the same planes of an unsharded frame.  Frames of a
+ * sharded block hold X*Y*z_count voxels. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_output_shard(uint32_t parameter_slot,
+                                                               uint32_t z_first, uint32_t z_count);
+
+/* beamformer_push_data_with_compute() for RF that already resides on the library's device
+ * (same layout and size rules).  The copy out of `device_data` is ordered on the library's
+ * current stream; the caller may reuse the buffer once work it enqueues later on that
+ * stream runs, or after beamformer_hip_synchronize(). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_push_device_data_with_compute(const void *device_data, uint32_t size,
+                                                                            uint32_t image_plane_tag,
+                                                                            uint32_t parameter_slot);
+
+/* Block until every queued frame is complete. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_synchronize(void);
+
+typedef struct {
+	void    *device_pointer;    /* valid until the frame ring wraps over it */
+	uint64_t size_bytes;        /* rounded up to 64, as exported by beamformer_get_last_frames */
+	uint32_t points[3];         /* x, y, z (z = shard planes) */
+	uint32_t data_kind;         /* BeamformerDataKind_Float32 or _Float32Complex */
+	uint32_t frame_id;
+	uint32_t parameter_block;
+} BeamformerHipFrameInfo;
+/* The newest frame, in place on the device (no copy, no synchronisation). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_info(BeamformerHipFrameInfo *out);
+
+#define BEAMFORMER_HIP_MAX_TIMED_STAGES 24
+typedef struct {
+	uint32_t stage_count;
+	uint32_t stage_kind[BEAMFORMER_HIP_MAX_TIMED_STAGES];  /* BeamformerShaderKind; ingest = 0xFFFF */
+	float    stage_ms[BEAMFORMER_HIP_MAX_TIMED_STAGES];    /* hipEvent pairs on the compute stream */
+	float    frame_ms;                                     /* first event to last event */
+	uint64_t das_pairs;        /* (voxel, channel, transmit) triples passing the apodization
+	                              test; counted only when pair counting is enabled */
+	uint64_t das_voxels;
+	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
+	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
+	uint32_t das_path;         /* 0 general kernel, 1 separable-delay fast path */
+} BeamformerHipFrameTimings;
+/* Timings of the newest frame; waits for it to finish. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
+
+/* When enabled, every frame also runs a geometry-only kernel that counts the triples that
+ * pass the apodization test (G in BASELINE.md section 4).  Off by default. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_pair_counting(uint32_t enable);
+
+/* min and max over the newest frame of |v| (complex) or v (real).  Build-defined: the
+ * reference's shaders/min_max.glsl is dead code (beamformer_core.c:632-637). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_frame_min_max(float out_min_max[2]);
+
+/* Select the DAS implementation: 0 = automatic (fast path when the geometry allows),
+ * 1 = always the general kernel.  For parity testing of both paths. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
+
+/* Free every device resource; the next call re-initialises. */
+BEAMFORMER_LIB_EXPORT void beamformer_hip_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGL_BEAMFORMER_HIP_H */

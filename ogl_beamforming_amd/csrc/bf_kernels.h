@@ -1,0 +1,112 @@
+/* bf_kernels.h -- launch interface between the host executor (C++) and the gfx950 kernels.
+ * Plain structs passed by value as kernel arguments: they replace the reference's Vulkan
+ * specialization constants ("Bake" structs, generated/beamformer.c:176-249) and push
+ * constants (generated/beamformer.c:251-279). */
+#ifndef BF_KERNELS_H
+#define BF_KERNELS_H
+
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+/* generated/beamformer.c:489-521 */
+static const int bf_kind_byte_size[6]     = {2, 4, 4, 8, 2, 4};
+static const int bf_kind_element_size[6]  = {2, 2, 4, 4, 2, 2};
+static const int bf_kind_element_count[6] = {1, 2, 1, 2, 1, 2};
+static const int bf_kind_complex[6]       = {0, 1, 0, 1, 0, 1};
+enum { BF_BASE_I16 = 0, BF_BASE_F32 = 1, BF_BASE_F16 = 2 };
+static const int bf_kind_base[6] = {BF_BASE_I16, BF_BASE_I16, BF_BASE_F32, BF_BASE_F32, BF_BASE_F16, BF_BASE_F16};
+
+/* per-transmit constants prepared on the host from focal_vectors / orientations
+ * (das.glsl:172-202): 32 bytes each, read through wave-uniform (scalar) loads */
+typedef struct {
+	float    sin_a, cos_a;       /* of the steering angle */
+	float    focus_x, focus_z;   /* focal_depth * (sin, cos); unused for plane waves */
+	uint32_t flags;              /* BF_TX_* */
+	float    pad[3];
+} BfTransmit;
+enum {
+	BF_TX_ROWS    = 1u << 0,   /* transmit orientation == Rows (project on y,z) */
+	BF_RX_ROWS    = 1u << 1,   /* receive  orientation == Rows */
+	BF_TX_NONE    = 1u << 2,   /* transmit orientation == None: distance 0 */
+	BF_TX_PLANE   = 1u << 3,   /* focal depth is +-inf */
+	BF_RX_COLUMNS = 1u << 4,   /* receive orientation == Columns (HERCULES test, das.glsl:238) */
+};
+
+enum { BF_DAS_RCA = 0, BF_DAS_HERCULES = 1, BF_DAS_FORCES = 2, BF_DAS_READI = 3 };
+
+typedef struct {
+	float xdc_transform[16];
+	float voxel_transform[16];
+	float pitch[2];
+	const void       *rf;             /* [channel][transmit][sample], float or float2 */
+	void             *out;            /* float or float2 per voxel of the shard */
+	const BfTransmit *transmits;      /* [acquisition_count] */
+	const int16_t    *sparse_elements;
+	const uint16_t   *readi_hadamard; /* binary16 bits, G*G */
+	unsigned long long *pair_counter; /* COUNT kernels only */
+	int32_t  family, interpolation, complex_data, coherency_weighting;
+	int32_t  acquisition_count, channel_count, sample_count, sparse;
+	float    sampling_frequency, inv_sampling_frequency, demodulation_frequency;
+	float    inv_speed_of_sound, time_offset, f_number;
+	uint32_t size[3];                 /* whole output grid */
+	uint32_t z_first, z_count;        /* shard of the grid computed by this launch */
+	uint32_t readi_group_count, readi_group;
+	uint32_t tile_shift[3];           /* log2 of the 256-thread block's extent per axis */
+	uint32_t blocks[3];               /* blocks per axis */
+} BfDasArgs;
+
+typedef struct {
+	const void *raw; void *out;
+	const int16_t *channel_mapping;   /* device, [channels] */
+	uint64_t in_row_bytes, out_row_bytes;
+	uint32_t channels;
+	int32_t  a1s2, base;              /* A1S2 contrast reduction on BF_BASE_* scalars */
+	uint32_t a1s2_scalars;            /* sample_count * element_count */
+} BfIngestArgs;
+
+typedef struct {
+	const void *left, *right; void *out;
+	uint32_t size[3];
+	int64_t  in_stride[3], out_stride[3];
+	int32_t  in_kind, out_kind, interleave;
+} BfReshapeArgs;
+
+typedef struct {
+	const void *in; void *out;
+	const float *hadamard_t;          /* T*T floats, transposed on the host: HtT[T*i + j] = Ht[T*j + i] */
+	uint32_t transmit_count, channel_count, sample_count;
+	int64_t  out_stride[3];           /* sample, channel, transmit */
+	int32_t  in_kind, out_kind;
+} BfDecodeArgs;
+
+typedef struct {
+	const void *in; void *out;
+	const float *coefficients;
+	const int16_t *channel_mapping;   /* unused (ingest owns the mapping) */
+	uint32_t filter_length, decimation, sample_count, batch_sample_count;
+	int32_t  complex_filter, demodulate;
+	float    sampling_frequency, demodulation_frequency;
+	int64_t  in_stride[3], out_stride[3];
+	int64_t  in_elements;
+	uint32_t channels, transmits;
+	int32_t  in_kind, out_kind;
+} BfFilterArgs;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* every launcher returns the hipError_t of the launch; nothing synchronises */
+hipError_t bf_launch_ingest(const BfIngestArgs *a, hipStream_t s);
+hipError_t bf_launch_reshape(const BfReshapeArgs *a, hipStream_t s);
+hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s);
+hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s);
+hipError_t bf_launch_das(const BfDasArgs *a, hipStream_t s);
+hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s);
+/* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
+ * 2*1024 floats */
+hipError_t bf_launch_min_max(const void *frame, uint64_t voxels, int complex_data,
+                             float *scratch, float *out2, hipStream_t s);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+/* context.h -- process-global state of the in-process HIP beamformer.
+ *
+ * Stands where the reference has a server process: BeamformerCtx / BeamformerComputeContext
+ * (beamformer_internal.h:386-470) reached through BeamformerSharedMemory
+ * (beamformer_shared_memory.c:133-166).  Here the "server" is this library: parameter
+ * blocks are plain host structs, the RF ring, the ping-pong buffers and the frame ring are
+ * HIP device allocations, timelines are stream order + HIP events. */
+#ifndef BF_CONTEXT_H
+#define BF_CONTEXT_H
+
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "planner.h"
+#include "bf_kernels.h"
+#include "../../include/ogl_beamformer_hip.h"
+
+namespace bf {
+
+struct DeviceBuffer {
+	void  *ptr  = nullptr;
+	size_t size = 0;
+	bool ensure(size_t bytes);      /* grows (never shrinks); false on allocation failure */
+	void release();
+};
+
+/* beamformer_internal.h:413-422 (BeamformerFrame / backlog) */
+struct FrameRecord {
+	uint64_t offset = 0, bytes = 0;
+	uint32_t points[3]{1, 1, 1};
+	int      data_kind = BeamformerDataKind_Float32;
+	uint32_t id = 0, block = 0;
+	int      timing_slot = -1;
+};
+
+struct TimingSlot {
+	hipEvent_t events[BEAMFORMER_HIP_MAX_TIMED_STAGES + 1]{};
+	uint32_t   kinds[BEAMFORMER_HIP_MAX_TIMED_STAGES]{};
+	uint32_t   count = 0;
+	bool       created = false, used = false;
+	uint64_t   das_voxels = 0;
+	uint32_t   das_taps = 0, das_sample_bytes = 0, das_path = 0;
+	bool       counted = false;
+	uint64_t   frame_id = 0;
+};
+
+struct PlanState {
+	Plan         plan;
+	bool         valid = false;
+	DeviceBuffer hadamard_t, readi_hadamard, transmits, sparse, mapping;
+	std::vector<DeviceBuffer> taps;     /* per stage */
+	std::vector<BfTransmit>   transmit_table;
+	std::vector<uint16_t>     readi_bits;
+	std::string  error;
+};
+
+constexpr uint32_t kTimingSlots = 32;    /* beamformer_compute_stats.c: 32-frame table */
+constexpr uint32_t kStageIngest    = 0xFFFF;
+constexpr uint32_t kStagePairCount = 0xFFFE;
+
+struct Context {
+	/* library-level state that needs no device */
+	BeamformerLibErrorKind last_error = BeamformerLibErrorKind_None;
+	int32_t        timeout_ms = 0;
+	ParameterBlock blocks[BeamformerMaxParameterBlocks];
+	uint32_t       reserved_parameter_blocks = 1;              /* beamformer.c:249-263 */
+	BeamformerLiveImagingParameters live{};
+	uint32_t       live_dirty_flags = 0;
+	uint64_t       frame_ring_bytes = 0;                       /* beamformed_frame_buffer_size */
+	uint32_t       das_path_mode = 0;
+	bool           count_pairs = false;
+
+	/* device state */
+	int          requested_device = -1;
+	int          device = -1;
+	bool         device_ready = false;
+	hipStream_t  own_stream = nullptr, stream = nullptr;
+	PlanState    plans[BeamformerMaxParameterBlocks];
+	DeviceBuffer raw_staging;
+	DeviceBuffer rf[BeamformerMaxRawDataFramesInFlight];     /* beamformer.meta:8: 3 in flight */
+	uint64_t     rf_index = 0;
+	DeviceBuffer scratch[2];                                   /* ping-pong (reference: 3 slots of one buffer) */
+	DeviceBuffer ring;                                         /* frame ring ("BeamformedData") */
+	uint64_t     ring_next_offset = 0, frame_counter = 0;
+	std::vector<FrameRecord> frames;                           /* BeamformerMaxBacklogFrames records */
+	TimingSlot   timing[kTimingSlots];
+	DeviceBuffer pair_counter, minmax_scratch;
+	hipEvent_t   last_rf_event = nullptr;
+	std::vector<float> rf_time_deltas;
+	double       last_push_time = 0;
+};
+
+Context &ctx();
+bool     set_error(BeamformerLibErrorKind kind);   /* records and returns false */
+
+/* executor.cpp */
+bool ensure_device();                               /* SharedMemory error when no HIP device */
+uint64_t default_frame_ring_bytes();
+bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool data_on_device);
+bool wait_for_frames(int32_t timeout_ms);
+bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms);
+bool last_frame_timings(BeamformerHipFrameTimings *out);
+bool fill_stats_table(BeamformerComputeStatsTable *out);
+bool frame_min_max(float out[2]);
+void shutdown_device();
+
+} // namespace bf
+#endif

@@ -1,0 +1,424 @@
+/* das.hip -- delay-and-sum for gfx950 (MI355X), general path.
+ *
+ * Replaces shaders/das.glsl of the reference (main :368-407, RCA :204-231, HERCULES
+ * :233-286, FORCES :288-321, READI_FORCES :323-366, sample_rf :99-124, cubic :67-97,
+ * rotate_iq :54-61, apodize :138-152) and the DAS leg of do_compute_shader
+ * (beamformer_core.c:1353-1369).
+ *
+ * Differences in structure (results agree within the float tolerance stated in
+ * tests/test_gpu_parity.py):
+ *   - ONE launch covers every receive channel; the reference launches the whole volume
+ *     once per 16-channel chunk and read-modify-writes the frame channel_count/16 times
+ *     (beamformer_core.c:1604-1614).  Here each voxel is written exactly once, so the
+ *     frame and incoherent clears (beamformer_core.c:1573-1585) disappear too.
+ *   - coherency weighting (coherency_weighting.glsl:28-37) is the epilogue of this kernel;
+ *     the incoherent sum never reaches HBM.
+ *   - per-transmit trigonometry is hoisted to a host-prepared BfTransmit table that the
+ *     wave reads through scalar loads.
+ *   - a 256-thread block covers a tile that is one voxel thick along the axis with the
+ *     steepest delay gradient (chosen by the host), so that the 64 lanes of a wave gather
+ *     neighbouring RF samples of one (channel, transmit) row: a few 128-B lines per
+ *     wave-instruction instead of 64.
+ *   - wave64 throughout; transcendental work uses the hardware's turn-based v_sin/v_cos
+ *     with the argument reduced by v_fract (Q3 in oracle/oracle.h).
+ * The gather-accumulate is memory/VALU bound: no MFMA.
+ */
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "bf_kernels.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+/* gathers are only element aligned: 8 B for complex, 4 B for real samples */
+typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
+typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
+
+template <bool CPLX> using sample_t = typename std::conditional<CPLX, f32x2, float>::type;
+
+#define BF_INTERP_NEAREST 0
+#define BF_INTERP_LINEAR  1
+#define BF_INTERP_CUBIC   2
+
+__device__ __forceinline__ float hw_sqrt(float x)      { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float hw_rcp(float x)       { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float hw_rsq(float x)       { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float hw_fract(float x)     { return __builtin_amdgcn_fractf(x); }
+__device__ __forceinline__ float hw_sin_turns(float x) { return __builtin_amdgcn_sinf(x); }   /* sin(2 pi x) */
+__device__ __forceinline__ float hw_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }   /* cos(2 pi x) */
+
+/* das.glsl:138-152: cos(pi a)^2 */
+__device__ __forceinline__ float apodize(float a)
+{
+	float c = hw_cos_turns(0.5f * a);
+	return c * c;
+}
+
+template <bool CPLX>
+__device__ __forceinline__ sample_t<CPLX> zero_sample()
+{
+	if constexpr (CPLX) return f32x2{0.f, 0.f}; else return 0.f;
+}
+
+/* byte offset arithmetic stays in 32 bits: the largest DAS input (256 ch x 256 tx x 8192
+ * complex samples) is 4 GiB - that case is rejected by the host */
+template <typename T>
+__device__ __forceinline__ T gather(const char *rf, uint32_t byte_offset)
+{
+	return *reinterpret_cast<const T *>(rf + byte_offset);
+}
+
+/* das.glsl:54-61 with the angle in turns, reduced to [0,1) */
+__device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const BfDasArgs &p)
+{
+	float turns = hw_fract(p.demodulation_frequency * (index * p.inv_sampling_frequency));
+	float c = hw_cos_turns(turns), s = hw_sin_turns(turns);
+	return f32x2{c * iq.x - s * iq.y, s * iq.x + c * iq.y};
+}
+
+/* das.glsl:99-124 (+ cubic :67-97).  rf_offset is an element index, already decremented by
+ * one for cubic (das.glsl:215). */
+template <int INTERP, bool CPLX>
+__device__ __forceinline__ sample_t<CPLX> sample_rf(const char *rf, int rf_offset, float index, const BfDasArgs &p)
+{
+	constexpr uint32_t ES = CPLX ? 8 : 4;
+	sample_t<CPLX> result = zero_sample<CPLX>();
+	const float S = (float)p.sample_count;
+	if constexpr (INTERP == BF_INTERP_NEAREST) {
+		if (index >= 0.f && index < S - 0.5f) {
+			int k = (int)__builtin_roundf(index);
+			result = gather<sample_t<CPLX>>(rf, (uint32_t)(rf_offset + k) * ES);
+			if constexpr (CPLX) result = rotate_iq(result, index, p);
+		}
+	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+		if (index >= 0.f && index < S - 1.f) {
+			float tk = __builtin_floorf(index), t = index - tk;
+			uint32_t off = (uint32_t)(rf_offset + (int)tk) * ES;
+			if constexpr (CPLX) {
+				f32x4 v = gather<f32x4_a8>(rf, off);
+				f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+				result = (1.f - t) * a + t * b;
+				result = rotate_iq(result, index, p);
+			} else {
+				f32x2 v = gather<f32x2_a4>(rf, off);
+				result = (1.f - t) * v.x + t * v.y;
+			}
+		}
+	} else {
+		if (index >= 1.f && index < S - 2.f) {
+			float tk = __builtin_floorf(index), t = index - tk;
+			uint32_t off = (uint32_t)(rf_offset + (int)tk) * ES;
+			float t2 = t * t, t3 = t2 * t;
+			/* Hermite basis with tangents 0.5 (P2 - P0), 0.5 (P3 - P1) */
+			float b0 =  2.f * t3 - 3.f * t2 + 1.f;
+			float b1 = -2.f * t3 + 3.f * t2;
+			float b2 =        t3 - 2.f * t2 + t;
+			float b3 =        t3 -       t2;
+			if constexpr (CPLX) {
+				f32x4 lo = gather<f32x4_a8>(rf, off), hi = gather<f32x4_a8>(rf, off + 16);
+				f32x2 s0 = {lo.x, lo.y}, s1 = {lo.z, lo.w}, s2 = {hi.x, hi.y}, s3 = {hi.z, hi.w};
+				f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1);
+				result = b0 * s1 + b1 * s2 + b2 * T1 + b3 * T2;
+				result = rotate_iq(result, index, p);
+			} else {
+				f32x4 v = gather<f32x4_a4>(rf, off);
+				float T1 = 0.5f * (v.z - v.x), T2 = 0.5f * (v.w - v.y);
+				result = b0 * v.y + b1 * v.z + b2 * T1 + b3 * T2;
+			}
+		}
+	}
+	return result;
+}
+
+template <bool CPLX, bool CW, bool COUNT>
+struct Accumulator {
+	sample_t<CPLX> coherent;
+	float          incoherent;
+	unsigned long long pairs;
+	__device__ __forceinline__ void init() { coherent = zero_sample<CPLX>(); incoherent = 0.f; pairs = 0; }
+	/* RESULT_STORE (das.glsl:28-32) */
+	__device__ __forceinline__ void add(sample_t<CPLX> v)
+	{
+		coherent += v;
+		if constexpr (CW) {
+			if constexpr (CPLX) incoherent += hw_sqrt(v.x * v.x + v.y * v.y);
+			else                incoherent += __builtin_fabsf(v);
+		}
+	}
+};
+
+__device__ __forceinline__ void m4_point(const float *m, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+	ox = m[0] * x + m[4] * y + m[8]  * z + m[12];
+	oy = m[1] * x + m[5] * y + m[9]  * z + m[13];
+	oz = m[2] * x + m[6] * y + m[10] * z + m[14];
+}
+
+/* das.glsl:187-202 with the per-transmit constants precomputed */
+__device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx, float wy, float wz)
+{
+	float result = 0.f;
+	if (!(t.flags & BF_TX_NONE)) {
+		float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+		if (t.flags & BF_TX_PLANE) {
+			result = px * t.sin_a + wz * t.cos_a;
+		} else {
+			float dx = px - t.focus_x, dz = wz - t.focus_z;
+			result = hw_sqrt(dx * dx + dz * dz);
+		}
+	}
+	return result;
+}
+
+/* das.glsl:126-130 */
+__device__ __forceinline__ float sample_index(float distance, const BfDasArgs &p)
+{
+	return (distance * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+}
+
+/* das.glsl:204-231 */
+template <int INTERP, bool CPLX, bool CW, bool COUNT>
+__device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, float wx, float wy, float wz,
+                                        Accumulator<CPLX, CW, COUNT> &acc)
+{
+	float xx, xy, xz;
+	m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+	const float inv_abs_z = hw_rcp(__builtin_fabsf(xz));
+	const float zz = xz * xz;
+
+	for (int acquisition = 0; acquisition < A; acquisition++) {
+		const BfTransmit t = p.transmits[acquisition];
+		const bool  rx_rows = (t.flags & BF_RX_ROWS) != 0;
+		const float lateral = rx_rows ? xy : xx;
+		const float pitch   = rx_rows ? p.pitch[1] : p.pitch[0];
+		const float tx_dist = transmit_distance(t, wx, wy, wz);
+		const float f_over_z = p.f_number * inv_abs_z;
+
+		int rf_offset = acquisition * S - (INTERP == BF_INTERP_CUBIC);
+		for (int channel = 0; channel < C; channel++) {
+			float dx    = lateral - (float)channel * pitch;
+			float a_arg = __builtin_fabsf(dx * f_over_z);
+			if (a_arg < 0.5f) {
+				if constexpr (COUNT) {
+					acc.pairs++;
+				} else {
+					float sidx = sample_index(tx_dist + hw_sqrt(dx * dx + zz), p);
+					acc.add(apodize(a_arg) * sample_rf<INTERP, CPLX>(rf, rf_offset, sidx, p));
+				}
+			}
+			rf_offset += S * A;
+		}
+	}
+}
+
+/* das.glsl:233-286 */
+template <int INTERP, bool CPLX, bool CW, bool COUNT>
+__device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf, float wx, float wy, float wz,
+                                             Accumulator<CPLX, CW, COUNT> &acc)
+{
+	float xx, xy, xz;
+	m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+	const int sparse = p.sparse != 0;
+	const BfTransmit t0 = p.transmits[0];
+	const bool  rx_cols = (t0.flags & BF_RX_COLUMNS) != 0;
+
+	const float transmit_index   = sample_index(transmit_distance(t0, wx, wy, wz), p);
+	const float z_delta_squared  = xz * xz;
+	const float f_number_over_z  = __builtin_fabsf(p.f_number * hw_rcp(xz));
+	const float apodization_test = 0.25f / (f_number_over_z * f_number_over_z);
+	const float fs_over_c        = p.sampling_frequency * p.inv_speed_of_sound;
+	const float first_weight     = hw_rsq((float)A);
+
+	for (int channel = 0; channel < C; channel++) {
+		int rf_offset = channel * S * A + sparse * S - (INTERP == BF_INTERP_CUBIC);
+		/* squared lateral distance to the receive element along the receive axis */
+		float rx_delta = rx_cols ? xx - (float)channel * p.pitch[0] : xy - (float)channel * p.pitch[1];
+		float rx_sq    = rx_delta * rx_delta;
+
+		for (int transmit = sparse; transmit < A; transmit++) {
+			float tx_channel = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
+			float tx_delta   = rx_cols ? xy - tx_channel * p.pitch[1] : xx - tx_channel * p.pitch[0];
+			float element_delta_squared = rx_cols ? rx_sq + tx_delta * tx_delta : tx_delta * tx_delta + rx_sq;
+			if (element_delta_squared < apodization_test) {
+				if constexpr (COUNT) {
+					acc.pairs++;
+				} else {
+					float apodization = (transmit == 0 ? first_weight : 1.0f)
+					                    * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
+					float index = transmit_index + hw_sqrt(z_delta_squared + element_delta_squared) * fs_over_c;
+					acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
+				}
+			}
+			rf_offset += S;
+		}
+	}
+}
+
+/* das.glsl:288-321 and :323-366.  (wx, wy, wz) is already in transducer space: the host
+ * pre-multiplies the voxel transform (beamformer_core.c:913-915). */
+template <int INTERP, bool CPLX, bool CW, bool COUNT, bool READI>
+__device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, float xx, float xy, float xz,
+                                           Accumulator<CPLX, CW, COUNT> &acc)
+{
+	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+	const int sparse = p.sparse != 0;
+	const float z_delta_squared     = xz * xz;
+	const float transmit_y_delta    = xy - p.pitch[1] * (float)C * 0.5f;
+	const float transmit_yz_squared = transmit_y_delta * transmit_y_delta + z_delta_squared;
+	const float fs_over_c           = p.sampling_frequency * p.inv_speed_of_sound;
+	const float f_over_z            = p.f_number * hw_rcp(xz);
+	const int   hadamard_offset     = (int)p.readi_group * (int)p.readi_group_count;
+
+	for (int channel = 0; channel < C; channel++) {
+		float receive_x_delta = xx - (float)channel * p.pitch[0];
+		float a_arg           = __builtin_fabsf(receive_x_delta * f_over_z);
+		if (!(a_arg < 0.5f)) continue;
+
+		float receive_index = sample_index(hw_sqrt(receive_x_delta * receive_x_delta + z_delta_squared), p);
+		float apodization   = COUNT ? 0.f : apodize(a_arg);
+
+		if constexpr (!READI) {
+			int rf_offset = channel * S * A + sparse * S - (INTERP == BF_INTERP_CUBIC);
+			for (int transmit = sparse; transmit < A; transmit++) {
+				if constexpr (COUNT) {
+					acc.pairs++;
+				} else {
+					float tx_channel       = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
+					float transmit_x_delta = xx - p.pitch[0] * tx_channel;
+					float transmit_index   = hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * fs_over_c;
+					acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, receive_index + transmit_index, p));
+				}
+				rf_offset += S;
+			}
+		} else {
+			int channel_rf_offset = channel * S * A - (INTERP == BF_INTERP_CUBIC);
+			for (int tx_group = 0; tx_group < (int)p.readi_group_count; tx_group++) {
+				_Float16 h = __builtin_bit_cast(_Float16, p.readi_hadamard[hadamard_offset + tx_group]);
+				float group_apodization = apodization * (float)h;
+				int   rf_offset = channel_rf_offset;
+				for (int tx_event = 0; tx_event < A; tx_event++) {
+					if constexpr (COUNT) {
+						acc.pairs++;
+					} else {
+						float tx_element       = (float)tx_group * (float)A + (float)tx_event;
+						float transmit_x_delta = xx - p.pitch[0] * tx_element;
+						float transmit_index   = hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * fs_over_c;
+						acc.add(group_apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, receive_index + transmit_index, p));
+					}
+					rf_offset += S;
+				}
+			}
+		}
+	}
+}
+
+/* das.glsl:368-407.  Grid: p.blocks[0]*p.blocks[1]*p.blocks[2] blocks of 256 threads; a
+ * block is a (1<<tile_shift[0]) x (1<<tile_shift[1]) x (1<<tile_shift[2]) voxel tile. */
+template <int FAMILY, int INTERP, bool CPLX, bool CW, bool COUNT>
+__global__ __launch_bounds__(256) void das_kernel(const BfDasArgs p)
+{
+	/* blockIdx -> tile: consecutive block ids go round-robin over the 8 XCDs, so ids that
+	 * share (id % 8) share an L2.  Deal the tile list out so that each XCD walks a
+	 * contiguous run of tiles (neighbouring tiles read neighbouring RF windows). */
+	uint32_t total  = p.blocks[0] * p.blocks[1] * p.blocks[2];
+	uint32_t bid    = blockIdx.x;
+	uint32_t per    = (total + 7u) / 8u;
+	uint32_t tile   = (bid & 7u) * per + (bid >> 3);
+	if (tile >= total) {
+		/* ragged tail: ids whose run is shorter map onto the unassigned remainder */
+		return;
+	}
+	uint32_t bx = tile % p.blocks[0];
+	uint32_t by = (tile / p.blocks[0]) % p.blocks[1];
+	uint32_t bz = tile / (p.blocks[0] * p.blocks[1]);
+
+	uint32_t tid = threadIdx.x;
+	uint32_t lx  = tid & ((1u << p.tile_shift[0]) - 1u);
+	uint32_t ly  = (tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u);
+	uint32_t lz  = tid >> (p.tile_shift[0] + p.tile_shift[1]);
+	uint32_t x = (bx << p.tile_shift[0]) + lx;
+	uint32_t y = (by << p.tile_shift[1]) + ly;
+	uint32_t zl = (bz << p.tile_shift[2]) + lz;       /* z inside the shard */
+	bool inside = x < p.size[0] && y < p.size[1] && zl < p.z_count;
+
+	Accumulator<CPLX, CW, COUNT> acc;
+	acc.init();
+	if (inside) {
+		uint32_t z = p.z_first + zl;
+		/* das.glsl:374-376 */
+		float px = (float)x / fmaxf(1.0f, (float)p.size[0] - 1.0f);
+		float py = (float)y / fmaxf(1.0f, (float)p.size[1] - 1.0f);
+		float pz = (float)z / fmaxf(1.0f, (float)p.size[2] - 1.0f);
+		float wx, wy, wz;
+		m4_point(p.voxel_transform, px, py, pz, wx, wy, wz);
+		const char *rf = (const char *)p.rf;
+
+		if constexpr (FAMILY == BF_DAS_RCA)           das_rca<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, acc);
+		else if constexpr (FAMILY == BF_DAS_HERCULES) das_hercules<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, acc);
+		else if constexpr (FAMILY == BF_DAS_FORCES)   das_forces<INTERP, CPLX, CW, COUNT, false>(p, rf, wx, wy, wz, acc);
+		else                                          das_forces<INTERP, CPLX, CW, COUNT, true>(p, rf, wx, wy, wz, acc);
+	}
+
+	if constexpr (COUNT) {
+		unsigned long long n = acc.pairs;
+		for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+		if ((tid & 63u) == 0 && n) atomicAdd(p.pair_counter, n);
+	} else if (inside) {
+		uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
+		sample_t<CPLX> v = acc.coherent;
+		/* coherency_weighting.glsl:36 with Scale = 1 (beamformer_core.c:949):
+		 * c *= c / incoherent, component-wise; incoherent == 0 gives NaN as in the reference */
+		if constexpr (CW) v = v * (v / acc.incoherent);
+		reinterpret_cast<sample_t<CPLX> *>(p.out)[out_index] = v;
+	}
+}
+
+template <int FAMILY, int INTERP, bool CPLX, bool CW, bool COUNT>
+static hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
+{
+	uint32_t total = a->blocks[0] * a->blocks[1] * a->blocks[2];
+	uint32_t grid  = ((total + 7u) / 8u) * 8u;
+	hipLaunchKernelGGL((das_kernel<FAMILY, INTERP, CPLX, CW, COUNT>), dim3(grid), dim3(256), 0, s, *a);
+	return hipGetLastError();
+}
+
+template <int FAMILY, int INTERP, bool COUNT>
+static hipError_t launch_kind(const BfDasArgs *a, hipStream_t s)
+{
+	if constexpr (COUNT) return launch_one<FAMILY, INTERP, false, false, true>(a, s);
+	else {
+		if (a->complex_data) return a->coherency_weighting ? launch_one<FAMILY, INTERP, true,  true,  false>(a, s)
+		                                                   : launch_one<FAMILY, INTERP, true,  false, false>(a, s);
+		else                 return a->coherency_weighting ? launch_one<FAMILY, INTERP, false, true,  false>(a, s)
+		                                                   : launch_one<FAMILY, INTERP, false, false, false>(a, s);
+	}
+}
+
+template <int FAMILY, bool COUNT>
+static hipError_t launch_interp(const BfDasArgs *a, hipStream_t s)
+{
+	if constexpr (COUNT) return launch_kind<FAMILY, BF_INTERP_NEAREST, true>(a, s);
+	else switch (a->interpolation) {
+	case BF_INTERP_NEAREST: return launch_kind<FAMILY, BF_INTERP_NEAREST, false>(a, s);
+	case BF_INTERP_LINEAR:  return launch_kind<FAMILY, BF_INTERP_LINEAR,  false>(a, s);
+	case BF_INTERP_CUBIC:   return launch_kind<FAMILY, BF_INTERP_CUBIC,   false>(a, s);
+	}
+	return hipErrorInvalidValue;
+}
+
+template <bool COUNT>
+static hipError_t launch_family(const BfDasArgs *a, hipStream_t s)
+{
+	switch (a->family) {
+	case BF_DAS_RCA:      return launch_interp<BF_DAS_RCA,      COUNT>(a, s);
+	case BF_DAS_HERCULES: return launch_interp<BF_DAS_HERCULES, COUNT>(a, s);
+	case BF_DAS_FORCES:   return launch_interp<BF_DAS_FORCES,   COUNT>(a, s);
+	case BF_DAS_READI:    return launch_interp<BF_DAS_READI,    COUNT>(a, s);
+	}
+	return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t bf_launch_das(const BfDasArgs *a, hipStream_t s)       { return launch_family<false>(a, s); }
+extern "C" hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s) { return launch_family<true>(a, s); }

@@ -1,0 +1,610 @@
+/* executor.cpp -- device side of the in-process beamformer: RF ingest, per-frame stage
+ * launches, frame ring, export, timings.
+ *
+ * Replaces the reference's two worker loops and their Vulkan plumbing:
+ *   beamformer_rf_upload        (beamformer_core.c:1756-1805)  -> push_rf_and_compute: one async
+ *                                                                H2D copy + the ingest kernel
+ *   complete_queue / Compute    (beamformer_core.c:1519-1677)  -> run_frame: stage launches in
+ *                                                                stream order, one pass over
+ *                                                                all channels
+ *   complete_queue / Export     (beamformer_core.c:1468-1509)  -> export_last_frames
+ *   beamformer_frame_next       (beamformer_core.c:440-466)    -> next_frame
+ *   gpu_command_timestamp + coalesce_timing_table
+ *                               (beamformer_core.c:1611-1655, :1683-1747) -> HIP event pairs
+ * There is no CPU fallback: without a HIP device every entry point fails with
+ * BeamformerLibErrorKind_SharedMemory.
+ */
+#include "context.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace bf {
+
+static Context g_context;
+Context &ctx() { return g_context; }
+
+bool set_error(BeamformerLibErrorKind kind)
+{
+	g_context.last_error = kind;
+	return false;
+}
+
+#define HIP_OK(expr) ((expr) == hipSuccess)
+
+bool DeviceBuffer::ensure(size_t bytes)
+{
+	if (bytes <= size && ptr) return true;
+	if (ptr) { (void)hipFree(ptr); ptr = nullptr; size = 0; }
+	if (bytes == 0) bytes = 64;
+	if (!HIP_OK(hipMalloc(&ptr, bytes))) { ptr = nullptr; return false; }
+	size = bytes;
+	return true;
+}
+
+void DeviceBuffer::release()
+{
+	if (ptr) (void)hipFree(ptr);
+	ptr = nullptr; size = 0;
+}
+
+static uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+/* beamformer.c:196-228 picks the first of {4, 2, 1.5, 1} GiB that fits half the device heap;
+ * on a 288 GB MI355X that is always 4 GiB, so the default needs no device query.
+ * BEAMFORMER_HIP_FRAME_RING_BYTES overrides it (before first use). */
+uint64_t default_frame_ring_bytes()
+{
+	if (const char *e = std::getenv("BEAMFORMER_HIP_FRAME_RING_BYTES")) {
+		unsigned long long v = std::strtoull(e, nullptr, 0);
+		if (v >= (1ull << 20)) return round_up(v, 64);
+	}
+	return 4ull << 30;
+}
+
+bool ensure_device()
+{
+	Context &c = g_context;
+	if (c.device_ready) {
+		if (!HIP_OK(hipSetDevice(c.device))) return set_error(BeamformerLibErrorKind_SharedMemory);
+		return true;
+	}
+	int count = 0;
+	if (!HIP_OK(hipGetDeviceCount(&count)) || count <= 0) return set_error(BeamformerLibErrorKind_SharedMemory);
+	int device = c.requested_device;
+	if (device < 0) {
+		const char *e = std::getenv("BEAMFORMER_HIP_DEVICE");
+		if (!e) e = std::getenv("LOCAL_RANK");
+		device = e ? std::atoi(e) : 0;
+	}
+	if (device < 0 || device >= count) return set_error(BeamformerLibErrorKind_SharedMemory);
+	if (!HIP_OK(hipSetDevice(device))) return set_error(BeamformerLibErrorKind_SharedMemory);
+	if (!HIP_OK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking)))
+		return set_error(BeamformerLibErrorKind_SharedMemory);
+	if (!c.stream) c.stream = c.own_stream;
+	if (!c.frame_ring_bytes) c.frame_ring_bytes = default_frame_ring_bytes();
+	if (!c.ring.ensure(c.frame_ring_bytes)) return set_error(BeamformerLibErrorKind_SharedMemory);
+	c.frames.assign(BeamformerMaxBacklogFrames, FrameRecord{});
+	c.device = device;
+	c.device_ready = true;
+	return true;
+}
+
+void shutdown_device()
+{
+	Context &c = g_context;
+	if (!c.device_ready) return;
+	(void)hipSetDevice(c.device);
+	(void)hipDeviceSynchronize();
+	for (auto &p : c.plans) {
+		p.hadamard_t.release(); p.readi_hadamard.release(); p.transmits.release();
+		p.sparse.release(); p.mapping.release();
+		for (auto &t : p.taps) t.release();
+		p.taps.clear(); p.valid = false;
+	}
+	c.raw_staging.release();
+	for (auto &b : c.rf) b.release();
+	for (auto &b : c.scratch) b.release();
+	c.ring.release(); c.pair_counter.release(); c.minmax_scratch.release();
+	for (auto &t : c.timing) {
+		if (t.created) for (auto &e : t.events) if (e) (void)hipEventDestroy(e);
+		t = TimingSlot{};
+	}
+	if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+	if (c.stream == c.own_stream) c.stream = nullptr;
+	c.own_stream = nullptr;
+	c.frames.clear();
+	c.ring_next_offset = 0; c.frame_counter = 0; c.rf_index = 0;
+	c.device_ready = false; c.device = -1;
+	for (auto &b : c.blocks) b.dirty |= Dirty_Parameters;   /* plans are rebuilt on next use */
+}
+
+static bool upload(DeviceBuffer &dst, const void *src, size_t bytes, hipStream_t s)
+{
+	if (!dst.ensure(bytes ? bytes : 64)) return false;
+	if (!bytes) return true;
+	return HIP_OK(hipMemcpyAsync(dst.ptr, src, bytes, hipMemcpyHostToDevice, s));
+}
+
+static uint16_t half_bits_pm1(float v) { return v < 0 ? 0xBC00 : 0x3C00; }   /* +-1 as binary16 */
+
+/* beamformer_commit_parameter_block (beamformer_core.c:1191-1287): replan when the block
+ * changed and refresh the device-side tables. */
+static PlanState *commit_block(uint32_t block)
+{
+	Context &c = g_context;
+	ParameterBlock &pb = c.blocks[block];
+	PlanState &ps = c.plans[block];
+	if (ps.valid && !pb.dirty) return &ps;
+
+	std::string error;
+	Plan plan;
+	if (!build_plan(pb, plan, error)) { ps.valid = false; ps.error = error; return nullptr; }
+	ps.plan = std::move(plan);
+	const BeamformerParameters &bp = pb.parameters;
+	hipStream_t s = c.stream;
+
+	/* a table a kernel of an earlier frame may still be reading must not be overwritten
+	 * under it: replanning is rare, so simply drain the stream first */
+	(void)hipStreamSynchronize(s);
+
+	bool ok = true;
+	ok &= upload(ps.mapping, pb.channel_mapping, sizeof(pb.channel_mapping), s);
+	ok &= upload(ps.sparse,  pb.sparse_elements, sizeof(pb.sparse_elements), s);
+
+	/* per-transmit constants (das.glsl:172-202) */
+	uint32_t A = bp.acquisition_count;
+	ps.transmit_table.assign(A, BfTransmit{});
+	for (uint32_t a = 0; a < A; a++) {
+		uint32_t txrx  = bp.single_orientation ? (bp.transmit_receive_orientation & 0xFFu) : pb.transmit_receive_orientations[a];
+		float    angle = bp.single_focus ? bp.focal_vector[0] : pb.focal_vectors[a][0];
+		float    depth = bp.single_focus ? bp.focal_vector[1] : pb.focal_vectors[a][1];
+		uint32_t tx = (txrx >> 4) & 0xF, rx = txrx & 0xF;
+		BfTransmit &t = ps.transmit_table[a];
+		float rad = angle * 0.017453292519943295f;               /* GLSL radians() */
+		t.sin_a = sinf(rad); t.cos_a = cosf(rad);
+		t.flags = 0;
+		if (tx == BeamformerRCAOrientation_None)    t.flags |= BF_TX_NONE;
+		if (tx == BeamformerRCAOrientation_Rows)    t.flags |= BF_TX_ROWS;
+		if (rx == BeamformerRCAOrientation_Rows)    t.flags |= BF_RX_ROWS;
+		if (rx == BeamformerRCAOrientation_Columns) t.flags |= BF_RX_COLUMNS;
+		if (std::isinf(depth)) { t.flags |= BF_TX_PLANE; t.focus_x = t.focus_z = 0; }
+		else                   { t.focus_x = depth * t.sin_a; t.focus_z = depth * t.cos_a; }
+	}
+	ok &= upload(ps.transmits, ps.transmit_table.data(), sizeof(BfTransmit) * A, s);
+
+	if (!ps.plan.hadamard_t.empty())
+		ok &= upload(ps.hadamard_t, ps.plan.hadamard_t.data(), sizeof(float) * ps.plan.hadamard_t.size(), s);
+	ps.readi_bits.clear();
+	for (float v : ps.plan.readi_hadamard) ps.readi_bits.push_back(half_bits_pm1(v));
+	if (!ps.readi_bits.empty())
+		ok &= upload(ps.readi_hadamard, ps.readi_bits.data(), sizeof(uint16_t) * ps.readi_bits.size(), s);
+
+	for (auto &t : ps.taps) t.release();
+	ps.taps.assign(ps.plan.stages.size(), DeviceBuffer{});
+	for (size_t i = 0; i < ps.plan.stages.size(); i++) {
+		const Stage &st = ps.plan.stages[i];
+		if (st.kind == BeamformerShaderKind_Filter || st.kind == BeamformerShaderKind_Demodulate)
+			ok &= upload(ps.taps[i], st.filter.taps.data(), sizeof(float) * st.filter.taps.size(), s);
+	}
+	if (ps.plan.intermediate_bytes) {
+		ok &= c.scratch[0].ensure(ps.plan.intermediate_bytes + 64);
+		ok &= c.scratch[1].ensure(ps.plan.intermediate_bytes + 64);
+	}
+	/* host vectors above must outlive the async copies out of pageable memory */
+	ok &= HIP_OK(hipStreamSynchronize(s));
+	if (!ok) { ps.valid = false; ps.error = "device allocation or upload failed"; return nullptr; }
+	pb.dirty = 0;
+	ps.valid = true;
+	return &ps;
+}
+
+/* beamformer_frame_next (beamformer_core.c:440-466) */
+static FrameRecord *next_frame(const uint32_t points[3], bool complex_frame, uint32_t block)
+{
+	Context &c = g_context;
+	int kind = complex_frame ? BeamformerDataKind_Float32Complex : BeamformerDataKind_Float32;
+	uint64_t bytes = round_up((uint64_t)points[0] * points[1] * points[2] * (uint64_t)bf_kind_byte_size[kind], 64);
+	if (bytes > c.ring.size) return nullptr;
+	if (c.ring_next_offset > c.ring.size - bytes) c.ring_next_offset = 0;
+	uint64_t id = c.frame_counter++;
+	FrameRecord *f = &c.frames[id % c.frames.size()];
+	f->offset = c.ring_next_offset; f->bytes = bytes;
+	f->points[0] = points[0]; f->points[1] = points[1]; f->points[2] = points[2];
+	f->data_kind = kind; f->id = (uint32_t)id; f->block = block;
+	c.ring_next_offset += bytes;
+	return f;
+}
+
+static uint32_t ceil_log2(uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; }
+
+/* Shape of the 256-voxel block of the DAS launch.  The axis along which the transducer-space
+ * depth changes fastest gets extent 1: sample indices move ~2 samples per voxel along depth
+ * but only a fraction of a sample per voxel laterally, so a depth-flat tile keeps the 64 lanes
+ * of a wave within a few cache lines of every (channel, transmit) row. */
+static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3])
+{
+	uint32_t extent[3] = {size[0], size[1], zcount};
+	uint32_t full[3]   = {size[0], size[1], size[2]};
+	int depth = -1; float best = -1;
+	for (int i = 0; i < 3; i++) {
+		if (extent[i] <= 1) continue;
+		float step = std::fabs(voxel_to_xdc[4 * i + 2]) / (float)(full[i] > 1 ? full[i] - 1 : 1);
+		if (step > best) { best = step; depth = i; }
+	}
+	uint32_t cap[3], left = 8;
+	for (int i = 0; i < 3; i++) { cap[i] = ceil_log2(extent[i]); shift[i] = 0; }
+	int lateral[2], nl = 0;
+	for (int i = 0; i < 3; i++) if (i != depth && extent[i] > 1) lateral[nl++] = i;
+	uint32_t first = nl == 2 ? 4 : 8;
+	for (int k = 0; k < nl; k++) {
+		uint32_t give = cap[lateral[k]] < first ? cap[lateral[k]] : first;
+		if (give > left) give = left;
+		shift[lateral[k]] = give; left -= give;
+	}
+	for (int k = 0; k < nl && left; k++) {
+		uint32_t room = cap[lateral[k]] - shift[lateral[k]];
+		uint32_t give = room < left ? room : left;
+		shift[lateral[k]] += give; left -= give;
+	}
+	if (depth >= 0 && left) {
+		uint32_t give = cap[depth] < left ? cap[depth] : left;
+		shift[depth] = give; left -= give;
+	}
+	shift[0] += left;   /* fewer than 256 voxels in total: idle lanes */
+}
+
+static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
+{
+	return HIP_OK(hipEventRecord(t.events[index], s));
+}
+
+static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
+{
+	Context &c = g_context;
+	PlanState *ps = commit_block(block);
+	if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
+	const Plan &plan = ps->plan;
+	const ParameterBlock &pb = c.blocks[block];
+	const BeamformerParameters &bp = pb.parameters;
+	hipStream_t s = c.stream;
+
+	TimingSlot &t = c.timing[c.frame_counter % kTimingSlots];
+	if (!t.created) {
+		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
+		t.created = true;
+	}
+	/* segment k of the frame is bracketed by events[k] and events[k+1]; events[0] was recorded
+	 * in front of the ingest by the caller when ingest_timed */
+	t.count = 0; t.used = true; t.counted = false;
+	auto segment = [&](uint32_t kind) {
+		if (t.count < BEAMFORMER_HIP_MAX_TIMED_STAGES) {
+			t.kinds[t.count++] = kind;
+			record(t, t.count, s);
+		}
+	};
+	if (ingest_timed) segment(kStageIngest);
+	else              record(t, 0, s);
+
+	const uint32_t C = plan.channels, A = plan.acquisitions, Sd = plan.das_samples;
+	const void *cur = c.rf[rf_slot].ptr;
+	int64_t cur_elements_bytes = (int64_t)c.rf[rf_slot].size;
+	int toggle = 0;
+	bool ok = true, das_segment_done = false;
+
+	for (size_t i = 0; i < plan.stages.size() && ok; i++) {
+		const Stage &st = plan.stages[i];
+		switch (st.kind) {
+		case BeamformerShaderKind_Reshape:{
+			BfReshapeArgs a{};
+			a.size[0] = Sd; a.size[1] = C; a.size[2] = A;                          /* beamformer_core.c:975-977 */
+			for (int k = 0; k < 3; k++) { a.in_stride[k] = st.in_stride[k]; a.out_stride[k] = st.out_stride[k]; }
+			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
+			a.interleave = !bf_kind_complex[st.in_kind] && bf_kind_complex[st.out_kind];
+			a.left  = cur;
+			a.right = (const char *)cur + (size_t)Sd * C * A * (size_t)bf_kind_byte_size[st.in_kind];   /* :1384-1385 */
+			a.out = c.scratch[toggle].ptr;
+			ok &= HIP_OK(bf_launch_reshape(&a, s));
+			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+		}break;
+		case BeamformerShaderKind_Decode:{
+			BfDecodeArgs a{};
+			a.in = cur; a.out = c.scratch[toggle].ptr;
+			a.hadamard_t = (const float *)ps->hadamard_t.ptr;
+			a.transmit_count = A; a.channel_count = C; a.sample_count = Sd;
+			for (int k = 0; k < 3; k++) a.out_stride[k] = st.out_stride[k];
+			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
+			ok &= HIP_OK(bf_launch_decode(&a, s));
+			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+		}break;
+		case BeamformerShaderKind_Filter:
+		case BeamformerShaderKind_Demodulate:{
+			bool demod = st.kind == BeamformerShaderKind_Demodulate;
+			BfFilterArgs a{};
+			a.in = cur; a.out = c.scratch[toggle].ptr;
+			a.coefficients   = (const float *)ps->taps[i].ptr;
+			a.filter_length  = (uint32_t)st.filter.length;
+			a.complex_filter = st.filter.complex_taps;
+			a.demodulate     = demod;
+			a.decimation     = demod ? plan.decimation : 1;                          /* :846 */
+			a.sample_count   = Sd;                                                  /* :845 */
+			bool deinterleave = bf_kind_complex[st.in_kind] && !bf_kind_complex[st.out_kind];
+			a.batch_sample_count = deinterleave ? C * Sd * A : 0;                   /* :848-851 */
+			if (demod) {                                                            /* :870-873 */
+				a.demodulation_frequency = bp.demodulation_frequency;
+				a.sampling_frequency     = bp.sampling_frequency / 2;
+			}
+			for (int k = 0; k < 3; k++) { a.in_stride[k] = st.in_stride[k]; a.out_stride[k] = st.out_stride[k]; }
+			a.in_elements = cur_elements_bytes / bf_kind_byte_size[st.in_kind];
+			a.channels = C; a.transmits = A;
+			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
+			ok &= HIP_OK(bf_launch_filter(&a, s));
+			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+		}break;
+		case BeamformerShaderKind_DAS:{
+			uint32_t zfirst = 0, zcount = plan.output_points[2];
+			if (pb.shard_z_count) { zfirst = pb.shard_z_first; zcount = pb.shard_z_count; }
+			uint32_t points[3] = {plan.output_points[0], plan.output_points[1], zcount};
+			FrameRecord *f = next_frame(points, plan.iq_pipeline, block);
+			if (!f) return set_error(BeamformerLibErrorKind_FrameSizeOverflow);
+			f->timing_slot = (int)(f->id % kTimingSlots);
+
+			BfDasArgs a{};
+			std::memcpy(a.xdc_transform,   bp.xdc_transform,         sizeof(a.xdc_transform));
+			std::memcpy(a.voxel_transform, plan.das_voxel_transform, sizeof(a.voxel_transform));
+			a.pitch[0] = bp.xdc_element_pitch[0]; a.pitch[1] = bp.xdc_element_pitch[1];
+			a.rf  = cur;
+			a.out = (char *)c.ring.ptr + f->offset;
+			a.transmits       = (const BfTransmit *)ps->transmits.ptr;
+			a.sparse_elements = (const int16_t *)ps->sparse.ptr;
+			a.readi_hadamard  = (const uint16_t *)ps->readi_hadamard.ptr;
+			switch (bp.acquisition_kind) {                                          /* das.glsl:381-400 */
+			case BeamformerAcquisitionKind_FORCES:
+			case BeamformerAcquisitionKind_UFORCES:
+				a.family = bp.readi_group_count > 1 ? BF_DAS_READI : BF_DAS_FORCES; break;
+			case BeamformerAcquisitionKind_HERCULES:
+			case BeamformerAcquisitionKind_UHERCULES:
+			case BeamformerAcquisitionKind_HERO_PA:
+				a.family = BF_DAS_HERCULES; break;
+			case BeamformerAcquisitionKind_Flash:
+			case BeamformerAcquisitionKind_RCA_TPW:
+			case BeamformerAcquisitionKind_RCA_VLS:
+				a.family = BF_DAS_RCA; break;
+			default: a.family = -1; break;      /* the shader leaves the voxel at zero */
+			}
+			a.interpolation = (int32_t)bp.interpolation_mode;
+			a.complex_data  = plan.iq_pipeline;
+			a.coherency_weighting = bp.coherency_weighting != 0;
+			a.acquisition_count = (int32_t)A; a.channel_count = (int32_t)C; a.sample_count = (int32_t)Sd;
+			a.sparse = plan.das_sparse;
+			a.sampling_frequency     = plan.das_sampling_frequency;
+			a.inv_sampling_frequency = 1.0f / plan.das_sampling_frequency;
+			a.demodulation_frequency = bp.demodulation_frequency;
+			a.inv_speed_of_sound     = 1.0f / bp.speed_of_sound;
+			a.time_offset = plan.das_time_offset;
+			a.f_number    = bp.f_number;
+			a.size[0] = plan.output_points[0]; a.size[1] = plan.output_points[1]; a.size[2] = plan.output_points[2];
+			a.z_first = zfirst; a.z_count = zcount;
+			a.readi_group_count = bp.readi_group_count; a.readi_group = bp.readi_group;
+
+			float to_xdc[16];
+			if (a.family == BF_DAS_FORCES || a.family == BF_DAS_READI) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
+			else m4_mul(bp.xdc_transform, plan.das_voxel_transform, to_xdc);
+			choose_tile(to_xdc, a.size, zcount, a.tile_shift);
+			uint32_t ext[3] = {a.size[0], a.size[1], zcount};
+			for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+
+			if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
+				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
+			} else {
+				ok &= HIP_OK(bf_launch_das(&a, s));
+				if (c.count_pairs) {
+					/* geometry-only recount of the apodization test; its own segment so that it
+					 * stays out of the DAS time */
+					ok &= c.pair_counter.ensure(sizeof(unsigned long long) * kTimingSlots);
+					a.pair_counter = (unsigned long long *)c.pair_counter.ptr + (f->id % kTimingSlots);
+					ok &= HIP_OK(hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned long long), s));
+					segment((uint32_t)st.kind);
+					ok &= HIP_OK(bf_launch_das_count(&a, s));
+					segment(kStagePairCount);
+					t.counted = true;
+					das_segment_done = true;
+				}
+			}
+			t.das_voxels = (uint64_t)ext[0] * ext[1] * ext[2];
+			t.das_taps = a.interpolation == 0 ? 1 : a.interpolation == 1 ? 2 : 4;
+			t.das_sample_bytes = plan.iq_pipeline ? 8 : 4;
+			t.das_path = 0; t.frame_id = f->id;
+		}break;
+		case BeamformerShaderKind_CoherencyWeighting:
+			/* fused into the DAS epilogue (das.hip); kept in the plan so that the stage list a
+			 * client sees through beamformer_compute_timings matches the reference's */
+			break;
+		default: break;
+		}
+		if (!(st.kind == BeamformerShaderKind_DAS && das_segment_done)) segment((uint32_t)st.kind);
+	}
+	if (!ok) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	return true;
+}
+
+/* lib .c:491-570 (client copy) + beamformer_core.c:1756-1805 (upload worker) */
+bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool data_on_device)
+{
+	Context &c = g_context;
+	ParameterBlock &pb = c.blocks[block];
+	const BeamformerParameters &bp = pb.parameters;
+	hipStream_t s = c.stream;
+
+	const uint64_t bytes   = (uint64_t)bf_kind_byte_size[pb.data_kind];
+	const uint64_t out_row = bytes * bp.sample_count * bp.acquisition_count;
+	const uint64_t in_row  = bytes * bp.raw_data_dimensions[0];
+	const uint64_t rf_size = out_row * bp.channel_count;
+
+	/* the reference copies whatever row the mapping names (lib .c:520-528); on a GPU an
+	 * out-of-range row would fault, so it is an error here */
+	bool identity = true;
+	for (uint32_t ch = 0; ch < bp.channel_count; ch++) {
+		uint16_t row = (uint16_t)pb.channel_mapping[ch];
+		if (row >= bp.raw_data_dimensions[1]) return set_error(BeamformerLibErrorKind_DataSizeMismatch);
+		identity &= row == ch;
+	}
+	bool a1s2 = bp.contrast_mode == BeamformerContrastMode_A1S2;
+
+	uint32_t slot = (uint32_t)(c.rf_index++ % BeamformerMaxRawDataFramesInFlight);
+	if (!c.rf[slot].ensure(round_up(rf_size, 64) + 64)) return set_error(BeamformerLibErrorKind_RFDataSizeOverflow);
+
+	TimingSlot &t = c.timing[c.frame_counter % kTimingSlots];
+	if (!t.created) {
+		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
+		t.created = true;
+	}
+	(void)hipEventRecord(t.events[0], s);
+
+	bool ok = true;
+	if (identity && !a1s2 && in_row == out_row) {
+		/* the mapped layout is the raw layout: one copy straight into the RF slot */
+		ok &= HIP_OK(hipMemcpyAsync(c.rf[slot].ptr, data, rf_size,
+		                            data_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+	} else {
+		const void *raw = data;
+		if (!data_on_device) {
+			if (!c.raw_staging.ensure(round_up(size, 64) + 64)) return set_error(BeamformerLibErrorKind_BufferOverflow);
+			ok &= HIP_OK(hipMemcpyAsync(c.raw_staging.ptr, data, size, hipMemcpyHostToDevice, s));
+			raw = c.raw_staging.ptr;
+		}
+		PlanState *ps = commit_block(block);
+		if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
+		BfIngestArgs a{};
+		a.raw = raw; a.out = c.rf[slot].ptr;
+		a.channel_mapping = (const int16_t *)ps->mapping.ptr;
+		a.in_row_bytes = in_row; a.out_row_bytes = out_row; a.channels = bp.channel_count;
+		a.a1s2 = a1s2; a.base = bf_kind_base[pb.data_kind];
+		a.a1s2_scalars = bp.sample_count * (uint32_t)bf_kind_element_count[pb.data_kind];
+		ok &= HIP_OK(bf_launch_ingest(&a, s));
+	}
+	if (!ok) return set_error(BeamformerLibErrorKind_InvalidAccess);
+
+	double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	if (c.last_push_time > 0) {
+		if (c.rf_time_deltas.size() >= 32) c.rf_time_deltas.erase(c.rf_time_deltas.begin());
+		c.rf_time_deltas.push_back((float)(now - c.last_push_time));
+	}
+	c.last_push_time = now;
+
+	return run_frame(block, slot, true);
+}
+
+/* the reference waits on futex locks with a timeout (lib .c:192-198, :679);
+ * (uint32_t)-1 blocks forever */
+bool wait_for_frames(int32_t timeout_ms)
+{
+	Context &c = g_context;
+	if (!c.device_ready) return true;
+	if (timeout_ms < 0) return HIP_OK(hipStreamSynchronize(c.stream)) || set_error(BeamformerLibErrorKind_InvalidAccess);
+	auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+	for (;;) {
+		hipError_t e = hipStreamQuery(c.stream);
+		if (e == hipSuccess) return true;
+		if (e != hipErrorNotReady) return set_error(BeamformerLibErrorKind_InvalidAccess);
+		if (std::chrono::steady_clock::now() >= deadline) return set_error(BeamformerLibErrorKind_SyncVariable);
+		std::this_thread::sleep_for(std::chrono::microseconds(50));
+	}
+}
+
+/* BeamformerExportKind_BeamformedData (beamformer_core.c:1474-1494) */
+bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms)
+{
+	Context &c = g_context;
+	if (!wait_for_frames(timeout_ms)) return false;
+	if (c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	uint64_t req = count < 1 ? 1 : count;
+	if (req > c.frame_counter) req = c.frame_counter;
+	if (req > c.frames.size()) req = c.frames.size();
+	uint64_t index = c.frame_counter - req, exported = 0;
+	bool ok = true;
+	for (uint64_t n = 0; n < req; n++, index++) {
+		const FrameRecord &f = c.frames[index % c.frames.size()];
+		if (exported + f.bytes <= out_size) {
+			ok &= HIP_OK(hipMemcpyAsync((char *)out + exported, (const char *)c.ring.ptr + f.offset, f.bytes,
+			                            hipMemcpyDeviceToHost, c.stream));
+			exported += f.bytes;
+		}
+	}
+	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+}
+
+bool last_frame_timings(BeamformerHipFrameTimings *out)
+{
+	Context &c = g_context;
+	std::memset(out, 0, sizeof(*out));
+	if (!c.device_ready || c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (!HIP_OK(hipStreamSynchronize(c.stream))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	TimingSlot &t = c.timing[(c.frame_counter - 1) % kTimingSlots];
+	out->stage_count = t.count;
+	for (uint32_t i = 0; i < t.count; i++) {
+		out->stage_kind[i] = t.kinds[i];
+		float ms = 0;
+		if (HIP_OK(hipEventElapsedTime(&ms, t.events[i], t.events[i + 1]))) out->stage_ms[i] = ms;
+	}
+	float total = 0;
+	if (t.count && HIP_OK(hipEventElapsedTime(&total, t.events[0], t.events[t.count]))) out->frame_ms = total;
+	out->das_voxels = t.das_voxels; out->das_taps = t.das_taps;
+	out->das_sample_bytes = t.das_sample_bytes; out->das_path = t.das_path;
+	if (t.counted && c.pair_counter.ptr) {
+		unsigned long long n = 0;
+		(void)hipMemcpy(&n, (unsigned long long *)c.pair_counter.ptr + ((c.frame_counter - 1) % kTimingSlots),
+		                sizeof(n), hipMemcpyDeviceToHost);
+		out->das_pairs = n;
+	}
+	return true;
+}
+
+/* BeamformerComputeStatsTable (beamformer_compute_stats.c:3-10) as coalesce_timing_table
+ * (beamformer_core.c:1683-1747) fills it: seconds per planned stage for the last 32 frames */
+bool fill_stats_table(BeamformerComputeStatsTable *out)
+{
+	Context &c = g_context;
+	std::memset(out, 0, sizeof(*out));
+	if (!c.device_ready || c.frame_counter == 0) return true;
+	if (!HIP_OK(hipStreamSynchronize(c.stream))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	uint64_t frames = c.frame_counter < kTimingSlots ? c.frame_counter : kTimingSlots;
+	for (uint64_t n = 0; n < frames; n++) {
+		uint64_t id = c.frame_counter - frames + n;
+		TimingSlot &t = c.timing[id % kTimingSlots];
+		uint32_t col = 0;
+		for (uint32_t i = 0; i < t.count; i++) {
+			if (t.kinds[i] == kStageIngest || t.kinds[i] == kStagePairCount) continue;
+			if (col >= BeamformerMaxComputeShaderStages) break;
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, t.events[i], t.events[i + 1]);
+			out->times[id % 32][col] = ms * 1e-3f;
+			if (n == frames - 1) out->shader_ids[col] = t.kinds[i];
+			col++;
+		}
+		if (n == frames - 1) out->shader_count = col;
+	}
+	for (size_t i = 0; i < c.rf_time_deltas.size() && i < 32; i++) out->rf_time_deltas[i] = c.rf_time_deltas[i];
+	return true;
+}
+
+bool frame_min_max(float out[2])
+{
+	Context &c = g_context;
+	if (!c.device_ready || c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	const FrameRecord &f = c.frames[(c.frame_counter - 1) % c.frames.size()];
+	if (!c.minmax_scratch.ensure(sizeof(float) * (2 * 1024 + 2))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	float *scratch = (float *)c.minmax_scratch.ptr;
+	uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
+	bool ok = HIP_OK(bf_launch_min_max((const char *)c.ring.ptr + f.offset, voxels,
+	                                   f.data_kind == BeamformerDataKind_Float32Complex, scratch + 2, scratch, c.stream));
+	ok &= HIP_OK(hipMemcpyAsync(out, scratch, 2 * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+}
+
+} // namespace bf

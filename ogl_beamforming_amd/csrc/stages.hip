@@ -1,0 +1,389 @@
+/* stages.hip -- the stages around DAS for gfx950: RF ingest (channel map + A1S2),
+ * Reshape, Hadamard Decode, Filter/Demodulate, frame min/max.
+ *
+ * Replaces lib/ogl_beamformer_lib.c:515-559 (the client's per-channel CPU copy),
+ * shaders/reshape.glsl, shaders/decode.glsl, shaders/filter.glsl of the reference and the
+ * matching legs of do_compute_shader (beamformer_core.c:1312-1351, :1378-1396).
+ * All kernels process every receive channel in one launch (no 16-channel chunk loop) and
+ * keep the reference's inter-stage element kinds (f16 staging where the reference stages in
+ * f16) so that results agree within the tolerances of tests/test_gpu_parity.py.
+ * These stages are bandwidth bound (< 2 % of a frame); no MFMA.
+ */
+#include <hip/hip_runtime.h>
+#include "bf_kernels.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+/* ------------------------------------------------------------------ element access */
+
+__device__ __forceinline__ f32x2 load_element(int kind, const void *buffer, int64_t index)
+{
+	f32x2 v = {0.f, 0.f};
+	switch (kind) {
+	case 0: v.x = (float)((const int16_t *)buffer)[index]; break;
+	case 1: { const int16_t *p = (const int16_t *)buffer + 2 * index; v.x = (float)p[0]; v.y = (float)p[1]; } break;
+	case 2: v.x = ((const float *)buffer)[index]; break;
+	case 3: v = ((const f32x2 *)buffer)[index]; break;
+	case 4: v.x = (float)((const _Float16 *)buffer)[index]; break;
+	case 5: { const _Float16 *p = (const _Float16 *)buffer + 2 * index; v.x = (float)p[0]; v.y = (float)p[1]; } break;
+	}
+	return v;
+}
+
+/* GLSL constructor conversion OutputDataType(value): float->int truncates, float->half RTE */
+__device__ __forceinline__ void store_scalar(int kind, void *buffer, int64_t scalar_index, float v)
+{
+	switch (kind >> 1) {            /* 0: int16, 1: float32, 2: float16 (kinds 0,1 / 2,3 / 4,5) */
+	case 0: ((int16_t *)buffer)[scalar_index]  = (int16_t)v; break;
+	case 1: ((float *)buffer)[scalar_index]    = v; break;
+	case 2: ((_Float16 *)buffer)[scalar_index] = (_Float16)v; break;
+	}
+}
+
+__device__ __forceinline__ void store_element(int kind, void *buffer, int64_t index, f32x2 v)
+{
+	if (kind & 1) { store_scalar(kind, buffer, 2 * index, v.x); store_scalar(kind, buffer, 2 * index + 1, v.y); }
+	else          { store_scalar(kind, buffer, index, v.x); }
+}
+
+/* ------------------------------------------------------------------ ingest */
+
+/* out[ch][0..out_row_bytes) = raw[channel_mapping[ch]][...]  (lib .c:519-529).
+ * V = bytes moved per lane per step. */
+template <typename V>
+__global__ __launch_bounds__(256) void ingest_copy_kernel(const BfIngestArgs a)
+{
+	uint32_t channel = blockIdx.y;
+	uint16_t row     = (uint16_t)a.channel_mapping[channel];
+	const V *in  = (const V *)((const char *)a.raw + a.in_row_bytes * row);
+	V       *out = (V *)((char *)a.out + a.out_row_bytes * channel);
+	uint64_t n   = a.out_row_bytes / sizeof(V);
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+		out[i] = in[i];
+}
+
+/* A1S2 contrast: out[s] = a[s] - b[s] - c[s] on the first n scalars of the row, the rest of
+ * the row is zero (lib .c:478-487, :553-556).  T arithmetic rounds per operation, as the
+ * reference's typed C loops do. */
+template <typename T>
+__global__ __launch_bounds__(256) void ingest_a1s2_kernel(const BfIngestArgs a)
+{
+	uint32_t channel = blockIdx.y;
+	uint16_t row     = (uint16_t)a.channel_mapping[channel];
+	const T *in  = (const T *)((const char *)a.raw + a.in_row_bytes * row);
+	T       *out = (T *)((char *)a.out + a.out_row_bytes * channel);
+	uint64_t total = a.out_row_bytes / sizeof(T);
+	uint32_t n     = a.a1s2_scalars;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+		T v = (T)0;
+		if (i < n) v = (T)((T)(in[i] - in[n + i]) - in[2 * (uint64_t)n + i]);
+		out[i] = v;
+	}
+}
+
+extern "C" hipError_t bf_launch_ingest(const BfIngestArgs *a, hipStream_t s)
+{
+	if (a->channels == 0 || a->out_row_bytes == 0) return hipSuccess;
+	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+	if (a->a1s2) {
+		uint64_t n = a->out_row_bytes / (a->base == BF_BASE_F32 ? 4 : 2);
+		dim3 grid((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), a->channels);
+		switch (a->base) {
+		case BF_BASE_I16: hipLaunchKernelGGL(ingest_a1s2_kernel<int16_t>,  grid, dim3(256), 0, s, *a); break;
+		case BF_BASE_F32: hipLaunchKernelGGL(ingest_a1s2_kernel<float>,    grid, dim3(256), 0, s, *a); break;
+		default:          hipLaunchKernelGGL(ingest_a1s2_kernel<_Float16>, grid, dim3(256), 0, s, *a); break;
+		}
+		return hipGetLastError();
+	}
+	uint64_t align = a->in_row_bytes | a->out_row_bytes | (uint64_t)(uintptr_t)a->raw | (uint64_t)(uintptr_t)a->out;
+	uint32_t v = (align % 16 == 0) ? 16 : (align % 4 == 0) ? 4 : 2;
+	uint64_t n = a->out_row_bytes / v;
+	dim3 grid((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), a->channels);
+	switch (v) {
+	case 16: hipLaunchKernelGGL(ingest_copy_kernel<u32x4>,    grid, dim3(256), 0, s, *a); break;
+	case 4:  hipLaunchKernelGGL(ingest_copy_kernel<uint32_t>, grid, dim3(256), 0, s, *a); break;
+	default: hipLaunchKernelGGL(ingest_copy_kernel<uint16_t>, grid, dim3(256), 0, s, *a); break;
+	}
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ reshape */
+
+/* reshape.glsl:61-82.  One thread per element; `order` lists the axes fastest first so
+ * that consecutive lanes walk the axis whose OUTPUT stride is 1.  Float16 data is IEEE
+ * half (quirk Q2). */
+struct ReshapeOrder { uint32_t axis[3]; };
+
+__global__ __launch_bounds__(256) void reshape_kernel(const BfReshapeArgs a, const ReshapeOrder order)
+{
+	uint64_t total = (uint64_t)a.size[0] * a.size[1] * a.size[2];
+	uint32_t n0 = a.size[order.axis[0]], n1 = a.size[order.axis[1]];
+	for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (uint64_t)gridDim.x * 256) {
+		uint32_t c[3];
+		c[order.axis[0]] = (uint32_t)(id % n0);
+		c[order.axis[1]] = (uint32_t)((id / n0) % n1);
+		c[order.axis[2]] = (uint32_t)(id / ((uint64_t)n0 * n1));
+		int64_t in_index  = a.in_stride[0]  * c[0] + a.in_stride[1]  * c[1] + a.in_stride[2]  * c[2];
+		int64_t out_index = a.out_stride[0] * c[0] + a.out_stride[1] * c[1] + a.out_stride[2] * c[2];
+		f32x2 v;
+		if (a.interleave) {
+			v.x = load_element(a.in_kind, a.left,  in_index).x;
+			v.y = load_element(a.in_kind, a.right, in_index).x;
+		} else {
+			v = load_element(a.in_kind, a.left, in_index);
+		}
+		store_element(a.out_kind, a.out, out_index, v);
+	}
+}
+
+extern "C" hipError_t bf_launch_reshape(const BfReshapeArgs *a, hipStream_t s)
+{
+	uint64_t total = (uint64_t)a->size[0] * a->size[1] * a->size[2];
+	if (!total) return hipSuccess;
+	ReshapeOrder order = {{0, 1, 2}};
+	int fast = 0;
+	for (int i = 0; i < 3; i++) if (a->out_stride[i] == 1 && a->size[i] > 1) fast = i;
+	order.axis[0] = (uint32_t)fast;
+	order.axis[1] = (uint32_t)((fast + 1) % 3);
+	order.axis[2] = (uint32_t)((fast + 2) % 3);
+	uint64_t blocks = (total + 255) / 256;
+	if (blocks > 65536) blocks = 65536;
+	hipLaunchKernelGGL(reshape_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *a, order);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ decode */
+
+/* decode.glsl:24-73 / :119-150: out[ch][i][s] = (1/T) sum_j in[s][ch][j] * Ht[T*j + i].
+ *
+ * Block = 64 consecutive samples of one channel; the 64 x T input tile is staged in LDS
+ * (rows padded by one element: lane s reads column j with stride T+1, conflict free).
+ * Wave w owns the outputs i = 4(w + 4g) .. +3; the four Hadamard rows it needs come from a
+ * host-transposed float copy HtT[i*T + j] through wave-uniform (scalar) loads, so the inner
+ * loop is one ds_read per 4 (real) or 8 (complex) v_fma.  Accumulation happens in the
+ * OUTPUT element type, as in the shader (OutputDataType result[]): f32, or f16 rounded
+ * after every operation when the planner leaves the output in half precision. */
+template <bool CPLX, bool ACC16>
+__global__ __launch_bounds__(256) void decode_kernel(const BfDecodeArgs a)
+{
+	const float *__restrict__ hadamard_t = a.hadamard_t;
+	extern __shared__ __attribute__((aligned(16))) float decode_lds[];
+	const uint32_t T = a.transmit_count, C = a.channel_count;
+	const uint32_t channel = blockIdx.y;
+	const uint32_t s0      = blockIdx.x * 64;
+	const uint32_t pitch   = T + 1;
+	constexpr uint32_t N   = CPLX ? 2 : 1;
+
+	for (uint32_t e = threadIdx.x; e < 64 * T; e += 256) {
+		uint32_t sl = e / T, j = e - sl * T;
+		uint32_t sample = s0 + sl;
+		f32x2 v = {0.f, 0.f};
+		if (sample < a.sample_count)
+			v = load_element(a.in_kind, a.in, ((int64_t)sample * C + channel) * T + j);
+		if (ACC16) { v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; }   /* OutputDataType(rf[j]) */
+		decode_lds[(sl * pitch + j) * N] = v.x;
+		if (CPLX) decode_lds[(sl * pitch + j) * N + 1] = v.y;
+	}
+	__syncthreads();
+
+	const uint32_t lane   = threadIdx.x & 63u;
+	const uint32_t wave   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t sample = s0 + lane;
+	const float   *x = decode_lds + (size_t)lane * pitch * N;
+
+	for (uint32_t i0 = wave * 4; i0 < T; i0 += 16) {
+		float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+		const float *h0 = hadamard_t + (size_t)(i0 + 0 < T ? i0 + 0 : 0) * T;
+		const float *h1 = hadamard_t + (size_t)(i0 + 1 < T ? i0 + 1 : 0) * T;
+		const float *h2 = hadamard_t + (size_t)(i0 + 2 < T ? i0 + 2 : 0) * T;
+		const float *h3 = hadamard_t + (size_t)(i0 + 3 < T ? i0 + 3 : 0) * T;
+		for (uint32_t j = 0; j < T; j++) {
+			float xr = x[j * N], xi = CPLX ? x[j * N + 1] : 0.f;
+			float h[4] = {h0[j], h1[j], h2[j], h3[j]};
+			#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				acc[k][0] += xr * h[k];
+				if (CPLX) acc[k][1] += xi * h[k];
+				if (ACC16) {
+					acc[k][0] = (float)(_Float16)acc[k][0];
+					if (CPLX) acc[k][1] = (float)(_Float16)acc[k][1];
+				}
+			}
+		}
+		if (sample < a.sample_count) {
+			#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				uint32_t i = i0 + k;
+				if (i >= T) break;
+				int64_t off = a.out_stride[1] * channel + a.out_stride[2] * i + a.out_stride[0] * sample;
+				f32x2 v = {acc[k][0] / (float)T, acc[k][1] / (float)T};
+				if (a.out_kind & 1) store_element(a.out_kind, a.out, off, v);
+				else                store_scalar(a.out_kind, a.out, off, v.x);
+			}
+		}
+	}
+}
+
+extern "C" hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s)
+{
+	if (!a->sample_count || !a->channel_count || !a->transmit_count) return hipSuccess;
+	bool cplx  = (a->in_kind & 1) != 0;
+	bool acc16 = (a->out_kind >> 1) == 2;
+	dim3 grid((a->sample_count + 63) / 64, a->channel_count);
+	size_t lds = (size_t)64 * (a->transmit_count + 1) * (cplx ? 8 : 4);
+	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	if (cplx) {
+		if (acc16) hipLaunchKernelGGL((decode_kernel<true,  true>),  grid, dim3(256), lds, s, *a);
+		else       hipLaunchKernelGGL((decode_kernel<true,  false>), grid, dim3(256), lds, s, *a);
+	} else {
+		if (acc16) hipLaunchKernelGGL((decode_kernel<false, true>),  grid, dim3(256), lds, s, *a);
+		else       hipLaunchKernelGGL((decode_kernel<false, false>), grid, dim3(256), lds, s, *a);
+	}
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ filter / demodulate */
+
+/* filter.glsl:68-135.  A wave owns one group of 64 outputs and its own LDS window of
+ * D*64 + L - 1 samples, exactly the shader's workgroup (the demodulation phase is indexed
+ * by the position inside that window, filter.glsl:99-107).  Four such groups share a
+ * 256-thread block.  F16 selects the shader's SAMPLE_TYPE (filter.glsl:2-14): binary16 for
+ * every 16-bit input kind, binary32 otherwise; products and sums are f32. */
+template <bool F16>
+__global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) float filter_lds[];
+	const uint32_t L = a.filter_length, D = a.decimation;
+	const uint32_t window = D * 64 + L - 1;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wg   = blockIdx.x * 4 + wave;                  /* the shader's gl_WorkGroupID.x */
+	const uint32_t channel = blockIdx.y, transmit = blockIdx.z;
+	float *w = filter_lds + (size_t)wave * window * 2;
+	const bool in_complex     = (a.in_kind & 1) != 0;
+	const bool complex_sample = in_complex || a.demodulate;          /* filter.glsl:16-19 */
+
+	const bool offset_wraps = (D * wg * 64) < (L - 1);             /* filter.glsl:79 */
+	int64_t row_start = a.in_stride[1] * channel + a.in_stride[2] * transmit;
+	if (a.demodulate) row_start /= 2;                               /* filter.glsl:81-87 */
+	const int64_t window_start = row_start + (int64_t)D * wg * 64 - (int64_t)(L - 1);
+
+	float scale = a.complex_filter ? 1.0f : __builtin_sqrtf(2.0f);   /* filter.glsl:98 */
+	if (F16) scale = (float)(_Float16)scale;
+
+	for (uint32_t index = lane; index < window; index += 64) {
+		f32x2 s = {0.f, 0.f};
+		int64_t e = window_start + index;
+		if ((!offset_wraps || index >= L - 1) && e >= 0 && e < a.in_elements) {
+			s = load_element(a.in_kind, a.in, e);
+			if (F16) { s.x = (float)(_Float16)s.x; s.y = (float)(_Float16)s.y; }
+			if (a.demodulate) {
+				/* s * (1,-1); rotate_iq (filter.glsl:57-64); * scale, all in SAMPLE_TYPE */
+				float arg = 6.28318530717958647692f * a.demodulation_frequency * (float)index / a.sampling_frequency;
+				float c = cosf(arg), sn = -sinf(arg);
+				f32x2 q = {s.x, -s.y};
+				f32x2 r = {c * q.x - sn * q.y, sn * q.x + c * q.y};
+				if (F16) {
+					_Float16 rx = (_Float16)r.x, ry = (_Float16)r.y, sc = (_Float16)scale;
+					s.x = (float)(_Float16)(sc * rx);
+					s.y = (float)(_Float16)(sc * ry);
+				} else {
+					s = scale * r;
+				}
+			}
+		}
+		w[2 * index] = s.x; w[2 * index + 1] = s.y;
+	}
+	__syncthreads();
+
+	const uint32_t out_sample = wg * 64 + lane;
+	if (out_sample < a.sample_count / D) {                            /* filter.glsl:115 */
+		f32x2 result = {0.f, 0.f};
+		const float *x = w + 2 * (size_t)(D * lane);
+		if (a.complex_filter && complex_sample) {
+			for (uint32_t j = 0; j < L; j++) {
+				float hr = a.coefficients[2 * j], hi = a.coefficients[2 * j + 1];
+				float xr = x[2 * j], xi = x[2 * j + 1];
+				result.x += hr * xr - hi * xi;
+				result.y += hi * xr + hr * xi;
+			}
+		} else {
+			const uint32_t hs = a.complex_filter ? 2 : 1;
+			for (uint32_t j = 0; j < L; j++) {
+				float h = a.coefficients[hs * j];
+				result.x += x[2 * j]     * h;
+				result.y += x[2 * j + 1] * h;
+			}
+		}
+		int64_t off = a.out_stride[1] * channel + a.out_stride[2] * transmit + a.out_stride[0] * out_sample;
+		if (a.batch_sample_count != 0) {                              /* filter.glsl:126-130 */
+			store_scalar(a.out_kind, a.out, off, result.x);
+			store_scalar(a.out_kind, a.out, off + a.batch_sample_count, result.y);
+		} else if (a.out_kind & 1) {
+			store_element(a.out_kind, a.out, off, result);
+		} else {
+			store_scalar(a.out_kind, a.out, off, result.x);
+		}
+	}
+}
+
+extern "C" hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s)
+{
+	if (!a->sample_count || !a->channels || !a->transmits) return hipSuccess;
+	uint32_t groups = (a->sample_count + 63) / 64;
+	dim3 grid((groups + 3) / 4, a->channels, a->transmits);
+	size_t lds = (size_t)4 * (a->decimation * 64 + a->filter_length - 1) * 2 * sizeof(float);
+	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	bool f16 = (a->in_kind >> 1) != 1;
+	if (f16) hipLaunchKernelGGL((filter_kernel<true>),  grid, dim3(256), lds, s, *a);
+	else     hipLaunchKernelGGL((filter_kernel<false>), grid, dim3(256), lds, s, *a);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ min / max */
+
+/* Build-defined reduction (the reference's shaders/min_max.glsl is never dispatched,
+ * beamformer_core.c:632-637): min and max over the frame of |v| (complex) or v (real).
+ * Two passes, no atomics: bitwise reproducible. */
+__global__ __launch_bounds__(256) void min_max_partial_kernel(const float *frame, uint64_t voxels, int cplx, float *scratch)
+{
+	float lo = __builtin_inff(), hi = -__builtin_inff();
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < voxels; i += (uint64_t)gridDim.x * 256) {
+		float v;
+		if (cplx) { f32x2 c = ((const f32x2 *)frame)[i]; v = __builtin_sqrtf(c.x * c.x + c.y * c.y); }
+		else      { v = frame[i]; }
+		lo = fminf(lo, v); hi = fmaxf(hi, v);
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		lo = fminf(lo, __shfl_xor(lo, off, 64));
+		hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+	}
+	__shared__ float slo[4], shi[4];
+	if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		scratch[2 * blockIdx.x]     = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+		scratch[2 * blockIdx.x + 1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+	}
+}
+
+__global__ __launch_bounds__(64) void min_max_final_kernel(const float *scratch, uint32_t n, float *out2)
+{
+	float lo = __builtin_inff(), hi = -__builtin_inff();
+	for (uint32_t i = threadIdx.x; i < n; i += 64) { lo = fminf(lo, scratch[2 * i]); hi = fmaxf(hi, scratch[2 * i + 1]); }
+	for (int off = 32; off > 0; off >>= 1) {
+		lo = fminf(lo, __shfl_xor(lo, off, 64));
+		hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+	}
+	if (threadIdx.x == 0) { out2[0] = lo; out2[1] = hi; }
+}
+
+extern "C" hipError_t bf_launch_min_max(const void *frame, uint64_t voxels, int complex_data,
+                                        float *scratch, float *out2, hipStream_t s)
+{
+	uint32_t blocks = (uint32_t)((voxels + 255) / 256 > 1024 ? 1024 : (voxels + 255) / 256);
+	if (!blocks) blocks = 1;
+	hipLaunchKernelGGL(min_max_partial_kernel, dim3(blocks), dim3(256), 0, s, (const float *)frame, voxels, complex_data, scratch);
+	hipLaunchKernelGGL(min_max_final_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, out2);
+	return hipGetLastError();
+}

@@ -1,0 +1,156 @@
+"""ctypes binding of libogl_beamformer_lib.so.
+
+This is the stub a maintainer of the reference would keep: the reference exposes its client
+library to Python through cffi over a preprocessed header (build.c:4798-4800); the function
+names, argument order and return conventions below are those of
+lib/ogl_beamformer_lib_base.h.  The library is the MI355X build in this repository; there
+is no CPU fallback -- loading fails loudly when the .so is missing, and compute calls fail
+with LibError.SharedMemory when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import params as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "libogl_beamformer_lib.so")
+
+
+class BeamformerError(RuntimeError):
+    def __init__(self, kind, message):
+        super().__init__(f"{P.LibError(kind).name}: {message}")
+        self.kind = P.LibError(kind)
+
+
+def _load():
+    if not os.path.exists(LIBRARY_PATH):
+        raise ImportError(
+            f"{LIBRARY_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU implementation to fall back to.")
+    lib = C.CDLL(LIBRARY_PATH)
+    u32, i32, u64, vp = C.c_uint32, C.c_int32, C.c_uint64, C.c_void_p
+    sig = {
+        "beamformer_get_api_version": (u32, []),
+        "beamformer_get_last_error": (i32, []),
+        "beamformer_get_last_error_string": (C.c_char_p, []),
+        "beamformer_error_string": (C.c_char_p, [i32]),
+        "beamformer_maximum_frames_for_parameters": (u64, [C.POINTER(P.Parameters)]),
+        "beamformer_maximum_frames_for_simple_parameters": (u64, [C.POINTER(P.SimpleParameters)]),
+        "beamformer_maximum_rf_data_size": (u64, []),
+        "beamformer_beamform_data": (u32, [C.POINTER(P.SimpleParameters), vp, u32, vp, i32]),
+        "beamformer_set_global_timeout": (None, [u32]),
+        "beamformer_push_data_with_compute": (u32, [vp, u32, u32, u32]),
+        "beamformer_get_last_frames": (u32, [vp, u64, u32]),
+        "beamformer_reserve_parameter_blocks": (u32, [u32]),
+        "beamformer_set_pipeline_stage_parameters": (u32, [u32, i32]),
+        "beamformer_set_pipeline_stage_parameters_at": (u32, [u32, i32, u32]),
+        "beamformer_push_pipeline": (u32, [C.POINTER(i32), u32, i32]),
+        "beamformer_push_pipeline_at": (u32, [C.POINTER(i32), u32, i32, u32]),
+        "beamformer_push_simple_parameters": (u32, [C.POINTER(P.SimpleParameters)]),
+        "beamformer_push_simple_parameters_at": (u32, [C.POINTER(P.SimpleParameters), u32]),
+        "beamformer_push_parameters": (u32, [C.POINTER(P.Parameters)]),
+        "beamformer_push_parameters_at": (u32, [C.POINTER(P.Parameters), u32]),
+        "beamformer_push_channel_mapping": (u32, [C.POINTER(C.c_int16), u32]),
+        "beamformer_push_channel_mapping_at": (u32, [C.POINTER(C.c_int16), u32, u32]),
+        "beamformer_push_sparse_elements": (u32, [C.POINTER(C.c_int16), u32]),
+        "beamformer_push_sparse_elements_at": (u32, [C.POINTER(C.c_int16), u32, u32]),
+        "beamformer_push_focal_vectors": (u32, [C.POINTER(C.c_float), u32]),
+        "beamformer_push_focal_vectors_at": (u32, [C.POINTER(C.c_float), u32, u32]),
+        "beamformer_push_transmit_receive_orientations": (u32, [C.POINTER(C.c_uint8), u32]),
+        "beamformer_push_transmit_receive_orientations_at": (u32, [C.POINTER(C.c_uint8), u32, u32]),
+        "beamformer_create_filter": (u32, [C.POINTER(P.FilterParameters), C.c_uint8, C.c_uint8]),
+        "beamformer_live_parameters_get_dirty_flag": (i32, []),
+        "beamformer_set_live_parameters": (u32, [C.POINTER(P.LiveImagingParameters)]),
+        "beamformer_get_live_parameters": (C.POINTER(P.LiveImagingParameters), []),
+        "beamformer_compute_timings": (u32, [C.POINTER(P.ComputeStatsTable), i32]),
+        # MI355X extensions (include/ogl_beamformer_hip.h)
+        "beamformer_hip_set_device": (u32, [i32]),
+        "beamformer_hip_get_device": (i32, []),
+        "beamformer_hip_set_stream": (u32, [vp]),
+        "beamformer_hip_set_output_shard": (u32, [u32, u32, u32]),
+        "beamformer_hip_push_device_data_with_compute": (u32, [vp, u32, u32, u32]),
+        "beamformer_hip_synchronize": (u32, []),
+        "beamformer_hip_get_last_frame_info": (u32, [C.POINTER(P.HipFrameInfo)]),
+        "beamformer_hip_get_last_frame_timings": (u32, [C.POINTER(P.HipFrameTimings)]),
+        "beamformer_hip_enable_pair_counting": (u32, [u32]),
+        "beamformer_hip_frame_min_max": (u32, [C.POINTER(C.c_float)]),
+        "beamformer_hip_set_das_path": (u32, [u32]),
+        "beamformer_hip_shutdown": (None, []),
+    }
+    for name, (restype, argtypes) in sig.items():
+        fn = getattr(lib, name)          # AttributeError: the library must export every symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    lib._signatures = sig
+    return lib
+
+
+_lib = None
+
+
+def library():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def exported_symbols():
+    """Names the headers under include/ declare (kept in step by tests/test_abi.py)."""
+    return sorted(library()._signatures)
+
+
+def last_error():
+    lib = library()
+    return P.LibError(lib.beamformer_get_last_error()), lib.beamformer_get_last_error_string().decode()
+
+
+def _check(result):
+    if not result:
+        kind, message = last_error()
+        raise BeamformerError(kind, message)
+    return result
+
+
+def frame_shape(bp):
+    pts = [max(1, int(v)) for v in bp.output_points[:3]]
+    return (pts[2], pts[1], pts[0])      # z slowest, x fastest (das.glsl:132-136)
+
+
+def output_is_complex(bp):
+    stages = list(bp.compute_stages[: bp.compute_stages_count])
+    return int(P.ShaderKind.Demodulate) in stages or P.DATA_KIND_COMPLEX[int(bp.data_kind)]
+
+
+def beamform(bp, rf, filters=(), timeout_ms=-1):
+    """One frame through the C ABI exactly as tests/throughput.c drives the reference:
+    create_filter* -> push_simple_parameters -> push_data_with_compute -> get_last_frames.
+    `rf` is a C-contiguous numpy array holding raw_data_dimensions[1] rows.  Returns the frame
+    as float32 or complex64 with shape (Z, Y, X)."""
+    lib = library()
+    for slot, fp in enumerate(filters):
+        if fp is not None:
+            _check(lib.beamformer_create_filter(C.byref(fp), slot, 0))
+    _check(lib.beamformer_push_simple_parameters(C.byref(bp)))
+    lib.beamformer_set_global_timeout(C.c_uint32(timeout_ms & 0xFFFFFFFF).value)
+    rf = np.ascontiguousarray(rf)
+    _check(lib.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0))
+    return get_last_frame(bp)
+
+
+def get_last_frame(bp, shard_planes=None):
+    lib = library()
+    shape = list(frame_shape(bp))
+    if shard_planes is not None:
+        shape[0] = shard_planes
+    info = P.HipFrameInfo()
+    _check(lib.beamformer_hip_get_last_frame_info(C.byref(info)))
+    complex_out = info.data_kind == int(P.DataKind.Float32Complex)
+    voxels = int(np.prod(shape))
+    raw = np.empty((int(info.size_bytes) + 3) // 4, dtype=np.float32)
+    _check(lib.beamformer_get_last_frames(raw.ctypes.data_as(C.c_void_p), raw.nbytes, 1))
+    if complex_out:
+        return raw[: 2 * voxels].view(np.complex64).reshape(shape)
+    return raw[:voxels].reshape(shape)

@@ -1,0 +1,138 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module,
+and only to check (or time, as the CPU baseline) what the HIP path produced.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ogl_beamforming_amd import params as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "liboracle.so")
+REF_LIBRARY_PATH = os.path.join(_HERE, "_ref", "libref_math.so")
+
+
+class OracleParameterBlock(C.Structure):
+    _fields_ = [
+        ("parameters", P.Parameters),
+        ("shaders", C.c_int32 * P.MAX_STAGES),
+        ("filter_slots", C.c_uint8 * P.MAX_STAGES),
+        ("shader_count", C.c_uint32),
+        ("data_kind", C.c_int32),
+        ("channel_mapping", C.c_int16 * P.MAX_CHANNELS),
+        ("sparse_elements", C.c_int16 * P.MAX_CHANNELS),
+        ("transmit_receive_orientations", C.c_uint8 * P.MAX_CHANNELS),
+        ("focal_vectors", (C.c_float * 2) * P.MAX_CHANNELS),
+        ("filters", P.FilterParameters * P.FILTER_SLOTS),
+    ]
+
+
+class OracleStage(C.Structure):
+    _fields_ = [("kind", C.c_int), ("in_kind", C.c_int), ("out_kind", C.c_int),
+                ("in_stride", C.c_int * 3), ("out_stride", C.c_int * 3),
+                ("filter_slot", C.c_int), ("user_index", C.c_int)]
+
+
+class OraclePlan(C.Structure):
+    _fields_ = [
+        ("stage_count", C.c_int), ("stages", OracleStage * P.MAX_STAGES),
+        ("first_image_stage", C.c_int), ("iq_pipeline", C.c_int), ("chunk_channel_count", C.c_int),
+        ("input_sample_count", C.c_int), ("das_sampling_frequency", C.c_float), ("das_time_offset", C.c_float),
+        ("rf_size", C.c_uint32), ("pipeline_data_kind", C.c_int), ("output_points", C.c_int * 3),
+        ("das_voxel_transform", C.c_float * 16), ("das_sparse", C.c_int),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(LIBRARY_PATH):
+        subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return LIBRARY_PATH
+
+
+_lib = None
+
+
+def library():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(LIBRARY_PATH)
+        fp = C.POINTER(C.c_float)
+        lib.oracle_beamform.restype = C.c_int
+        lib.oracle_beamform.argtypes = [C.POINTER(OracleParameterBlock), C.c_void_p, fp, C.POINTER(C.c_uint64), C.c_int]
+        lib.oracle_plan.restype = C.c_int
+        lib.oracle_plan.argtypes = [C.POINTER(OracleParameterBlock), C.POINTER(OraclePlan)]
+        lib.oracle_hadamard_transpose.argtypes = [C.c_int, fp]
+        lib.oracle_kaiser_low_pass.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, fp]
+        lib.oracle_bessel_i0.restype = C.c_double
+        lib.oracle_bessel_i0.argtypes = [C.c_double]
+        lib.oracle_tukey_window.restype = C.c_float
+        lib.oracle_tukey_window.argtypes = [C.c_float, C.c_float]
+        lib.oracle_rf_chirp.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, fp]
+        lib.oracle_baseband_chirp.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, fp]
+        lib.oracle_real_filter_first_moment.restype = C.c_float
+        lib.oracle_real_filter_first_moment.argtypes = [fp, C.c_int, C.c_float]
+        lib.oracle_complex_filter_first_moment.restype = C.c_float
+        lib.oracle_complex_filter_first_moment.argtypes = [fp, C.c_int, C.c_float]
+        lib.oracle_m4_mul.argtypes = [fp, fp, fp]
+        lib.oracle_das_transform.argtypes = [fp, fp, C.POINTER(C.c_int), fp]
+        lib.oracle_das_transform_2d.argtypes = [C.c_int, fp, fp, C.c_float, fp]
+        lib.oracle_das_transform_3d.argtypes = [fp, fp, fp]
+        lib.oracle_filter_create.restype = C.c_int
+        lib.oracle_filter_create.argtypes = [C.POINTER(P.FilterParameters), fp, C.c_int, fp]
+        _lib = lib
+    return _lib
+
+
+def parameter_block(bp, filters=()):
+    """What the library holds for one block after beamformer_push_simple_parameters
+    (lib/ogl_beamformer_lib.c:620-646) and beamformer_create_filter."""
+    pb = OracleParameterBlock()
+    C.memmove(C.byref(pb.parameters), C.byref(bp), C.sizeof(P.Parameters))
+    for i in range(bp.compute_stages_count):
+        pb.shaders[i] = bp.compute_stages[i]
+        pb.filter_slots[i] = bp.compute_stage_parameters[i] & 0xFF
+    pb.shader_count = bp.compute_stages_count
+    pb.data_kind = bp.data_kind
+    for i in range(P.MAX_CHANNELS):
+        pb.channel_mapping[i] = bp.channel_mapping[i]
+        pb.sparse_elements[i] = bp.sparse_elements[i]
+        pb.transmit_receive_orientations[i] = bp.transmit_receive_orientations[i]
+        pb.focal_vectors[i][0] = bp.steering_angles[i]
+        pb.focal_vectors[i][1] = bp.focal_depths[i]
+    for slot, f in enumerate(filters):
+        if f is not None:
+            pb.filters[slot] = f
+    return pb
+
+
+def plan(bp, filters=()):
+    pb = parameter_block(bp, filters)
+    out = OraclePlan()
+    ok = library().oracle_plan(C.byref(pb), C.byref(out))
+    return out if ok else None
+
+
+def beamform(bp, rf, filters=(), threads=0):
+    """Whole frame on the CPU, 16-channel chunks as the reference runs it.  Returns
+    (frame (Z, Y, X) float32|complex64, pairs)."""
+    pb = parameter_block(bp, filters)
+    p = plan(bp, filters)
+    if p is None:
+        raise RuntimeError("oracle could not plan this pipeline")
+    pts = [max(1, v) for v in bp.output_points[:3]]
+    voxels = pts[0] * pts[1] * pts[2]
+    n = 2 if p.iq_pipeline else 1
+    out = np.zeros(voxels * n, np.float32)
+    pairs = C.c_uint64(0)
+    rf = np.ascontiguousarray(rf)
+    ok = library().oracle_beamform(C.byref(pb), rf.ctypes.data_as(C.c_void_p),
+                                   out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(pairs), threads)
+    if not ok:
+        raise RuntimeError("oracle_beamform failed")
+    frame = out.view(np.complex64) if p.iq_pipeline else out
+    return frame.reshape(pts[2], pts[1], pts[0]), int(pairs.value)

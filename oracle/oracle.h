@@ -23,6 +23,16 @@
  *   Q2  Float16 data is IEEE half in Reshape (reshape.glsl:7-10 reads it as int16).
  *   Q3  IQ rotation arguments are range-reduced (turns = frac(f*t)) before sin/cos;
  *       the reference feeds ~1e3..1e4 rad to the driver's sin/cos.
+ *   Q4  Decode bounds the sample loop by the sample count (decode.glsl:46,:125 use
+ *       OutputTransmitStride, equal to it only for DAS-layout output).
+ *   Q5  The last 16-channel chunk is clamped to the channels that exist
+ *       (beamformer_core.c:595,:1604-1606 run a full chunk past the end of the data).
+ *   Q6  A plan that starts with DAS (Float32/Float32Complex data, decode off) beamforms
+ *       the ingested RF directly (the reference reads an unwritten slot,
+ *       beamformer_core.c:1353-1362).
+ *   Q7  A Kaiser filter always has real taps (beamformer_core.c:372-377); the ComplexFilter
+ *       flag is honoured only for matched chirps (the reference would read real taps as
+ *       pairs, beamformer_core.c:833,:840).
  */
 #ifndef ORACLE_H
 #define ORACLE_H
@@ -71,6 +81,7 @@ void oracle_reshape(const OracleReshape *r, const void *left, const void *right,
 
 typedef struct {
 	int   transmit_count, chunk_channel_count, sample_count; /* sample_count = dispatch extent */
+	int   active_channels;    /* channels of the chunk that exist (0: all chunk_channel_count) */
 	int   out_stride[3];      /* sample, channel, transmit */
 	int   in_kind, out_kind;
 	const float *hadamard;    /* transmit_count^2, as uploaded (f16-exact +-1) */

@@ -193,6 +193,7 @@ typedef struct {
 	float   *hadamard, *readi_hadamard;
 	uint64_t pairs;
 	int      threads;
+	int      chunk_channels;  /* channels in the chunk being run (Q5: the last chunk is clamped) */
 } Exec;
 
 static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_pointer, int64_t rf_elements_left)
@@ -200,7 +201,8 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 	const OraclePlan  *plan = e->plan;
 	const OracleStage *st   = &plan->stages[slot];
 	const BeamformerParameters *bp = &e->pb->parameters;
-	int A = (int)bp->acquisition_count, Cc = plan->chunk_channel_count;
+	/* Cc: the planned chunk (layout strides); Cn: channels actually present in this chunk */
+	int A = (int)bp->acquisition_count, Cc = plan->chunk_channel_count, Cn = e->chunk_channels;
 	int das_index = plan->first_image_stage - 1;                /* :1304 */
 	int output_index = !e->input_index, das_output_index = 2;
 	uint8_t *pp_in  = e->ping_pong + e->slot_bytes * (size_t)e->input_index;
@@ -210,7 +212,7 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 	switch (st->kind) {
 	case BeamformerShaderKind_Decode:{
 		OracleDecode d = {0};
-		d.transmit_count = A; d.chunk_channel_count = Cc; d.sample_count = plan->input_sample_count;
+		d.transmit_count = A; d.chunk_channel_count = Cc; d.active_channels = Cn; d.sample_count = plan->input_sample_count;
 		memcpy(d.out_stride, st->out_stride, sizeof(d.out_stride));
 		d.in_kind = st->in_kind; d.out_kind = st->out_kind; d.hadamard = e->hadamard;
 		oracle_decode(&d, pp_in, (slot + 1) == das_index ? pp_das : pp_out);
@@ -223,7 +225,7 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		const BeamformerFilterParameters *fp = &e->pb->filters[st->filter_slot % BeamformerFilterSlots];
 		OracleFilter f = {0};
 		f.filter_length  = oracle_filter_create(fp, coeffs, 8192, &delay);
-		f.complex_filter = fp->complex != 0;
+		f.complex_filter = fp->complex != 0 && fp->kind == BeamformerFilterKind_MatchedChirp;   /* Q7 */
 		f.demodulate     = demod;
 		f.coefficients   = coeffs;
 		f.sample_count   = plan->input_sample_count;                                   /* :845 */
@@ -233,7 +235,7 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		memcpy(f.in_stride,  st->in_stride,  sizeof(f.in_stride));
 		memcpy(f.out_stride, st->out_stride, sizeof(f.out_stride));
 		f.in_kind = st->in_kind; f.out_kind = st->out_kind;
-		f.channels = Cc; f.transmits = A; f.workgroup = 64;
+		f.channels = Cn; f.transmits = A; f.workgroup = 64;
 		if (demod) {                                                                    /* :870-873 */
 			f.demodulation_frequency = bp->demodulation_frequency;
 			f.sampling_frequency     = bp->sampling_frequency / 2;
@@ -248,20 +250,20 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 	}break;
 	case BeamformerShaderKind_Reshape:{
 		OracleReshape r = {0};
-		r.size[0] = plan->input_sample_count; r.size[1] = Cc; r.size[2] = A;              /* :975-977 */
+		r.size[0] = plan->input_sample_count; r.size[1] = Cn; r.size[2] = A;              /* :975-977 */
 		memcpy(r.in_stride,  st->in_stride,  sizeof(r.in_stride));
 		memcpy(r.out_stride, st->out_stride, sizeof(r.out_stride));
 		r.in_kind = st->in_kind; r.out_kind = st->out_kind;
 		r.interleave = !kind_complex[st->in_kind] && kind_complex[st->out_kind];        /* :961-965 */
 		const uint8_t *left  = slot == 0 ? rf_pointer : pp_in;                          /* :1381-1386 */
-		const uint8_t *right = left + (size_t)r.size[0] * r.size[1] * r.size[2] * (size_t)kind_byte_size[st->in_kind];
+		const uint8_t *right = left + (size_t)r.size[0] * Cc * r.size[2] * (size_t)kind_byte_size[st->in_kind];
 		oracle_reshape(&r, left, right, (slot + 1) == das_index ? pp_das : pp_out);
 		e->input_index = !e->input_index;
 	}break;
 	case BeamformerShaderKind_DAS:{
 		OracleDAS d; memset(&d, 0, sizeof(d));
 		d.acquisition_kind = bp->acquisition_kind; d.sparse = plan->das_sparse;
-		d.acquisition_count = A; d.channel_count = (int)bp->channel_count; d.chunk_channel_count = Cc;
+		d.acquisition_count = A; d.channel_count = (int)bp->channel_count; d.chunk_channel_count = Cn;
 		d.sample_count = plan->input_sample_count;
 		d.sampling_frequency = plan->das_sampling_frequency;
 		d.demodulation_frequency = bp->demodulation_frequency;
@@ -303,10 +305,9 @@ int oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out,
 	int das_stage = -1;
 	for (int i = 0; i < plan.stage_count; i++) if (plan.stages[i].kind == BeamformerShaderKind_DAS) das_stage = i;
 	if (das_stage < 0) return 0;
-	/* quirk 6 (beamformer_core.c:1353-1362): a plan whose first stage is DAS reads a slot
-	 * nothing wrote.  Refuse it. */
-	if (das_stage == 0) return 0;
-
+	/* Q6 (beamformer_core.c:1353-1362 vs :1337): a plan whose first stage is DAS reads a
+	 * ping-pong slot nothing wrote, so the reference cannot run Float32(Complex) data with
+	 * decoding off.  Build-defined: DAS consumes the ingested RF directly. */
 	size_t bytes     = (size_t)kind_byte_size[pb->data_kind];
 	size_t rf_bytes  = bytes * bp->sample_count * bp->acquisition_count * bp->channel_count;
 	uint8_t *mapped  = (uint8_t *)calloc(1, rf_bytes + 64);
@@ -343,6 +344,10 @@ int oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out,
 		const uint8_t *rf_pointer = mapped + raw_channel_byte_stride * channel_offset;
 		int64_t left = (int64_t)((rf_bytes - raw_channel_byte_stride * channel_offset) /
 		                         (size_t)kind_byte_size[plan.stages[0].in_kind]);
+		e.chunk_channels = (int)bp->channel_count - (int)channel_offset;
+		if (e.chunk_channels > plan.chunk_channel_count) e.chunk_channels = plan.chunk_channel_count;   /* Q5 */
+		if (das_stage == 0)
+			memcpy(e.ping_pong + 2 * e.slot_bytes, rf_pointer, raw_channel_byte_stride * (size_t)e.chunk_channels);
 		for (int i = 0; i < plan.first_image_stage; i++)
 			run_stage(&e, i, (int)channel_offset, rf_pointer, left);
 	}

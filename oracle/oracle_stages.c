@@ -126,11 +126,12 @@ void oracle_reshape(const OracleReshape *r, const void *left, const void *right,
 void oracle_decode(const OracleDecode *d, const void *in, void *out)
 {
 	int T = d->transmit_count, Cc = d->chunk_channel_count;
+	int Cn = d->active_channels > 0 ? d->active_channels : Cc;
 	int n = kind_element_count[d->out_kind];
 	float *row = (float *)malloc(sizeof(float) * 2 * (size_t)T);
 	int out_base_f16 = kind_base[d->out_kind] == BASE_F16;
 	for (int sample = 0; sample < d->sample_count; sample++) {
-		for (int channel = 0; channel < Cc; channel++) {
+		for (int channel = 0; channel < Cn; channel++) {
 			int64_t rf_offset = (int64_t)T * Cc * sample + (int64_t)T * channel;
 			for (int j = 0; j < T; j++) load_element(d->in_kind, in, rf_offset + j, row + 2 * j);
 			for (int i = 0; i < T; i++) {

@@ -1,0 +1,89 @@
+"""Small acquisitions shared by the CPU and GPU parity tests: every DAS geometry family,
+interpolation mode, data kind and pre-DAS stage combination the reference can run, at sizes
+the CPU oracle finishes in well under a second each."""
+import numpy as np
+
+from ogl_beamforming_amd import configs as cfg
+from ogl_beamforming_amd import params as P
+
+I = P.InterpolationMode
+K = P.AcquisitionKind
+D = P.DataKind
+S = P.ShaderKind
+
+LO3, HI3 = (-3e-3, -3e-3, 6e-3), (3e-3, 3e-3, 18e-3)
+
+
+def _cases():
+    c = {}
+    # the five BASELINE.json configs, shrunk
+    c["config1_small"] = lambda: cfg.config(1, 0.25)
+    c["config2_small"] = lambda: cfg.config(2, 0.0625)
+    c["config3_small"] = lambda: cfg.config(3, 0.125)
+    c["config4_small"] = lambda: cfg.config(4, 0.0625)
+    c["config5_small"] = lambda: cfg.config(5, 0.0625)
+    # RCA variants
+    c["rca_nearest_real"] = lambda: cfg.rca("rca_nearest_real", 16, 3, 512, (24, 1, 40), LO3, HI3, seed=11,
+                                            interp=I.Nearest, demodulate=False, data_kind=D.Int16,
+                                            single=False, orientation=0x22)
+    c["rca_cubic_real"] = lambda: cfg.rca("rca_cubic_real", 16, 2, 512, (20, 20, 1), LO3, HI3, seed=12,
+                                          interp=I.Cubic, demodulate=False, data_kind=D.Int16)
+    c["rca_vls_cw"] = lambda: cfg.rca("rca_vls_cw", 32, 4, 512, (12, 10, 14), LO3, HI3, seed=13, cw=True,
+                                      kind=K.RCA_VLS, orientation=0x21, depths=np.array([-10e-3, 25e-3, -15e-3, 40e-3]),
+                                      angles=np.array([-5.0, 0.0, 5.0, 10.0]), f_number=0.7)
+    c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
+                                              demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
+    c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,
+                                              demodulate=False, data_kind=D.Int16Complex, cw=True)
+    c["rca_f32_demod"] = lambda: cfg.rca("rca_f32_demod", 16, 2, 512, (16, 1, 24), LO3, HI3, seed=16,
+                                         data_kind=D.Float32, interp=I.Nearest)
+    c["rca_shuffled_padded"] = lambda: cfg.rca("rca_shuffled_padded", 24, 2, 384, (16, 16, 1), LO3, HI3, seed=17,
+                                               channel_shuffle=True, raw_pad=37)
+    c["rca_a1s2"] = lambda: cfg.rca("rca_a1s2", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=18, contrast=True)
+    c["rca_flash_none_tx"] = lambda: cfg.rca("rca_flash_none_tx", 16, 1, 512, (16, 16, 1), LO3, HI3, seed=19,
+                                             kind=K.Flash, orientation=0x02, single=True)
+    # HERCULES family
+    c["hercules_real"] = lambda: cfg.hercules("hercules_real", 16, 8, 512, (10, 12, 14), LO3, HI3, seed=21,
+                                              interp=I.Cubic, f_number=0.8)
+    c["uhercules_sparse"] = lambda: cfg.hercules("uhercules_sparse", 16, 8, 512, (10, 10, 10), LO3, HI3, seed=22,
+                                                 kind=K.UHERCULES, sparse=[0, 3, 5, 9, 12, 14, 15], decode=0,
+                                                 orientation=0x21)
+    c["hercules_demod_decode_cw"] = lambda: cfg.hercules(
+        "hercules_demod_decode_cw", 16, 16, 512, (10, 10, 12), LO3, HI3, seed=23, cw=True,
+        stages=(S.Demodulate, S.Decode, S.DAS), interp=I.Nearest)
+    c["hercules_order12"] = lambda: cfg.hercules("hercules_order12", 16, 12, 256, (8, 8, 8), LO3, HI3, seed=24)
+    c["hercules_chirp"] = lambda: cfg.hercules(
+        "hercules_chirp", 16, 4, 1024, (8, 8, 8), LO3, HI3, seed=25, decode=0, data_kind=D.Float32,
+        stages=(S.Demodulate, S.DAS),
+        filters=[cfg.matched_chirp_filter(12.5e6, 4e-6, -2e6, 2e6, complex_taps=True)])
+    # FORCES family
+    c["forces"] = lambda: cfg.forces("forces", 16, 16, 512, (20, 1, 20), LO3, HI3, seed=31)
+    c["uforces_sparse"] = lambda: cfg.forces("uforces_sparse", 16, 8, 512, (16, 1, 16), LO3, HI3, seed=32,
+                                             kind=K.UFORCES, sparse=[1, 4, 6, 8, 11, 13, 15], decode=0, interp=I.Cubic,
+                                             cw=True)
+    c["readi"] = lambda: cfg.forces("readi", 16, 4, 512, (16, 1, 16), LO3, HI3, seed=33, decode=0,
+                                    readi_groups=4, readi_group=2)
+    c["forces_filter_f32"] = lambda: cfg.forces("forces_filter_f32", 16, 4, 512, (12, 12, 1), LO3, HI3, seed=34,
+                                                decode=0, data_kind=D.Float32, stages=(S.Decode, S.Filter, S.DAS))
+    return c
+
+
+CASES = _cases()
+
+
+def make(name):
+    acq = CASES[name]()
+    if name == "forces_filter_f32":
+        acq.filters = [cfg.kaiser_filter(25e6, 4e6, length=21, beta=4.0)]
+    return acq
+
+
+# tolerance on max|gpu - oracle| / max|oracle| (stated per SURVEY section 8c):
+#   f32 staging, linear/cubic 1e-4; stages the reference runs through binary16 2e-3;
+#   nearest interpolation is judged by a mismatch fraction instead (a tap can flip)
+def tolerance(acq):
+    base = P.DATA_KIND_NUMPY[int(acq.bp.data_kind)]
+    stages = list(acq.bp.compute_stages[: acq.bp.compute_stages_count])
+    f16_staged = base in ("int16", "float16") and (int(S.Demodulate) in stages or int(S.Filter) in stages
+                                                   or (int(S.Decode) in stages and acq.bp.decode_mode))
+    return 2e-3 if f16_staged else 1e-4
