@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- beamformed voxels/s of the DAS hot path on MI355X (BASELINE.json metric).
+
+A step is one whole frame of BASELINE.json configs[3] through the C ABI: Int16 RF resident
+in HBM -> Demodulate -> DAS with fused coherency weighting -> 512^3 complex voxels
+(3-D row-column array, 256 channels x 75 plane waves).
+With N > 1 (one process per GPU, launched by torch.distributed.run) the volume is the SAME
+512^3 grid cut into N z-slabs (strong scaling): rank 0 holds the RF frame, every step
+broadcasts it over RCCL/xGMI (the one collective of the path), every rank beamforms its
+slab.  No reduction collective.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the DAS kernel against the HBM roofline
+with the ALGORITHMIC gather bytes of BASELINE.md section 4; `cpu_baseline` times the CPU
+oracle (a port of the reference shaders, the reference itself cannot be built here) on a
+bounded sub-grid of the same frame on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=4, help="BASELINE.json configs index (1-based)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 force the general DAS kernel")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if distributed else 0)
+
+    from ogl_beamforming_amd import configs, lib, params as P
+    L = lib.library()
+    assert L.beamformer_hip_set_device(device.index), lib.last_error()
+    L.beamformer_hip_set_das_path(args.das_path)
+
+    # every rank builds the parameter block (cheap, deterministic); only rank 0 owns the RF
+    acq = configs.config(args.config, args.scale)
+    bp = acq.bp
+    X, Y, Z = (max(1, v) for v in bp.output_points[:3])
+    voxels_total = X * Y * Z
+    for slot, fp in enumerate(acq.filters):
+        assert L.beamformer_create_filter(C.byref(fp), slot, 0), lib.last_error()
+    assert L.beamformer_push_simple_parameters(C.byref(bp)), lib.last_error()
+    z_first = rank * Z // world
+    z_count = (rank + 1) * Z // world - z_first
+    if distributed:
+        assert L.beamformer_hip_set_output_shard(0, z_first, z_count), lib.last_error()
+
+    rf_host = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1))
+    rf_dev = torch.empty(rf_host.numel(), dtype=torch.uint8, device=device)
+    if rank == 0:
+        rf_dev.copy_(rf_host)
+    stream = torch.cuda.current_stream(device)
+    assert L.beamformer_hip_set_stream(C.c_void_p(stream.cuda_stream)), lib.last_error()
+
+    def step():
+        if distributed:
+            dist.broadcast(rf_dev, src=0)          # RCCL over xGMI; same stream as the kernels
+        ok = L.beamformer_hip_push_device_data_with_compute(C.c_void_p(rf_dev.data_ptr()), rf_dev.numel(), 0, 0)
+        assert ok, lib.last_error()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # one untimed frame with the geometry-only pair count: G of BASELINE.md section 4
+    L.beamformer_hip_enable_pair_counting(1)
+    step()
+    fence()
+    t = P.HipFrameTimings()
+    assert L.beamformer_hip_get_last_frame_timings(C.byref(t)), lib.last_error()
+    pairs_local = int(t.das_pairs)
+    taps, sample_bytes, das_path = int(t.das_taps), int(t.das_sample_bytes), int(t.das_path)
+    L.beamformer_hip_enable_pair_counting(0)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # DAS kernel duration: HIP event pairs recorded by the library on the stream it launches
+    # on (beamformer_compute_timings = the reference's per-stage stats table)
+    stats = P.ComputeStatsTable()
+    assert L.beamformer_compute_timings(C.byref(stats), -1), lib.last_error()
+    n_stage = int(stats.shader_count)
+    ids = [int(stats.shader_ids[i]) for i in range(n_stage)]
+    das_col = ids.index(int(P.ShaderKind.DAS))
+    info = P.HipFrameInfo()
+    L.beamformer_hip_get_last_frame_info(C.byref(info))
+    last_id = int(info.frame_id)
+    rows = [(last_id - k) % 32 for k in range(args.steps)]
+    das_s = float(np.mean([stats.times[r][das_col] for r in rows]))
+    stage_ms = {P.ShaderKind(ids[i]).name: float(np.mean([stats.times[r][i] for r in rows])) * 1e3 for i in range(n_stage)}
+
+    if distributed:
+        agg = torch.tensor([elapsed, das_s, float(pairs_local)], dtype=torch.float64, device=device)
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = agg.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, das_s_max, pairs_total = float(mx[0]), float(mx[1]), int(sm[2].item())
+    else:
+        das_s_max, pairs_total = das_s, pairs_local
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = voxels_total / (elapsed / args.steps)
+        voxel_bytes = 8 if int(info.data_kind) == int(P.DataKind.Float32Complex) else 4
+        cw = 4 if bp.coherency_weighting else 0
+        # per launch = this rank's slab; ranks are symmetric, report rank 0's launch
+        bytes_alg = pairs_local * taps * sample_bytes + (X * Y * z_count) * (voxel_bytes + cw)
+        achieved = bytes_alg / das_s / 1e9
+        out = {
+            "metric": "beamformed voxels/s (and %HBM-roofline), 256-ch 3D DAS 512^3, 1/2/4/8 GPUs",
+            "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[{args.config - 1}]: 3-D row-column DAS + coherency weighting, "
+                            f"{bp.channel_count} ch x {bp.acquisition_count} plane waves, Int16 RF {bp.sample_count} samples "
+                            f"-> Demodulate -> {X}x{Y}x{Z} complex voxels",
+                "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
+                "f_number": bp.f_number, "sharding": f"{world} z-slab(s), RF broadcast via RCCL" if distributed else "none",
+                "das_path": "separable-delay fast path" if das_path else "general kernel",
+                "stage_ms": stage_ms,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                "kernel": "das_kernel", "kernel_ms": das_s * 1e3,
+                "algorithmic_bytes_per_launch": bytes_alg,
+                "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
+                "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
+                         "compulsory HBM traffic is ~1e4x smaller (BASELINE.md section 4)",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(acq, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(acq, budget_s):
+    """The CPU oracle (port of the reference shaders) on a bounded sub-grid of the same
+    frame: all x, a few rows of the centre z-plane; voxels are independent, so voxels/s
+    extrapolates linearly."""
+    from oracle import binding as oracle
+    bp = acq.bp
+    X, Y, Z = (max(1, v) for v in bp.output_points[:3])
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    per_voxel_pairs = bp.channel_count * bp.acquisition_count
+    # ~1.5e7 pairs/s/core for the scalar port; size the sample for the budget
+    target_voxels = max(X, int(budget_s * 1.2e7 * cores / per_voxel_pairs))
+    rows = max(1, min(Y, target_voxels // X))
+    timing = {}
+    t0 = time.perf_counter()
+    _, pairs = oracle.beamform(bp, acq.rf, acq.filters, threads=cores, z=(Z // 2, 1), y=((Y - rows) // 2, rows), timing=timing)
+    wall = time.perf_counter() - t0
+    das_s = timing["das_seconds"]
+    return {
+        "value": X * rows / das_s, "unit": "voxels/s", "cores": cores, "kind": "port",
+        "sample": f"oracle DAS over {X}x{rows}x1 voxels (z plane {Z // 2}, {rows} centre rows) of the {X}x{Y}x{Z} frame, "
+                  f"{pairs} pairs in {das_s:.2f} s DAS time ({wall:.2f} s incl. the single-threaded demodulate of the whole RF)",
+    }
+
+
+if __name__ == "__main__":
+    main()

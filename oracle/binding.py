@@ -64,6 +64,9 @@ def library():
         fp = C.POINTER(C.c_float)
         lib.oracle_beamform.restype = C.c_int
         lib.oracle_beamform.argtypes = [C.POINTER(OracleParameterBlock), C.c_void_p, fp, C.POINTER(C.c_uint64), C.c_int]
+        lib.oracle_beamform_subgrid.restype = C.c_int
+        lib.oracle_beamform_subgrid.argtypes = [C.POINTER(OracleParameterBlock), C.c_void_p, fp, C.POINTER(C.c_uint64), C.c_int,
+                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         lib.oracle_plan.restype = C.c_int
         lib.oracle_plan.argtypes = [C.POINTER(OracleParameterBlock), C.POINTER(OraclePlan)]
         lib.oracle_hadamard_transpose.argtypes = [C.c_int, fp]
@@ -117,22 +120,28 @@ def plan(bp, filters=()):
     return out if ok else None
 
 
-def beamform(bp, rf, filters=(), threads=0):
-    """Whole frame on the CPU, 16-channel chunks as the reference runs it.  Returns
-    (frame (Z, Y, X) float32|complex64, pairs)."""
+def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None):
+    """Whole frame on the CPU, 16-channel chunks as the reference runs it.  z / y = (first,
+    count) restrict the computed planes / rows (count 0 = whole axis).  Returns
+    (frame (Z, Y, X) float32|complex64, pairs); timing (a dict) receives das_seconds."""
     pb = parameter_block(bp, filters)
     p = plan(bp, filters)
     if p is None:
         raise RuntimeError("oracle could not plan this pipeline")
     pts = [max(1, v) for v in bp.output_points[:3]]
-    voxels = pts[0] * pts[1] * pts[2]
+    ny, nz = (y[1] or pts[1]), (z[1] or pts[2])
+    voxels = pts[0] * ny * nz
     n = 2 if p.iq_pipeline else 1
     out = np.zeros(voxels * n, np.float32)
     pairs = C.c_uint64(0)
+    das_seconds = C.c_double(0)
     rf = np.ascontiguousarray(rf)
-    ok = library().oracle_beamform(C.byref(pb), rf.ctypes.data_as(C.c_void_p),
-                                   out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(pairs), threads)
+    ok = library().oracle_beamform_subgrid(C.byref(pb), rf.ctypes.data_as(C.c_void_p),
+                                           out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(pairs), threads,
+                                           z[0], z[1], y[0], y[1], C.byref(das_seconds))
     if not ok:
         raise RuntimeError("oracle_beamform failed")
+    if timing is not None:
+        timing["das_seconds"] = das_seconds.value
     frame = out.view(np.complex64) if p.iq_pipeline else out
-    return frame.reshape(pts[2], pts[1], pts[0]), int(pairs.value)
+    return frame.reshape(nz, ny, pts[0]), int(pairs.value)

@@ -142,6 +142,7 @@ typedef struct {
 	const float   *readi_hadamard;               /* readi_group_count^2 or NULL */
 	/* build extension: z-slab of the output grid (whole grid when z_count == 0) */
 	uint32_t z_first, z_count;
+	uint32_t y_first, y_count;    /* likewise rows (whole when y_count == 0); output holds only the sub-grid */
 	int32_t  threads;             /* OpenMP threads, 0 = default */
 } OracleDAS;
 /* das.glsl:368-407: output[...] += sum, incoherent[...] += |.| sums.
@@ -196,6 +197,12 @@ int  oracle_plan(const OracleParameterBlock *pb, OraclePlan *plan);
  * chunks, ping-pong slots.  out: X*Y*Z float or float pair.  Returns 1 on success. */
 int  oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out,
                      uint64_t *pairs_out, int threads);
+/* the same frame restricted to z planes [z_first, z_first+z_count) and rows
+ * [y_first, y_first+y_count) (0 counts = whole axis); out holds X * rows * planes voxels.
+ * das_seconds (optional) receives the wall time spent inside oracle_das. */
+int  oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, float *out, uint64_t *pairs_out,
+                             int threads, uint32_t z_first, uint32_t z_count, uint32_t y_first, uint32_t y_count,
+                             double *das_seconds);
 
 #ifdef __cplusplus
 }

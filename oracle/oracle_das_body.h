@@ -289,13 +289,14 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 {
 	uint32_t X = p->output_size[0], Y = p->output_size[1], Z = p->output_size[2];
 	uint32_t z0 = p->z_count ? p->z_first : 0, zn = p->z_count ? p->z_count : Z;
+	uint32_t y0 = p->y_count ? p->y_first : 0, yn = p->y_count ? p->y_count : Y;
 	int      elements = p->complex_data ? 2 : 1;
 	uint64_t pairs = 0;
-	int64_t  rows  = (int64_t)zn * Y;
+	int64_t  rows  = (int64_t)zn * yn;
 
 	#pragma omp parallel for schedule(dynamic, 4) reduction(+:pairs) num_threads(oracle_thread_count(p->threads))
 	for (int64_t row = 0; row < rows; row++) {
-		uint32_t zl = (uint32_t)(row / Y), y = (uint32_t)(row % Y), z = z0 + zl;
+		uint32_t zl = (uint32_t)(row / yn), yl = (uint32_t)(row % yn), z = z0 + zl, y = y0 + yl;
 		for (uint32_t x = 0; x < X; x++) {
 			REAL point[3] = {
 				(REAL)x / (REAL)(X > 2 ? X - 1 : 1),
@@ -324,7 +325,7 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 				break;
 			default: break;
 			}
-			uint64_t out_index = (uint64_t)X * Y * zl + (uint64_t)X * y + x;
+			uint64_t out_index = (uint64_t)X * yn * zl + (uint64_t)X * yl + x;
 			if (p->coherency_weighting) incoherent[out_index] += acc.c[2];
 			output[elements * out_index] += acc.c[0];
 			if (elements == 2) output[elements * out_index + 1] += acc.c[1];

@@ -7,6 +7,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double oracle_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static const int kind_byte_size[6]     = {2, 4, 4, 8, 2, 4};
 static const int kind_element_size[6]  = {2, 2, 4, 4, 2, 2};
@@ -194,6 +202,8 @@ typedef struct {
 	uint64_t pairs;
 	int      threads;
 	int      chunk_channels;  /* channels in the chunk being run (Q5: the last chunk is clamped) */
+	uint32_t z_first, z_count, y_first, y_count;   /* sub-grid (build extension), 0 counts = whole */
+	double   das_seconds;
 } Exec;
 
 static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_pointer, int64_t rf_elements_left)
@@ -287,10 +297,14 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		d.transmit_receive_orientations = e->pb->transmit_receive_orientations;
 		d.readi_hadamard = e->readi_hadamard;
 		d.threads = e->threads;
+		d.z_first = e->z_first; d.z_count = e->z_count; d.y_first = e->y_first; d.y_count = e->y_count;
+		double t0 = oracle_now();
 		e->pairs += oracle_das(&d, (const float *)pp_das, e->frame, e->incoherent);
+		e->das_seconds += oracle_now() - t0;
 	}break;
 	case BeamformerShaderKind_CoherencyWeighting:{
-		uint32_t voxels = (uint32_t)plan->output_points[0] * (uint32_t)plan->output_points[1] * (uint32_t)plan->output_points[2];
+		uint32_t voxels = (uint32_t)plan->output_points[0] * (e->y_count ? e->y_count : (uint32_t)plan->output_points[1])
+		                  * (e->z_count ? e->z_count : (uint32_t)plan->output_points[2]);
 		oracle_coherency_weighting(e->frame, e->incoherent, voxels, plan->iq_pipeline, 1.0f);  /* :949 */
 	}break;
 	default: break;
@@ -298,6 +312,13 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 }
 
 int oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out, uint64_t *pairs_out, int threads)
+{
+	return oracle_beamform_subgrid(pb, raw, out, pairs_out, threads, 0, 0, 0, 0, 0);
+}
+
+int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, float *out, uint64_t *pairs_out,
+                            int threads, uint32_t z_first, uint32_t z_count, uint32_t y_first, uint32_t y_count,
+                            double *das_seconds)
 {
 	const BeamformerParameters *bp = &pb->parameters;
 	OraclePlan plan;
@@ -313,11 +334,13 @@ int oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out,
 	uint8_t *mapped  = (uint8_t *)calloc(1, rf_bytes + 64);
 	oracle_channel_map(raw, mapped, bp, pb->data_kind, pb->channel_mapping);
 
-	uint64_t voxels = (uint64_t)plan.output_points[0] * plan.output_points[1] * plan.output_points[2];
+	uint64_t voxels = (uint64_t)plan.output_points[0] * (y_count ? y_count : (uint32_t)plan.output_points[1])
+	                  * (z_count ? z_count : (uint32_t)plan.output_points[2]);
 	int elements = plan.iq_pipeline ? 2 : 1;
 
 	Exec e; memset(&e, 0, sizeof(e));
 	e.pb = pb; e.plan = &plan; e.threads = threads;
+	e.z_first = z_first; e.z_count = z_count; e.y_first = y_first; e.y_count = y_count;
 	/* ping-pong: 3 x round_up(rf_size, 64) (:1229); intermediate kinds never exceed the DAS kind */
 	e.slot_bytes = ((size_t)plan.rf_size + 63) & ~(size_t)63;
 	{	/* head-room so that a wider-than-DAS intermediate cannot overrun in the checker */
@@ -355,6 +378,7 @@ int oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out,
 		run_stage(&e, i, 0, 0, 0);
 
 	if (pairs_out) *pairs_out = e.pairs;
+	if (das_seconds) *das_seconds = e.das_seconds;
 	free(mapped); free(e.ping_pong); free(e.incoherent); free(e.hadamard); free(e.readi_hadamard);
 	return 1;
 }

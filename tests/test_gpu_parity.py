@@ -20,8 +20,12 @@ def compare(gpu, ref, acq):
     assert scale > 0, "oracle image is empty: the case does not exercise the path"
     err = np.abs(gpu[ok] - ref[ok]) / scale
     if acq.bp.interpolation_mode == int(P.InterpolationMode.Nearest):
-        # a sample index within float rounding of k + 0.5 may pick the other tap
-        assert np.mean(err > 1e-3) < 1e-3, f"nearest: mismatch fraction {np.mean(err > 1e-3):.2e}"
+        # a sample index within float rounding of k + 0.5 may pick the other tap; the chance
+        # grows with the pairs summed per voxel (~1e-4 each)
+        allowed = min(0.05, max(1e-3, 3e-4 * acq.bp.channel_count * acq.bp.acquisition_count))
+        bad = float(np.mean(err > 1e-3))
+        assert bad < allowed, f"nearest: mismatch fraction {bad:.2e} (allowed {allowed:.2e})"
+        assert np.median(err) < 1e-5
         return float(np.median(err))
     tol = cases.tolerance(acq)
     assert err.max() <= tol, f"max relative error {err.max():.3e} > {tol:.0e}"
