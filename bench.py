@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
     ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 force the general DAS kernel")
+    ap.add_argument("--planes", type=int, default=0, help="profiling aid: beamform only this many centre z-planes (value is then NOT the metric)")
     return ap.parse_args()
 
 
@@ -73,7 +74,11 @@ def main():
     assert L.beamformer_push_simple_parameters(C.byref(bp)), lib.last_error()
     z_first = rank * Z // world
     z_count = (rank + 1) * Z // world - z_first
-    if distributed:
+    if args.planes and not distributed:
+        z_count = min(Z, args.planes)
+        z_first = (Z - z_count) // 2
+        voxels_total = X * Y * z_count
+    if distributed or args.planes:
         assert L.beamformer_hip_set_output_shard(0, z_first, z_count), lib.last_error()
 
     rf_host = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1))

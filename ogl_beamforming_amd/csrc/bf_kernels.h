@@ -55,6 +55,16 @@ typedef struct {
 	uint32_t blocks[3];               /* blocks per axis */
 } BfDasArgs;
 
+/* tile geometry of the separable-delay fast path (das_separable.hip) */
+typedef struct {
+	uint32_t u_axis;          /* output axis (0 = x, 1 = y) the receive aperture runs along */
+	uint32_t u_shift, v_shift;/* log2 of the tile extent along the receive / transmit axis */
+	uint32_t threads;         /* (1 << u_shift) * (1 << v_shift): 256, 512 or 1024 */
+	uint32_t channel_chunk;   /* channels per receive-table rebuild */
+	uint32_t lds_bytes;       /* 16 * (channel_chunk << u_shift) + 16 * (transmits << v_shift) */
+	uint32_t tiles[3];        /* tiles along u, along v, z planes of the shard */
+} BfSeparableArgs;
+
 typedef struct {
 	const void *raw; void *out;
 	const int16_t *channel_mapping;   /* device, [channels] */
@@ -102,6 +112,7 @@ hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s);
 hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s);
 hipError_t bf_launch_das(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s);
+hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
  * 2*1024 floats */
 hipError_t bf_launch_min_max(const void *frame, uint64_t voxels, int complex_data,

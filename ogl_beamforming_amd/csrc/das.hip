@@ -23,50 +23,7 @@
  *     with the argument reduced by v_fract (Q3 in oracle/oracle.h).
  * The gather-accumulate is memory/VALU bound: no MFMA.
  */
-#include <hip/hip_runtime.h>
-#include <type_traits>
-#include "bf_kernels.h"
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-/* gathers are only element aligned: 8 B for complex, 4 B for real samples */
-typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
-typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
-typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
-
-template <bool CPLX> using sample_t = typename std::conditional<CPLX, f32x2, float>::type;
-
-#define BF_INTERP_NEAREST 0
-#define BF_INTERP_LINEAR  1
-#define BF_INTERP_CUBIC   2
-
-__device__ __forceinline__ float hw_sqrt(float x)      { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float hw_rcp(float x)       { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float hw_rsq(float x)       { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ float hw_fract(float x)     { return __builtin_amdgcn_fractf(x); }
-__device__ __forceinline__ float hw_sin_turns(float x) { return __builtin_amdgcn_sinf(x); }   /* sin(2 pi x) */
-__device__ __forceinline__ float hw_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }   /* cos(2 pi x) */
-
-/* das.glsl:138-152: cos(pi a)^2 */
-__device__ __forceinline__ float apodize(float a)
-{
-	float c = hw_cos_turns(0.5f * a);
-	return c * c;
-}
-
-template <bool CPLX>
-__device__ __forceinline__ sample_t<CPLX> zero_sample()
-{
-	if constexpr (CPLX) return f32x2{0.f, 0.f}; else return 0.f;
-}
-
-/* byte offset arithmetic stays in 32 bits: the largest DAS input (256 ch x 256 tx x 8192
- * complex samples) is 4 GiB - that case is rejected by the host */
-template <typename T>
-__device__ __forceinline__ T gather(const char *rf, uint32_t byte_offset)
-{
-	return *reinterpret_cast<const T *>(rf + byte_offset);
-}
+#include "das_common.h"
 
 /* das.glsl:54-61 with the angle in turns, reduced to [0,1) */
 __device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const BfDasArgs &p)
@@ -76,57 +33,15 @@ __device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const BfDasArg
 	return f32x2{c * iq.x - s * iq.y, s * iq.x + c * iq.y};
 }
 
-/* das.glsl:99-124 (+ cubic :67-97).  rf_offset is an element index, already decremented by
- * one for cubic (das.glsl:215). */
+/* das.glsl:99-124 (+ cubic :67-97); rf_offset is the element index of the row's sample 0.
+ * Branch-free (das_common.h): an out-of-range index yields +0. */
 template <int INTERP, bool CPLX>
 __device__ __forceinline__ sample_t<CPLX> sample_rf(const char *rf, int rf_offset, float index, const BfDasArgs &p)
 {
 	constexpr uint32_t ES = CPLX ? 8 : 4;
-	sample_t<CPLX> result = zero_sample<CPLX>();
-	const float S = (float)p.sample_count;
-	if constexpr (INTERP == BF_INTERP_NEAREST) {
-		if (index >= 0.f && index < S - 0.5f) {
-			int k = (int)__builtin_roundf(index);
-			result = gather<sample_t<CPLX>>(rf, (uint32_t)(rf_offset + k) * ES);
-			if constexpr (CPLX) result = rotate_iq(result, index, p);
-		}
-	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
-		if (index >= 0.f && index < S - 1.f) {
-			float tk = __builtin_floorf(index), t = index - tk;
-			uint32_t off = (uint32_t)(rf_offset + (int)tk) * ES;
-			if constexpr (CPLX) {
-				f32x4 v = gather<f32x4_a8>(rf, off);
-				f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-				result = (1.f - t) * a + t * b;
-				result = rotate_iq(result, index, p);
-			} else {
-				f32x2 v = gather<f32x2_a4>(rf, off);
-				result = (1.f - t) * v.x + t * v.y;
-			}
-		}
-	} else {
-		if (index >= 1.f && index < S - 2.f) {
-			float tk = __builtin_floorf(index), t = index - tk;
-			uint32_t off = (uint32_t)(rf_offset + (int)tk) * ES;
-			float t2 = t * t, t3 = t2 * t;
-			/* Hermite basis with tangents 0.5 (P2 - P0), 0.5 (P3 - P1) */
-			float b0 =  2.f * t3 - 3.f * t2 + 1.f;
-			float b1 = -2.f * t3 + 3.f * t2;
-			float b2 =        t3 - 2.f * t2 + t;
-			float b3 =        t3 -       t2;
-			if constexpr (CPLX) {
-				f32x4 lo = gather<f32x4_a8>(rf, off), hi = gather<f32x4_a8>(rf, off + 16);
-				f32x2 s0 = {lo.x, lo.y}, s1 = {lo.z, lo.w}, s2 = {hi.x, hi.y}, s3 = {hi.z, hi.w};
-				f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1);
-				result = b0 * s1 + b1 * s2 + b2 * T1 + b3 * T2;
-				result = rotate_iq(result, index, p);
-			} else {
-				f32x4 v = gather<f32x4_a4>(rf, off);
-				float T1 = 0.5f * (v.z - v.x), T2 = 0.5f * (v.w - v.y);
-				result = b0 * v.y + b1 * v.z + b2 * T1 + b3 * T2;
-			}
-		}
-	}
+	sample_t<CPLX> result = interpolate<INTERP, CPLX>(rf, (uint32_t)rf_offset * ES, index,
+	                                                  (float)p.sample_count, p.sample_count - 1);
+	if constexpr (CPLX) result = rotate_iq(result, index, p);
 	return result;
 }
 
@@ -146,13 +61,6 @@ struct Accumulator {
 		}
 	}
 };
-
-__device__ __forceinline__ void m4_point(const float *m, float x, float y, float z, float &ox, float &oy, float &oz)
-{
-	ox = m[0] * x + m[4] * y + m[8]  * z + m[12];
-	oy = m[1] * x + m[5] * y + m[9]  * z + m[13];
-	oz = m[2] * x + m[6] * y + m[10] * z + m[14];
-}
 
 /* das.glsl:187-202 with the per-transmit constants precomputed */
 __device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx, float wy, float wz)
@@ -195,17 +103,18 @@ __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, floa
 		const float tx_dist = transmit_distance(t, wx, wy, wz);
 		const float f_over_z = p.f_number * inv_abs_z;
 
-		int rf_offset = acquisition * S - (INTERP == BF_INTERP_CUBIC);
+		int rf_offset = acquisition * S;
 		for (int channel = 0; channel < C; channel++) {
 			float dx    = lateral - (float)channel * pitch;
 			float a_arg = __builtin_fabsf(dx * f_over_z);
-			if (a_arg < 0.5f) {
-				if constexpr (COUNT) {
-					acc.pairs++;
-				} else {
-					float sidx = sample_index(tx_dist + hw_sqrt(dx * dx + zz), p);
-					acc.add(apodize(a_arg) * sample_rf<INTERP, CPLX>(rf, rf_offset, sidx, p));
-				}
+			bool  pass  = a_arg < 0.5f;
+			if constexpr (COUNT) {
+				acc.pairs += pass;
+			} else if (__builtin_amdgcn_ballot_w64(pass)) {
+				/* the F# test is taken per wave; lanes outside the aperture get weight 0 */
+				float sidx = sample_index(tx_dist + hw_sqrt(dx * dx + zz), p);
+				float apod = pass ? apodize(a_arg) : 0.f;
+				acc.add(apod * sample_rf<INTERP, CPLX>(rf, rf_offset, sidx, p));
 			}
 			rf_offset += S * A;
 		}
@@ -232,7 +141,7 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 	const float first_weight     = hw_rsq((float)A);
 
 	for (int channel = 0; channel < C; channel++) {
-		int rf_offset = channel * S * A + sparse * S - (INTERP == BF_INTERP_CUBIC);
+		int rf_offset = channel * S * A + sparse * S;
 		/* squared lateral distance to the receive element along the receive axis */
 		float rx_delta = rx_cols ? xx - (float)channel * p.pitch[0] : xy - (float)channel * p.pitch[1];
 		float rx_sq    = rx_delta * rx_delta;
@@ -241,15 +150,14 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 			float tx_channel = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
 			float tx_delta   = rx_cols ? xy - tx_channel * p.pitch[1] : xx - tx_channel * p.pitch[0];
 			float element_delta_squared = rx_cols ? rx_sq + tx_delta * tx_delta : tx_delta * tx_delta + rx_sq;
-			if (element_delta_squared < apodization_test) {
-				if constexpr (COUNT) {
-					acc.pairs++;
-				} else {
-					float apodization = (transmit == 0 ? first_weight : 1.0f)
-					                    * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
-					float index = transmit_index + hw_sqrt(z_delta_squared + element_delta_squared) * fs_over_c;
-					acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
-				}
+			bool pass = element_delta_squared < apodization_test;
+			if constexpr (COUNT) {
+				acc.pairs += pass;
+			} else if (__builtin_amdgcn_ballot_w64(pass)) {
+				float apodization = pass ? (transmit == 0 ? first_weight : 1.0f)
+				                           * apodize(f_number_over_z * hw_sqrt(element_delta_squared)) : 0.f;
+				float index = transmit_index + hw_sqrt(z_delta_squared + element_delta_squared) * fs_over_c;
+				acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 			}
 			rf_offset += S;
 		}
@@ -274,16 +182,17 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 	for (int channel = 0; channel < C; channel++) {
 		float receive_x_delta = xx - (float)channel * p.pitch[0];
 		float a_arg           = __builtin_fabsf(receive_x_delta * f_over_z);
-		if (!(a_arg < 0.5f)) continue;
+		bool  pass            = a_arg < 0.5f;
+		if (!__builtin_amdgcn_ballot_w64(pass)) continue;
 
 		float receive_index = sample_index(hw_sqrt(receive_x_delta * receive_x_delta + z_delta_squared), p);
-		float apodization   = COUNT ? 0.f : apodize(a_arg);
+		float apodization   = (COUNT || !pass) ? 0.f : apodize(a_arg);
 
 		if constexpr (!READI) {
-			int rf_offset = channel * S * A + sparse * S - (INTERP == BF_INTERP_CUBIC);
+			int rf_offset = channel * S * A + sparse * S;
 			for (int transmit = sparse; transmit < A; transmit++) {
 				if constexpr (COUNT) {
-					acc.pairs++;
+					acc.pairs += pass;
 				} else {
 					float tx_channel       = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
 					float transmit_x_delta = xx - p.pitch[0] * tx_channel;
@@ -293,14 +202,14 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 				rf_offset += S;
 			}
 		} else {
-			int channel_rf_offset = channel * S * A - (INTERP == BF_INTERP_CUBIC);
+			int channel_rf_offset = channel * S * A;
 			for (int tx_group = 0; tx_group < (int)p.readi_group_count; tx_group++) {
 				_Float16 h = __builtin_bit_cast(_Float16, p.readi_hadamard[hadamard_offset + tx_group]);
 				float group_apodization = apodization * (float)h;
 				int   rf_offset = channel_rf_offset;
 				for (int tx_event = 0; tx_event < A; tx_event++) {
 					if constexpr (COUNT) {
-						acc.pairs++;
+						acc.pairs += pass;
 					} else {
 						float tx_element       = (float)tx_group * (float)A + (float)tx_event;
 						float transmit_x_delta = xx - p.pitch[0] * tx_element;

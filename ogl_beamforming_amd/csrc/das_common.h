@@ -1,0 +1,173 @@
+/* das_common.h -- device helpers shared by das.hip (general path) and das_separable.hip
+ * (row-column fast path): hardware transcendental wrappers, element-aligned gathers and the
+ * branch-free restatement of sample_rf (shaders/das.glsl:99-124, cubic :67-97).
+ *
+ * Branch-free on purpose: the reference tests the sample index and only then loads.  On
+ * CDNA4 a load inside a divergent branch has to be waited for inside that branch, which
+ * serialises every gather of a wave.  Here the tap address is clamped into the row (always a
+ * legal address) and the validity test becomes a 0/1 weight folded into the interpolation
+ * weights, so the compiler can issue the gathers of several (channel, transmit) terms
+ * back to back and wait once.  The result is bit-identical to the branchy form: a valid
+ * sample is multiplied by 1.0f, an invalid one contributes +0.
+ */
+#ifndef BF_DAS_COMMON_H
+#define BF_DAS_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "bf_kernels.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+/* gathers are only element aligned: 8 B for complex, 4 B for real samples */
+typedef f32x4 f32x4_a8 __attribute__((aligned(8)));
+typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+typedef f32x2 f32x2_a4 __attribute__((aligned(4)));
+
+#define BF_INTERP_NEAREST 0
+#define BF_INTERP_LINEAR  1
+#define BF_INTERP_CUBIC   2
+
+template <bool CPLX> using sample_t = typename std::conditional<CPLX, f32x2, float>::type;
+
+__device__ __forceinline__ float hw_sqrt(float x)      { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float hw_rcp(float x)       { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float hw_rsq(float x)       { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float hw_fract(float x)     { return __builtin_amdgcn_fractf(x); }
+__device__ __forceinline__ float hw_sin_turns(float x) { return __builtin_amdgcn_sinf(x); }   /* sin(2 pi x) */
+__device__ __forceinline__ float hw_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }   /* cos(2 pi x) */
+
+/* das.glsl:138-152: cos(pi a)^2 */
+__device__ __forceinline__ float apodize(float a)
+{
+	float c = hw_cos_turns(0.5f * a);
+	return c * c;
+}
+
+template <bool CPLX>
+__device__ __forceinline__ sample_t<CPLX> zero_sample()
+{
+	if constexpr (CPLX) return f32x2{0.f, 0.f}; else return 0.f;
+}
+
+/* byte offsets stay in 32 bits: the host rejects DAS inputs of 4 GiB and more */
+template <typename T>
+__device__ __forceinline__ T gather(const char *rf, uint32_t byte_offset)
+{
+	return *reinterpret_cast<const T *>(rf + byte_offset);
+}
+
+__device__ __forceinline__ void m4_point(const float *m, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+	ox = m[0] * x + m[4] * y + m[8]  * z + m[12];
+	oy = m[1] * x + m[5] * y + m[9]  * z + m[13];
+	oz = m[2] * x + m[6] * y + m[10] * z + m[14];
+}
+
+/* The interpolation of sample_rf split in three steps so that a caller can issue the
+ * gathers of several terms before consuming any of them (software pipelining by hand; hipcc
+ * otherwise waits for each load right after issuing it once registers are capped):
+ *   tap_setup  : index -> byte offset inside the row (clamped to a legal address) + weights
+ *                (zero when the index is outside the valid range)
+ *   tap_load   : the 1 or 2 vector loads
+ *   tap_finish : weighted sum
+ *   Nearest: valid 0 <= index < S - 0.5, tap round(index)
+ *   Linear:  valid 0 <= index < S - 1,   taps k, k+1
+ *   Cubic:   valid 1 <= index < S - 2,   taps k-1 .. k+2 (Catmull-Rom Hermite, das.glsl:67-97)
+ * last = SampleCount - 1, sample_count_f = (float)SampleCount. */
+template <int INTERP> struct Tap;
+template <> struct Tap<BF_INTERP_NEAREST> { uint32_t off; float w0; };
+template <> struct Tap<BF_INTERP_LINEAR>  { uint32_t off; float w0, w1; };
+template <> struct Tap<BF_INTERP_CUBIC>   { uint32_t off; float w0, w1, w2, w3; };
+
+template <int INTERP, bool CPLX> struct TapData;
+template <> struct TapData<BF_INTERP_NEAREST, true>  { f32x2 a; };
+template <> struct TapData<BF_INTERP_NEAREST, false> { float a; };
+template <> struct TapData<BF_INTERP_LINEAR,  true>  { f32x4 a; };
+template <> struct TapData<BF_INTERP_LINEAR,  false> { f32x2 a; };
+template <> struct TapData<BF_INTERP_CUBIC,   true>  { f32x4 a, b; };
+template <> struct TapData<BF_INTERP_CUBIC,   false> { f32x4 a; };
+
+template <int INTERP, bool CPLX>
+__device__ __forceinline__ Tap<INTERP> tap_setup(float index, float sample_count_f, int last)
+{
+	constexpr uint32_t ES = CPLX ? 8 : 4;
+	Tap<INTERP> tap;
+	if constexpr (INTERP == BF_INTERP_NEAREST) {
+		tap.w0 = (index >= 0.f && index < sample_count_f - 0.5f) ? 1.f : 0.f;
+		int k  = (int)__builtin_roundf(index);
+		k = k < 0 ? 0 : (k > last ? last : k);
+		tap.off = (uint32_t)k * ES;
+	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+		/* 0 <= index < S-1  <=>  (unsigned)floor(index) < S-1 */
+		float    t  = hw_fract(index);
+		uint32_t k  = (uint32_t)(int)__builtin_floorf(index);
+		float    w  = k < (uint32_t)last ? 1.f : 0.f;
+		k = k < (uint32_t)(last - 1) ? k : (uint32_t)(last - 1);
+		tap.off = k * ES;
+		tap.w1  = w * t;               /* t and (1 - t) when w == 1 */
+		tap.w0  = w - tap.w1;
+	} else {
+		/* 1 <= index < S-2  <=>  (unsigned)(floor(index) - 1) < S-3 */
+		float    t  = hw_fract(index);
+		uint32_t k  = (uint32_t)((int)__builtin_floorf(index) - 1);
+		float    w  = k < (uint32_t)(last - 2) ? 1.f : 0.f;
+		k = k < (uint32_t)(last - 3) ? k : (uint32_t)(last - 3);
+		tap.off = k * ES;
+		float t2 = t * t, t3 = t2 * t;
+		/* Hermite basis, tangents 0.5 (P2 - P0) and 0.5 (P3 - P1) */
+		tap.w0 = w * ( 2.f * t3 - 3.f * t2 + 1.f);
+		tap.w1 = w * (-2.f * t3 + 3.f * t2);
+		tap.w2 = w * (       t3 - 2.f * t2 + t);
+		tap.w3 = w * (       t3 -       t2);
+	}
+	return tap;
+}
+
+template <int INTERP, bool CPLX>
+__device__ __forceinline__ TapData<INTERP, CPLX> tap_load(const char *rf, uint32_t byte_offset)
+{
+	TapData<INTERP, CPLX> d;
+	if constexpr (INTERP == BF_INTERP_NEAREST) {
+		d.a = gather<sample_t<CPLX>>(rf, byte_offset);
+	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+		if constexpr (CPLX) d.a = gather<f32x4_a8>(rf, byte_offset);
+		else                d.a = gather<f32x2_a4>(rf, byte_offset);
+	} else {
+		if constexpr (CPLX) { d.a = gather<f32x4_a8>(rf, byte_offset); d.b = gather<f32x4_a8>(rf, byte_offset + 16); }
+		else                { d.a = gather<f32x4_a4>(rf, byte_offset); }
+	}
+	return d;
+}
+
+template <int INTERP, bool CPLX>
+__device__ __forceinline__ sample_t<CPLX> tap_finish(const Tap<INTERP> &tap, const TapData<INTERP, CPLX> &d)
+{
+	if constexpr (INTERP == BF_INTERP_NEAREST) {
+		return tap.w0 * d.a;
+	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+		if constexpr (CPLX) return tap.w0 * f32x2{d.a.x, d.a.y} + tap.w1 * f32x2{d.a.z, d.a.w};
+		else                return tap.w0 * d.a.x + tap.w1 * d.a.y;
+	} else {
+		if constexpr (CPLX) {
+			f32x2 s0 = {d.a.x, d.a.y}, s1 = {d.a.z, d.a.w}, s2 = {d.b.x, d.b.y}, s3 = {d.b.z, d.b.w};
+			f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1);
+			return tap.w0 * s1 + tap.w1 * s2 + tap.w2 * T1 + tap.w3 * T2;
+		} else {
+			float T1 = 0.5f * (d.a.z - d.a.x), T2 = 0.5f * (d.a.w - d.a.y);
+			return tap.w0 * d.a.y + tap.w1 * d.a.z + tap.w2 * T1 + tap.w3 * T2;
+		}
+	}
+}
+
+/* Interpolated sample of the row starting at row_byte_offset, WITHOUT the IQ rotation. */
+template <int INTERP, bool CPLX>
+__device__ __forceinline__ sample_t<CPLX> interpolate(const char *rf, uint32_t row_byte_offset, float index,
+                                                      float sample_count_f, int last)
+{
+	Tap<INTERP> tap = tap_setup<INTERP, CPLX>(index, sample_count_f, last);
+	TapData<INTERP, CPLX> d = tap_load<INTERP, CPLX>(rf, row_byte_offset + tap.off);
+	return tap_finish<INTERP, CPLX>(tap, d);
+}
+
+#endif

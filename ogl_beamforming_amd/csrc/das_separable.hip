@@ -1,0 +1,231 @@
+/* das_separable.hip -- delay-and-sum fast path for row-column geometries on gfx950.
+ *
+ * Same arithmetic contract as das.hip's RCA family (shaders/das.glsl:204-231 of the
+ * reference): out(v) = sum over transmits a and channels c of
+ *     apodize(c, v) * rotate_iq( interpolate( rf[c][a], idx(v, a, c) ) ).
+ *
+ * What the reference (and das.hip) recompute for every (voxel, channel, transmit) triple
+ * factors when the receive aperture and the transmit steering lie along different
+ * transducer axes (rows vs columns) and the volume's z axis is the depth axis:
+ *     idx(v, a, c)  = T(a; v_tx, z) + R(c; v_rx, z)          delay: transmit part + receive part
+ *     phasor        = e^{j phi(T)} * e^{j phi(R)}            demodulation phase of each part
+ *     apodization   = A(c; v_rx, z)                          receive part only
+ * where v_rx / v_tx are the voxel coordinates along the receive / transmit lateral axes.
+ * A block therefore owns a tile of U (receive axis) x V (transmit axis) voxels of one
+ * z-plane and builds two small LDS tables -- R[c][u] (C*U entries) and T[a][v] (A*V
+ * entries) -- costing C*U + A*V square roots and sin/cos pairs instead of U*V*C*A.
+ * The inner loop per triple is then: one broadcast LDS read, one add, the index split, one
+ * 16-byte gather, the interpolation and a complex multiply-accumulate; the channel's
+ * apodization and receive phasor are applied once per channel to the transmit-summed value.
+ *
+ * MI355X mapping: wave64; 512 or 1024 threads per block share the tables (up to 160 KB of
+ * LDS per CU); lanes are laid along the output's x axis so voxel stores are 128-B or 512-B
+ * segments; blocks are dealt to XCDs in contiguous runs so that neighbouring tiles (which
+ * read neighbouring RF windows) share an L2.  Gather-accumulate, VALU/L1-bound: no MFMA.
+ */
+#include "das_common.h"
+
+/* demodulation phase of a partial sample index, in turns in [0,1): fract(k * index) with the
+ * rounding error of the product recovered by an fma, so that splitting the phase in two
+ * parts does not cost precision (Q3 of oracle/oracle.h: the phase is defined range-reduced) */
+__device__ __forceinline__ float phase_turns(float k, float index)
+{
+	float p = k * index;
+	float e = __builtin_fmaf(k, index, -p);
+	return hw_fract(p) + e;
+}
+
+/* LDS tables, 16-byte entries so that every read is one ds_read_b128:
+ *   R[(c - c0)*U + u] = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }   (apod == 0: fails the F# test)
+ *   T[a*V + v]        = { t_index, cos(phi_t), sin(phi_t), 0 }
+ * For real data the phasors are (1, 0).  T covers every transmit; R covers a chunk of
+ * q.channel_chunk channels at a time and is rebuilt between chunks, which keeps the block's
+ * LDS under 80 KB so that two 1024-thread blocks (8 waves per SIMD) share a CU: the gathers
+ * are latency bound at lower occupancy. */
+template <int INTERP, bool CPLX, bool CW>
+__global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasArgs p, const BfSeparableArgs q)
+{
+	extern __shared__ __attribute__((aligned(16))) f32x4 sep_lds[];
+	const uint32_t U = 1u << q.u_shift, V = 1u << q.v_shift;
+	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
+	const int chunk = (int)q.channel_chunk;
+	f32x4 *R = sep_lds;
+	f32x4 *T = sep_lds + (size_t)chunk * U;
+
+	/* blockIdx -> tile with each XCD walking a contiguous run of tiles (das.hip) */
+	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
+	const uint32_t per   = (total + 7u) / 8u;
+	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+	if (tile >= total) return;                               /* whole block: no barrier is skipped */
+	const uint32_t tu = tile % q.tiles[0];                    /* along the receive axis */
+	const uint32_t tv = (tile / q.tiles[0]) % q.tiles[1];     /* along the transmit axis */
+	const uint32_t zl = tile / (q.tiles[0] * q.tiles[1]);     /* plane inside the shard */
+	const uint32_t z  = p.z_first + zl;
+
+	const uint32_t u_axis = q.u_axis, v_axis = 1u - q.u_axis;
+	const float denom[3] = {fmaxf(1.0f, (float)p.size[0] - 1.0f), fmaxf(1.0f, (float)p.size[1] - 1.0f),
+	                        fmaxf(1.0f, (float)p.size[2] - 1.0f)};
+	const float pz = (float)z / denom[2];
+	const float phase_k = p.demodulation_frequency * p.inv_sampling_frequency;
+	const BfTransmit t0 = p.transmits[0];
+	const bool  rx_rows = (t0.flags & BF_RX_ROWS) != 0;
+	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
+
+	/* ---- transmit table: A x V entries, built once */
+	for (uint32_t e = threadIdx.x; e < (uint32_t)A * V; e += blockDim.x) {
+		uint32_t a = e >> q.v_shift, iv = e & (V - 1);
+		float coord[3] = {0.f, 0.f, pz};
+		coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
+		float wx, wy, wz;
+		m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+		const BfTransmit t = p.transmits[a];
+		float dist = 0.f;
+		if (!(t.flags & BF_TX_NONE)) {
+			float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+			if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
+			else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
+		}
+		float t_idx = (dist * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+		f32x4 entry = {t_idx, 1.f, 0.f, 0.f};
+		if constexpr (CPLX) {
+			float turns = phase_turns(phase_k, t_idx);
+			entry.y = hw_cos_turns(turns);
+			entry.z = hw_sin_turns(turns);
+		}
+		T[e] = entry;
+	}
+
+	/* thread -> voxel: lanes run along the output's x axis */
+	uint32_t lu, lv;
+	if (u_axis == 0) { lu = threadIdx.x & (U - 1); lv = threadIdx.x >> q.u_shift; }
+	else             { lv = threadIdx.x & (V - 1); lu = threadIdx.x >> q.v_shift; }
+	const uint32_t gu = tu * U + lu, gv = tv * V + lv;
+	const uint32_t x = u_axis == 0 ? gu : gv, y = u_axis == 0 ? gv : gu;
+	const bool inside = x < p.size[0] && y < p.size[1];
+
+	using VT = sample_t<CPLX>;
+	VT    coherent   = zero_sample<CPLX>();
+	float incoherent = 0.f;
+
+	const char *rf = (const char *)p.rf;
+	constexpr uint32_t ES = CPLX ? 8 : 4;
+	const float    fS = (float)S;
+	const uint32_t row_bytes = (uint32_t)S * ES;
+	const f32x4   *Rl = R + lu, *Tl = T + lv;
+
+	for (int c0 = 0; c0 < C; c0 += chunk) {
+		const int cn = (C - c0) < chunk ? (C - c0) : chunk;
+		__syncthreads();            /* previous chunk's readers are done (and T is complete) */
+		/* ---- receive table for channels [c0, c0 + cn) */
+		for (uint32_t e = threadIdx.x; e < (uint32_t)cn * U; e += blockDim.x) {
+			uint32_t c = (uint32_t)c0 + (e >> q.u_shift), iu = e & (U - 1);
+			float coord[3] = {0.f, 0.f, pz};
+			coord[u_axis] = (float)(tu * U + iu) / denom[u_axis];
+			float wx, wy, wz, xx, xy, xz;
+			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+			float lateral = rx_rows ? xy : xx;
+			float dx      = lateral - (float)c * rx_pitch;
+			float a_arg   = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(xz))));
+			f32x4 entry   = {0.f, 0.f, 0.f, 0.f};
+			if (a_arg < 0.5f) {
+				float cs    = hw_cos_turns(0.5f * a_arg);
+				float apod  = cs * cs;
+				float r_idx = hw_sqrt(dx * dx + xz * xz) * p.inv_speed_of_sound * p.sampling_frequency;
+				entry.x = r_idx;
+				entry.w = apod;
+				if constexpr (CPLX) {
+					float turns = phase_turns(phase_k, r_idx);
+					entry.y = apod * hw_cos_turns(turns);
+					entry.z = apod * hw_sin_turns(turns);
+				} else {
+					entry.y = apod;
+				}
+			}
+			R[e] = entry;
+		}
+		__syncthreads();
+		if (!inside) continue;
+
+		for (int cl = 0; cl < cn; cl++) {
+			const f32x4 r = Rl[(size_t)cl * U];
+			/* F# culling: skip the channel when no lane of the wave is inside the aperture */
+			if (__builtin_amdgcn_ballot_w64(r.w != 0.f) == 0) continue;
+			VT    sum = zero_sample<CPLX>();
+			float mag = 0.f;
+			uint32_t row = (uint32_t)(c0 + cl) * (uint32_t)A * row_bytes;
+			/* transmits in batches of B: B broadcast table reads, B index splits, B gathers in
+			 * flight, then B interpolate + rotate-accumulate steps */
+			constexpr int B = 4;
+			auto term = [&](const f32x4 &t, VT sv) {
+				if constexpr (CPLX) {
+					sum.x += sv.x * t.y - sv.y * t.z;
+					sum.y += sv.x * t.z + sv.y * t.y;
+					if constexpr (CW) mag += hw_sqrt(sv.x * sv.x + sv.y * sv.y);
+				} else {
+					sum += sv;
+					if constexpr (CW) mag += __builtin_fabsf(sv);
+				}
+			};
+			int a = 0;
+			for (; a + B <= A; a += B, row += B * row_bytes) {
+				f32x4 t[B];
+				Tap<INTERP> tap[B];
+				TapData<INTERP, CPLX> d[B];
+				#pragma unroll
+				for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k) * V];
+				#pragma unroll
+				for (int k = 0; k < B; k++) tap[k] = tap_setup<INTERP, CPLX>(r.x + t[k].x, fS, S - 1);
+				#pragma unroll
+				for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, row + (uint32_t)k * row_bytes + tap[k].off);
+				#pragma unroll
+				for (int k = 0; k < B; k++) term(t[k], tap_finish<INTERP, CPLX>(tap[k], d[k]));
+			}
+			for (; a < A; a++, row += row_bytes) {
+				const f32x4 t = Tl[(size_t)a * V];
+				term(t, interpolate<INTERP, CPLX>(rf, row, r.x + t.x, fS, S - 1));
+			}
+			if constexpr (CPLX) {
+				coherent.x += sum.x * r.y - sum.y * r.z;
+				coherent.y += sum.x * r.z + sum.y * r.y;
+			} else {
+				coherent += sum * r.y;
+			}
+			if constexpr (CW) incoherent += r.w * mag;
+		}
+	}
+	if (!inside) return;
+
+	uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
+	if constexpr (CW) coherent = coherent * (coherent / incoherent);   /* coherency_weighting.glsl:36 */
+	reinterpret_cast<VT *>(p.out)[out_index] = coherent;
+}
+
+template <int INTERP, bool CPLX, bool CW>
+static hipError_t launch_sep(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
+{
+	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
+	uint32_t grid  = ((total + 7u) / 8u) * 8u;
+	auto kernel = das_rca_separable_kernel<INTERP, CPLX, CW>;
+	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(q->threads), q->lds_bytes, s, *a, *q);
+	return hipGetLastError();
+}
+
+template <int INTERP>
+static hipError_t launch_sep_kind(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
+{
+	if (a->complex_data) return a->coherency_weighting ? launch_sep<INTERP, true,  true>(a, q, s) : launch_sep<INTERP, true,  false>(a, q, s);
+	return a->coherency_weighting ? launch_sep<INTERP, false, true>(a, q, s) : launch_sep<INTERP, false, false>(a, q, s);
+}
+
+extern "C" hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
+{
+	switch (a->interpolation) {
+	case BF_INTERP_NEAREST: return launch_sep_kind<BF_INTERP_NEAREST>(a, q, s);
+	case BF_INTERP_LINEAR:  return launch_sep_kind<BF_INTERP_LINEAR>(a, q, s);
+	case BF_INTERP_CUBIC:   return launch_sep_kind<BF_INTERP_CUBIC>(a, q, s);
+	}
+	return hipErrorInvalidValue;
+}

@@ -257,6 +257,80 @@ static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint3
 	shift[0] += left;   /* fewer than 256 voxels in total: idle lanes */
 }
 
+/* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
+ * receive and one transmit orientation for all transmits, on different transducer axes, a
+ * volume whose z axis alone carries depth, and voxel x / y axes that each move only one of
+ * the two lateral coordinates -- every coefficient that must vanish has to be an exact
+ * zero product, so that the tables reproduce the general kernel's per-voxel arithmetic. */
+static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
+                           uint32_t zcount, BfSeparableArgs &q)
+{
+	if (a.family != BF_DAS_RCA || tx.empty()) return false;
+	const uint32_t orient = BF_TX_ROWS | BF_RX_ROWS | BF_TX_NONE;
+	for (const BfTransmit &t : tx) if ((t.flags & orient) != (tx[0].flags & orient)) return false;
+	const bool tx_none = (tx[0].flags & BF_TX_NONE) != 0;
+	const int  r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0;      /* transducer coordinate the receive aperture uses */
+	const int  w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;      /* world coordinate the transmit uses */
+	auto W = [&](int row, int col) { return vox[4 * col + row]; };
+	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
+	/* transducer coordinate `row` must not move with voxel axis `col` */
+	auto xdc_fixed = [&](int row, int col) {
+		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return false;
+		return true;
+	};
+	if (a.size[0] < 2 || a.size[1] < 2) return false;
+	for (int col = 0; col < 2; col++) {
+		if (!xdc_fixed(2, col)) return false;                 /* transducer depth: voxel z only */
+		if (!tx_none && W(2, col) != 0.f) return false;       /* world depth: voxel z only */
+	}
+	int u_axis = -1;
+	for (int u = 0; u < 2 && u_axis < 0; u++) {
+		int v = 1 - u;
+		if (!xdc_fixed(r, v)) continue;                       /* receive lateral: not along v */
+		if (!tx_none && W(w, u) != 0.f) continue;             /* transmit lateral: not along u */
+		u_axis = u;
+	}
+	if (u_axis < 0) return false;
+
+	/* Tile (U along the receive axis, V along the transmit axis), block size and the number of
+	 * channels per receive-table chunk: maximise resident waves per CU (LDS: 160 KB per CU, 32
+	 * waves per CU), then prefer big chunks (fewer rebuilds) and square-ish tiles. */
+	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
+	const uint32_t lds_cu = 160u * 1024u;
+	uint32_t best_waves = 0, best_score = 0;
+	for (uint32_t threads_shift = 10; threads_shift >= 8; threads_shift--) {
+		for (uint32_t us = 2; us + 2 <= threads_shift; us++) {
+			uint32_t vs = threads_shift - us;
+			if ((u_axis == 0 ? us : vs) < 4) continue;        /* >= 16 lanes of a wave along x */
+			for (uint32_t chunk = 16; chunk <= 256; chunk *= 2) {
+				uint32_t cc = chunk < C ? chunk : C;
+				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A << vs));
+				if (lds > lds_cu) continue;
+				uint32_t blocks = (uint32_t)(lds_cu / lds);
+				uint32_t by_waves = 2048u >> threads_shift;
+				if (blocks > by_waves) blocks = by_waves;
+				uint32_t waves = blocks << (threads_shift - 6);
+				uint32_t balance = us > vs ? us - vs : vs - us;
+				uint32_t score = (cc << 4) + (16 - balance);
+				if (waves > best_waves || (waves == best_waves && score > best_score)) {
+					best_waves = waves; best_score = score;
+					q.u_shift = us; q.v_shift = vs; q.threads = 1u << threads_shift;
+					q.channel_chunk = cc; q.lds_bytes = (uint32_t)lds;
+				}
+				if (cc == C) break;
+			}
+		}
+	}
+	if (!best_waves) return false;
+	q.u_axis = (uint32_t)u_axis;
+	const uint32_t best_u = q.u_shift, best_v = q.v_shift;
+	uint32_t nu = a.size[u_axis], nv = a.size[1 - u_axis];
+	q.tiles[0] = (nu + (1u << best_u) - 1) >> best_u;
+	q.tiles[1] = (nv + (1u << best_v) - 1) >> best_v;
+	q.tiles[2] = zcount;
+	return true;
+}
+
 static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
 {
 	return HIP_OK(hipEventRecord(t.events[index], s));
@@ -294,6 +368,7 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 	int64_t cur_elements_bytes = (int64_t)c.rf[rf_slot].size;
 	int toggle = 0;
 	bool ok = true, das_segment_done = false;
+	uint32_t das_path = 0;
 
 	for (size_t i = 0; i < plan.stages.size() && ok; i++) {
 		const Stage &st = plan.stages[i];
@@ -400,7 +475,13 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 			if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
 			} else {
-				ok &= HIP_OK(bf_launch_das(&a, s));
+				BfSeparableArgs sep{};
+				if (c.das_path_mode == 0 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+					ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
+					das_path = 1;
+				} else {
+					ok &= HIP_OK(bf_launch_das(&a, s));
+				}
 				if (c.count_pairs) {
 					/* geometry-only recount of the apodization test; its own segment so that it
 					 * stays out of the DAS time */
@@ -417,7 +498,7 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 			t.das_voxels = (uint64_t)ext[0] * ext[1] * ext[2];
 			t.das_taps = a.interpolation == 0 ? 1 : a.interpolation == 1 ? 2 : 4;
 			t.das_sample_bytes = plan.iq_pipeline ? 8 : 4;
-			t.das_path = 0; t.frame_id = f->id;
+			t.das_path = das_path; t.frame_id = f->id;
 		}break;
 		case BeamformerShaderKind_CoherencyWeighting:
 			/* fused into the DAS epilogue (das.hip); kept in the plan so that the stage list a

@@ -31,6 +31,12 @@ def _cases():
     c["rca_vls_cw"] = lambda: cfg.rca("rca_vls_cw", 32, 4, 512, (12, 10, 14), LO3, HI3, seed=13, cw=True,
                                       kind=K.RCA_VLS, orientation=0x21, depths=np.array([-10e-3, 25e-3, -15e-3, 40e-3]),
                                       angles=np.array([-5.0, 0.0, 5.0, 10.0]), f_number=0.7)
+    c["rca_sep_ragged_cubic"] = lambda: cfg.rca("rca_sep_ragged_cubic", 32, 5, 512, (21, 37, 5), LO3, HI3, seed=41,
+                                                interp=I.Cubic, orientation=0x12, cw=True, f_number=1.5,
+                                                angles=np.linspace(-8, 8, 5))
+    c["rca_sep_real_nearest"] = lambda: cfg.rca("rca_sep_real_nearest", 16, 3, 512, (19, 18, 3), LO3, HI3, seed=42,
+                                                interp=I.Nearest, orientation=0x21, demodulate=False,
+                                                angles=np.linspace(-5, 5, 3))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

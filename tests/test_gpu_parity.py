@@ -32,9 +32,57 @@ def compare(gpu, ref, acq):
     return float(err.max())
 
 
+def last_das_path(bflib):
+    import ctypes as C
+    t = P.HipFrameTimings()
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
+    return int(t.das_path)
+
+
+# geometries whose receive and transmit axes differ: the separable-delay fast path must pick
+# them up on its own (das_separable.hip)
+SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest"}
+
+
 @pytest.mark.parametrize("name", sorted(cases.CASES))
 def test_frame_parity(name, bflib, oracle):
+    """default (automatic) DAS path"""
     acq = cases.make(name)
     ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    bflib.library().beamformer_hip_set_das_path(0)
     gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    assert last_das_path(bflib) == (1 if name in SEPARABLE else 0)
     compare(gpu, ref, acq)
+
+
+@pytest.mark.parametrize("name", sorted(SEPARABLE))
+def test_general_kernel_on_separable_geometry(name, bflib, oracle):
+    """the general kernel on the cases the fast path would otherwise take"""
+    acq = cases.make(name)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    lib.beamformer_hip_set_das_path(1)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == 0
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq)
+
+
+def test_pair_count_matches_oracle(bflib, oracle):
+    """G of the roofline model: the geometry-only count kernel agrees with the oracle's tally
+    of taken apodization branches (exactly, up to aperture-edge rounding)."""
+    import ctypes as C
+    lib = bflib.library()
+    for name in ("config4_small", "rca_vls_cw", "hercules_real", "forces"):
+        acq = cases.make(name)
+        _, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+        lib.beamformer_hip_enable_pair_counting(1)
+        try:
+            bflib.beamform(acq.bp, acq.rf, acq.filters)
+            t = P.HipFrameTimings()
+            assert lib.beamformer_hip_get_last_frame_timings(C.byref(t))
+        finally:
+            lib.beamformer_hip_enable_pair_counting(0)
+        assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs), (name, int(t.das_pairs), pairs)
