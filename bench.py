@@ -59,7 +59,7 @@ def main():
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if distributed else 0)
 
-    from ogl_beamforming_amd import configs, lib, params as P
+    from ogl_beamforming_amd import configs, lib, params as P, sharding
     L = lib.library()
     assert L.beamformer_hip_set_device(device.index), lib.last_error()
     L.beamformer_hip_set_das_path(args.das_path)
@@ -72,8 +72,7 @@ def main():
     for slot, fp in enumerate(acq.filters):
         assert L.beamformer_create_filter(C.byref(fp), slot, 0), lib.last_error()
     assert L.beamformer_push_simple_parameters(C.byref(bp)), lib.last_error()
-    z_first = rank * Z // world
-    z_count = (rank + 1) * Z // world - z_first
+    z_first, z_count = sharding.slab(rank, world, Z)
     if args.planes and not distributed:
         z_count = min(Z, args.planes)
         z_first = (Z - z_count) // 2
@@ -90,7 +89,7 @@ def main():
 
     def step():
         if distributed:
-            dist.broadcast(rf_dev, src=0)          # RCCL over xGMI; same stream as the kernels
+            sharding.broadcast_rf(rf_dev, src=0)   # RCCL over xGMI; same stream as the kernels
         ok = L.beamformer_hip_push_device_data_with_compute(C.c_void_p(rf_dev.data_ptr()), rf_dev.numel(), 0, 0)
         assert ok, lib.last_error()
 

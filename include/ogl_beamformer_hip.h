@@ -88,6 +88,35 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_frame_min_max(float out_min_max[2]
  * 1 = always the general kernel.  For parity testing of both paths. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 
+/* ---- host-side introspection (no device needed; used by tests/ to pin the host math
+ * against the compiled reference and to check the planner) ---- */
+
+/* Hadamard matrix this library uploads for Decode: order*order floats, row major,
+ * Ht[order*j + i] (math.c:35-134).  Returns 0 when no construction exists. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_host_hadamard(uint32_t order, float *out);
+
+/* Filter taps this library generates for a beamformer_create_filter() request
+ * (beamformer_core.c:366-398).  Returns the tap count (pairs when *complex_taps), or -1. */
+BEAMFORMER_LIB_EXPORT int32_t beamformer_hip_host_filter(const BeamformerFilterParameters *filter, float *taps,
+                                                         uint32_t capacity_floats, float *time_delay,
+                                                         uint32_t *complex_taps);
+
+typedef struct {
+	int32_t kind;                     /* BeamformerShaderKind */
+	int32_t in_kind, out_kind;        /* BeamformerDataKind */
+	int64_t in_stride[3], out_stride[3];   /* sample, channel, transmit (elements) */
+} BeamformerHipPlanStage;
+typedef struct {
+	uint32_t stage_count;
+	BeamformerHipPlanStage stages[BeamformerMaxComputeShaderStages];
+	uint32_t das_samples, iq_pipeline;
+	float    das_sampling_frequency, das_time_offset;
+	float    das_voxel_transform[16];
+} BeamformerHipPlan;
+/* The stage list the library would run for a parameter block (plan_compute_pipeline,
+ * beamformer_core.c:553-1013, with the whole channel count as the chunk). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_describe_plan(uint32_t parameter_slot, BeamformerHipPlan *out);
+
 /* Free every device resource; the next call re-initialises. */
 BEAMFORMER_LIB_EXPORT void beamformer_hip_shutdown(void);
 

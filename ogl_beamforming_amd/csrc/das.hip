@@ -33,15 +33,59 @@ __device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const BfDasArg
 	return f32x2{c * iq.x - s * iq.y, s * iq.x + c * iq.y};
 }
 
-/* das.glsl:99-124 (+ cubic :67-97); rf_offset is the element index of the row's sample 0.
- * Branch-free (das_common.h): an out-of-range index yields +0. */
+/* das.glsl:99-124 (+ cubic :67-97).  rf_offset is the element index of the row's sample 0.
+ * The general kernel keeps the reference's test-then-load form: it runs at 8 waves per SIMD and
+ * is VALU bound, so the extra select/clamp work of the branch-free form (das_common.h, used by
+ * the fast path) costs more than the serialised gathers do. */
 template <int INTERP, bool CPLX>
 __device__ __forceinline__ sample_t<CPLX> sample_rf(const char *rf, int rf_offset, float index, const BfDasArgs &p)
 {
 	constexpr uint32_t ES = CPLX ? 8 : 4;
-	sample_t<CPLX> result = interpolate<INTERP, CPLX>(rf, (uint32_t)rf_offset * ES, index,
-	                                                  (float)p.sample_count, p.sample_count - 1);
-	if constexpr (CPLX) result = rotate_iq(result, index, p);
+	sample_t<CPLX> result = zero_sample<CPLX>();
+	const float S = (float)p.sample_count;
+	if constexpr (INTERP == BF_INTERP_NEAREST) {
+		if (index >= 0.f && index < S - 0.5f) {
+			int k = (int)__builtin_roundf(index);
+			result = gather<sample_t<CPLX>>(rf, (uint32_t)(rf_offset + k) * ES);
+			if constexpr (CPLX) result = rotate_iq(result, index, p);
+		}
+	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+		if (index >= 0.f && index < S - 1.f) {
+			float tk = __builtin_floorf(index), t = index - tk;
+			uint32_t off = (uint32_t)(rf_offset + (int)tk) * ES;
+			if constexpr (CPLX) {
+				f32x4 v = gather<f32x4_a8>(rf, off);
+				f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+				result = (1.f - t) * a + t * b;
+				result = rotate_iq(result, index, p);
+			} else {
+				f32x2 v = gather<f32x2_a4>(rf, off);
+				result = (1.f - t) * v.x + t * v.y;
+			}
+		}
+	} else {
+		if (index >= 1.f && index < S - 2.f) {
+			float tk = __builtin_floorf(index), t = index - tk;
+			uint32_t off = (uint32_t)(rf_offset + (int)tk - 1) * ES;
+			float t2 = t * t, t3 = t2 * t;
+			/* Hermite basis with tangents 0.5 (P2 - P0), 0.5 (P3 - P1) */
+			float b0 =  2.f * t3 - 3.f * t2 + 1.f;
+			float b1 = -2.f * t3 + 3.f * t2;
+			float b2 =        t3 - 2.f * t2 + t;
+			float b3 =        t3 -       t2;
+			if constexpr (CPLX) {
+				f32x4 lo = gather<f32x4_a8>(rf, off), hi = gather<f32x4_a8>(rf, off + 16);
+				f32x2 s0 = {lo.x, lo.y}, s1 = {lo.z, lo.w}, s2 = {hi.x, hi.y}, s3 = {hi.z, hi.w};
+				f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1);
+				result = b0 * s1 + b1 * s2 + b2 * T1 + b3 * T2;
+				result = rotate_iq(result, index, p);
+			} else {
+				f32x4 v = gather<f32x4_a4>(rf, off);
+				float T1 = 0.5f * (v.z - v.x), T2 = 0.5f * (v.w - v.y);
+				result = b0 * v.y + b1 * v.z + b2 * T1 + b3 * T2;
+			}
+		}
+	}
 	return result;
 }
 
@@ -110,11 +154,9 @@ __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, floa
 			bool  pass  = a_arg < 0.5f;
 			if constexpr (COUNT) {
 				acc.pairs += pass;
-			} else if (__builtin_amdgcn_ballot_w64(pass)) {
-				/* the F# test is taken per wave; lanes outside the aperture get weight 0 */
+			} else if (pass) {
 				float sidx = sample_index(tx_dist + hw_sqrt(dx * dx + zz), p);
-				float apod = pass ? apodize(a_arg) : 0.f;
-				acc.add(apod * sample_rf<INTERP, CPLX>(rf, rf_offset, sidx, p));
+				acc.add(apodize(a_arg) * sample_rf<INTERP, CPLX>(rf, rf_offset, sidx, p));
 			}
 			rf_offset += S * A;
 		}
@@ -153,9 +195,9 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 			bool pass = element_delta_squared < apodization_test;
 			if constexpr (COUNT) {
 				acc.pairs += pass;
-			} else if (__builtin_amdgcn_ballot_w64(pass)) {
-				float apodization = pass ? (transmit == 0 ? first_weight : 1.0f)
-				                           * apodize(f_number_over_z * hw_sqrt(element_delta_squared)) : 0.f;
+			} else if (pass) {
+				float apodization = (transmit == 0 ? first_weight : 1.0f)
+				                    * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
 				float index = transmit_index + hw_sqrt(z_delta_squared + element_delta_squared) * fs_over_c;
 				acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 			}
@@ -182,11 +224,11 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 	for (int channel = 0; channel < C; channel++) {
 		float receive_x_delta = xx - (float)channel * p.pitch[0];
 		float a_arg           = __builtin_fabsf(receive_x_delta * f_over_z);
-		bool  pass            = a_arg < 0.5f;
-		if (!__builtin_amdgcn_ballot_w64(pass)) continue;
+		const bool pass       = a_arg < 0.5f;
+		if (!pass) continue;
 
 		float receive_index = sample_index(hw_sqrt(receive_x_delta * receive_x_delta + z_delta_squared), p);
-		float apodization   = (COUNT || !pass) ? 0.f : apodize(a_arg);
+		float apodization   = COUNT ? 0.f : apodize(a_arg);
 
 		if constexpr (!READI) {
 			int rf_offset = channel * S * A + sparse * S;

@@ -423,6 +423,44 @@ uint32_t beamformer_hip_frame_min_max(float out_min_max[2])
 
 uint32_t beamformer_hip_set_das_path(uint32_t mode) { ctx().das_path_mode = mode; return 1; }
 
+uint32_t beamformer_hip_host_hadamard(uint32_t order, float *out)
+{
+	std::vector<float> h = hadamard_transpose((int)order);
+	if (h.empty()) return 0;
+	std::memcpy(out, h.data(), sizeof(float) * h.size());
+	return 1;
+}
+
+int32_t beamformer_hip_host_filter(const BeamformerFilterParameters *filter, float *taps, uint32_t capacity_floats,
+                                   float *time_delay, uint32_t *complex_taps)
+{
+	Filter f;
+	if (!filter_create(*filter, f) || f.taps.size() > capacity_floats) return -1;
+	std::memcpy(taps, f.taps.data(), sizeof(float) * f.taps.size());
+	if (time_delay)   *time_delay   = f.time_delay;
+	if (complex_taps) *complex_taps = f.complex_taps;
+	return f.length;
+}
+
+uint32_t beamformer_hip_describe_plan(uint32_t parameter_slot, BeamformerHipPlan *out)
+{
+	if (!valid_parameter_block(parameter_slot)) return 0;
+	Plan plan;
+	std::string error;
+	if (!build_plan(ctx().blocks[parameter_slot], plan, error)) return check(false, BeamformerLibErrorKind_InvalidComputeStage);
+	std::memset(out, 0, sizeof(*out));
+	out->stage_count = (uint32_t)plan.stages.size();
+	for (size_t i = 0; i < plan.stages.size() && i < BeamformerMaxComputeShaderStages; i++) {
+		const Stage &st = plan.stages[i];
+		out->stages[i].kind = st.kind; out->stages[i].in_kind = st.in_kind; out->stages[i].out_kind = st.out_kind;
+		for (int k = 0; k < 3; k++) { out->stages[i].in_stride[k] = st.in_stride[k]; out->stages[i].out_stride[k] = st.out_stride[k]; }
+	}
+	out->das_samples = plan.das_samples; out->iq_pipeline = plan.iq_pipeline;
+	out->das_sampling_frequency = plan.das_sampling_frequency; out->das_time_offset = plan.das_time_offset;
+	std::memcpy(out->das_voxel_transform, plan.das_voxel_transform, sizeof(out->das_voxel_transform));
+	return 1;
+}
+
 void beamformer_hip_shutdown(void) { shutdown_device(); }
 
 } // extern "C"

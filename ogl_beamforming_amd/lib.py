@@ -77,6 +77,10 @@ def _load():
         "beamformer_hip_enable_pair_counting": (u32, [u32]),
         "beamformer_hip_frame_min_max": (u32, [C.POINTER(C.c_float)]),
         "beamformer_hip_set_das_path": (u32, [u32]),
+        "beamformer_hip_host_hadamard": (u32, [u32, C.POINTER(C.c_float)]),
+        "beamformer_hip_host_filter": (i32, [C.POINTER(P.FilterParameters), C.POINTER(C.c_float), u32,
+                                        C.POINTER(C.c_float), C.POINTER(u32)]),
+        "beamformer_hip_describe_plan": (u32, [u32, C.POINTER(P.HipPlan)]),
         "beamformer_hip_shutdown": (None, []),
     }
     for name, (restype, argtypes) in sig.items():

@@ -215,6 +215,18 @@ class HipFrameTimings(C.Structure):
     ]
 
 
+class HipPlanStage(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_kind", C.c_int32), ("out_kind", C.c_int32),
+                ("in_stride", C.c_int64 * 3), ("out_stride", C.c_int64 * 3)]
+
+
+class HipPlan(C.Structure):
+    _fields_ = [("stage_count", C.c_uint32), ("stages", HipPlanStage * MAX_STAGES),
+                ("das_samples", C.c_uint32), ("iq_pipeline", C.c_uint32),
+                ("das_sampling_frequency", C.c_float), ("das_time_offset", C.c_float),
+                ("das_voxel_transform", C.c_float * 16)]
+
+
 assert C.sizeof(Parameters) == 264
 assert C.sizeof(SimpleParameters) == 3728
 assert C.sizeof(FilterParameters) == 24

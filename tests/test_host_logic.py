@@ -1,0 +1,181 @@
+"""Host logic of the C ABI that needs no GPU: parameter validation in the reference's order
+and with its error codes (lib/ogl_beamformer_lib.c:252-311, :438-456, :509-511), the planner
+(beamformer_core.c:553-1013) against SURVEY's worked examples and the oracle's restatement."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ogl_beamforming_amd import configs as cfg
+from ogl_beamforming_amd import params as P
+from tests import cases
+
+E = P.LibError
+S = P.ShaderKind
+D = P.DataKind
+
+
+@pytest.fixture()
+def L(bflib):
+    lib = bflib.library()
+    lib.beamformer_reserve_parameter_blocks(1)
+    return lib
+
+
+def err(bflib):
+    return bflib.last_error()[0]
+
+
+def base_parameters():
+    return cfg.config(1, 0.25).bp
+
+
+def test_validate_parameters_order(L, bflib):
+    bp = base_parameters()
+    assert L.beamformer_push_simple_parameters(C.byref(bp))
+    p = P.Parameters.from_buffer_copy(bytes(bp)[:264])
+    p.contrast_mode = 7
+    assert not L.beamformer_push_parameters(C.byref(p)) and err(bflib) == E.InvalidContrastMode
+    p.contrast_mode = 1                                   # A1S2 needs 3x the samples per row
+    assert not L.beamformer_push_parameters(C.byref(p)) and err(bflib) == E.DataSizeMismatch
+    p.contrast_mode = 0
+    p.raw_data_dimensions[0] = p.sample_count * p.acquisition_count - 1
+    assert not L.beamformer_push_parameters(C.byref(p)) and err(bflib) == E.DataSizeMismatch
+    p.raw_data_dimensions[0] = p.sample_count * p.acquisition_count
+    p.output_points[:] = [1024, 1024, 1024, 1]            # 8 GiB frame > 4 GiB ring
+    assert not L.beamformer_push_parameters(C.byref(p)) and err(bflib) == E.FrameSizeOverflow
+    assert L.beamformer_maximum_frames_for_parameters(C.byref(p)) == 2**64 - 1
+    p.output_points[:] = [512, 512, 512, 1]
+    p.coherency_weighting = 0
+    assert L.beamformer_maximum_frames_for_parameters(C.byref(p)) == 4     # 4 GiB ring / 1 GiB
+    p.coherency_weighting = 1
+    assert L.beamformer_maximum_frames_for_parameters(C.byref(p)) == 3     # lib .c:262-273
+
+
+def test_validate_pipeline_order(L, bflib):
+    def push(stages, kind):
+        arr = (C.c_int32 * len(stages))(*[int(s) for s in stages])
+        return L.beamformer_push_pipeline(arr, len(stages), int(kind))
+    assert not push([S.Demodulate, S.DAS], 9) and err(bflib) == E.InvalidDataKind
+    assert not push([S.Demodulate] * 17, D.Int16) and err(bflib) == E.ComputeStageOverflow
+    assert not push([S.Demodulate, S.Reshape], D.Int16) and err(bflib) == E.InvalidComputeStage
+    assert not push([S.Decode, S.Hilbert, S.DAS], D.Int16) and err(bflib) == E.InvalidComputeStage   # capabilities.hilbert = 0
+    assert not push([S.Demodulate, S.DAS], D.Int16Complex) and err(bflib) == E.InvalidDemodulationDataKind
+    assert not push([S.DAS], D.Int16) and err(bflib) == E.InvalidStartShader
+    assert not push([S.Filter, S.DAS], D.Int16) and err(bflib) == E.InvalidStartShader
+    assert push([S.Demodulate, S.Decode, S.DAS], D.Int16)
+    assert push([S.Decode, S.DAS], D.Float32Complex)
+
+
+def test_block_and_array_limits(L, bflib):
+    assert not L.beamformer_reserve_parameter_blocks(17) and err(bflib) == E.ParameterBlockOverflow
+    assert L.beamformer_reserve_parameter_blocks(2)
+    bp = base_parameters()
+    assert L.beamformer_push_simple_parameters_at(C.byref(bp), 1)
+    assert not L.beamformer_push_simple_parameters_at(C.byref(bp), 2) and err(bflib) == E.ParameterBlockUnallocated
+    mapping = (C.c_int16 * 300)()
+    assert not L.beamformer_push_channel_mapping(mapping, 257) and err(bflib) == E.BufferOverflow
+    assert L.beamformer_push_channel_mapping(mapping, 256)
+    fv = (C.c_float * 600)()
+    assert not L.beamformer_push_focal_vectors(fv, 257) and err(bflib) == E.BufferOverflow
+    assert L.beamformer_push_focal_vectors(fv, 256)
+    f = P.FilterParameters()
+    f.kind = 5
+    assert not L.beamformer_create_filter(C.byref(f), 0, 0) and err(bflib) == E.InvalidFilterKind
+    assert L.beamformer_reserve_parameter_blocks(1)
+
+
+def test_live_parameters_roundtrip(L):
+    lp = P.LiveImagingParameters()
+    lp.active = 1
+    lp.transmit_power = 0.5
+    assert L.beamformer_set_live_parameters(C.byref(lp))
+    back = L.beamformer_get_live_parameters().contents
+    assert back.active == 1 and back.transmit_power == 0.5
+    assert L.beamformer_live_parameters_get_dirty_flag() == -1
+
+
+def test_compute_fails_loudly_without_a_device(L, bflib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    acq = cfg.config(1, 0.25)
+    assert L.beamformer_push_simple_parameters(C.byref(acq.bp))
+    rf = np.ascontiguousarray(acq.rf)
+    assert not L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0)
+    assert err(bflib) == E.SharedMemory                    # no CPU fallback
+    out = np.zeros(16, np.float32)
+    assert not L.beamformer_get_last_frames(out.ctypes.data_as(C.c_void_p), out.nbytes, 1)
+    assert L.beamformer_maximum_rf_data_size() == 2**64 - 1
+
+
+def describe(L, acq):
+    for slot, fp in enumerate(acq.filters):
+        assert L.beamformer_create_filter(C.byref(fp), slot, 0)
+    assert L.beamformer_push_simple_parameters(C.byref(acq.bp))
+    plan = P.HipPlan()
+    assert L.beamformer_hip_describe_plan(0, C.byref(plan))
+    return plan
+
+
+def test_planner_worked_example_a(L):
+    """SURVEY section 8a example A: Int16, {Demodulate, Decode, DAS}, Hadamard, C 256, A 128, S 4096"""
+    acq = cfg.hercules("example_a", 256, 128, 4096, (8, 8, 8), (-1e-3, -1e-3, 5e-3), (1e-3, 1e-3, 9e-3), seed=1,
+                       stages=(S.Demodulate, S.Decode, S.DAS))
+    plan = describe(L, acq)
+    kinds = [plan.stages[i].kind for i in range(plan.stage_count)]
+    assert kinds == [S.Demodulate, S.Decode, S.DAS]
+    demod, decode, das = plan.stages[0], plan.stages[1], plan.stages[2]
+    assert (demod.in_kind, demod.out_kind) == (D.Int16Complex, D.Float16Complex)
+    assert list(demod.in_stride) == [1, 4096 * 128, 4096]            # raw real-sample units
+    assert list(demod.out_stride) == [256 * 128, 128, 1]             # [sample][channel][transmit], chunk = all channels
+    assert (decode.in_kind, decode.out_kind) == (D.Float16Complex, D.Float32Complex)
+    assert list(decode.out_stride) == [1, 2048 * 128, 2048]
+    assert (das.in_kind, das.out_kind) == (D.Float32Complex, D.Float32Complex)
+    assert plan.das_samples == 2048 and plan.iq_pipeline == 1
+    assert plan.das_sampling_frequency == pytest.approx(12.5e6)
+    assert plan.das_time_offset == pytest.approx(36 / 2 / 12.5e6)     # Kaiser length 36 at fs/2
+
+
+def test_planner_worked_examples_b_c(L):
+    # B: Int16, {Decode, DAS}, decode None -> Reshape(i16 -> f32) -> DAS real
+    acq = cfg.rca("example_b", 32, 4, 512, (8, 8, 1), (-1e-3, 0, 5e-3), (1e-3, 0, 9e-3), seed=1, demodulate=False)
+    plan = describe(L, acq)
+    assert [plan.stages[i].kind for i in range(plan.stage_count)] == [S.Reshape, S.DAS]
+    r = plan.stages[0]
+    assert (r.in_kind, r.out_kind) == (D.Int16, D.Float32)
+    assert list(r.in_stride) == list(r.out_stride) == [1, 512 * 4, 512]
+    assert plan.iq_pipeline == 0
+    # C: Float16, {Demodulate, DAS}: filter writes f32 complex straight in DAS layout
+    acq = cfg.config(2, 0.0625)
+    plan = describe(L, acq)
+    assert [plan.stages[i].kind for i in range(plan.stage_count)] == [S.Demodulate, S.DAS]
+    assert (plan.stages[0].in_kind, plan.stages[0].out_kind) == (D.Float16Complex, D.Float32Complex)
+    # coherency weighting adds the implicit node after DAS (beamformer_core.c:676-678)
+    plan = describe(L, cfg.config(4, 0.0625))
+    assert [plan.stages[i].kind for i in range(plan.stage_count)] == [S.Demodulate, S.DAS, S.CoherencyWeighting]
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_planner_agrees_with_oracle(name, L, oracle):
+    """stage order, element kinds and DAS parameters equal the oracle's restatement of
+    plan_compute_pipeline; strides equal wherever the 16-channel chunk does not enter."""
+    acq = cases.make(name)
+    ours = describe(L, acq)
+    ref = oracle.plan(acq.bp, acq.filters)
+    assert ref is not None
+    assert ours.stage_count == ref.stage_count
+    C_ = acq.bp.channel_count
+    chunk = min(C_, 16)
+    for i in range(ours.stage_count):
+        a, b = ours.stages[i], ref.stages[i]
+        assert (a.kind, a.in_kind, a.out_kind) == (b.kind, b.in_kind, b.out_kind), (name, i)
+        for mine, theirs in ((a.in_stride, b.in_stride), (a.out_stride, b.out_stride)):
+            for k in range(3):
+                if theirs[k] % chunk == 0 and mine[k] != theirs[k] and chunk != C_:
+                    assert mine[k] == theirs[k] // chunk * C_          # Decode layout scales with the chunk
+                else:
+                    assert mine[k] == theirs[k], (name, i, list(mine), list(theirs))
+    assert ours.das_samples == ref.input_sample_count
+    assert ours.das_time_offset == pytest.approx(ref.das_time_offset, rel=1e-6, abs=1e-12)
+    assert np.allclose(np.array(ours.das_voxel_transform[:]), np.array(ref.das_voxel_transform[:]), rtol=1e-6, atol=1e-12)
