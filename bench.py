@@ -166,8 +166,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
-                "kernel": "das_kernel", "kernel_ms": das_s * 1e3,
+                "frac": achieved * 1e9 / HBM_PEAK, "traffic": measured_traffic(args, world, das_path),
+                "kernel": "das_rca_separable_kernel" if das_path else "das_kernel", "kernel_ms": das_s * 1e3,
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
@@ -183,6 +183,19 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(args, world, das_path):
+    """HBM bytes per DAS launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/das_traffic.json); None when this run's configuration was not profiled."""
+    if world != 1 or args.scale != 1.0 or args.planes or args.config != 4:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "das_traffic.json")) as f:
+            table = json.load(f)["config4_scale1_n1"]
+        return table["das_rca_separable_kernel" if das_path else "das_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(acq, budget_s):
     """The CPU oracle (port of the reference shaders) on a bounded sub-grid of the same
     frame: all x, a few rows of the centre z-plane; voxels are independent, so voxels/s
@@ -195,6 +208,8 @@ def cpu_baseline(acq, budget_s):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    # a one-GPU box owns a 16-core share of the host (gpurun's guidance for worker pools)
+    cores = min(cores, int(os.environ.get("BENCH_CPU_THREADS", "16")))
     per_voxel_pairs = bp.channel_count * bp.acquisition_count
     # ~1.5e7 pairs/s/core for the scalar port; size the sample for the budget
     target_voxels = max(X, int(budget_s * 1.2e7 * cores / per_voxel_pairs))
