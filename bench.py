@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
     ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 force the general DAS kernel")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: run the N-rank code path with every rank on GPU 0 and gloo for the "
+                         "collectives (RCCL refuses two ranks per device); the value is NOT the metric")
     ap.add_argument("--planes", type=int, default=0, help="profiling aid: beamform only this many centre z-planes (value is then NOT the metric)")
     return ap.parse_args()
 
@@ -50,10 +53,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    rehearse = args.rehearse_on_one_gpu
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if rehearse:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -87,8 +96,15 @@ def main():
     stream = torch.cuda.current_stream(device)
     assert L.beamformer_hip_set_stream(C.c_void_p(stream.cuda_stream)), lib.last_error()
 
+    rf_bounce = torch.empty(rf_host.numel(), dtype=torch.uint8) if (distributed and rehearse) else None
+
     def step():
-        if distributed:
+        if distributed and rehearse:               # gloo has no device tensors: bounce through the host
+            if rank == 0:
+                rf_bounce.copy_(rf_dev)
+            sharding.broadcast_rf(rf_bounce, src=0)
+            rf_dev.copy_(rf_bounce)
+        elif distributed:
             sharding.broadcast_rf(rf_dev, src=0)   # RCCL over xGMI; same stream as the kernels
         ok = L.beamformer_hip_push_device_data_with_compute(C.c_void_p(rf_dev.data_ptr()), rf_dev.numel(), 0, 0)
         assert ok, lib.last_error()
@@ -133,7 +149,7 @@ def main():
     stage_ms = {P.ShaderKind(ids[i]).name: float(np.mean([stats.times[r][i] for r in rows])) * 1e3 for i in range(n_stage)}
 
     if distributed:
-        agg = torch.tensor([elapsed, das_s, float(pairs_local)], dtype=torch.float64, device=device)
+        agg = torch.tensor([elapsed, das_s, float(pairs_local)], dtype=torch.float64, device="cpu" if rehearse else device)
         mx = agg.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = agg.clone()
