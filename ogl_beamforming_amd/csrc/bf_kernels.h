@@ -63,6 +63,8 @@ typedef struct {
 	uint32_t channel_chunk;   /* channels per receive-table rebuild */
 	uint32_t lds_bytes;       /* 16 * (channel_chunk << u_shift) + 16 * (transmits << v_shift) */
 	uint32_t tiles[3];        /* tiles along u, along v, z planes of the shard */
+	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes the host keeps behind
+	                             the DAS input: where out-of-range lanes gather from */
 } BfSeparableArgs;
 
 typedef struct {

@@ -37,6 +37,14 @@ __device__ __forceinline__ float hw_fract(float x)     { return __builtin_amdgcn
 __device__ __forceinline__ float hw_sin_turns(float x) { return __builtin_amdgcn_sinf(x); }   /* sin(2 pi x) */
 __device__ __forceinline__ float hw_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }   /* cos(2 pi x) */
 
+/* (int)floor(x) in one instruction (hipcc emits v_floor_f32 + v_cvt_i32_f32) */
+__device__ __forceinline__ int cvt_floor_i32(float x)
+{
+	int r;
+	asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
+}
+
 /* das.glsl:138-152: cos(pi a)^2 */
 __device__ __forceinline__ float apodize(float a)
 {

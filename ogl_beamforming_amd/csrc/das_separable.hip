@@ -37,16 +37,20 @@ __device__ __forceinline__ float phase_turns(float k, float index)
 
 /* LDS tables, 16-byte entries so that every read is one ds_read_b128:
  *   R[(c - c0)*U + u] = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }   (apod == 0: fails the F# test)
- *   T[a*V + v]        = { t_index, cos(phi_t), sin(phi_t), 0 }
+ *   T[a*V + v]        = { cos(phi_t), sin(phi_t), t_index, 0 }   (phasor first: it lands in an
+ *                       even-aligned register pair, which packed FMAs need)
  * For real data the phasors are (1, 0).  T covers every transmit; R covers a chunk of
  * q.channel_chunk channels at a time and is rebuilt between chunks, which keeps the block's
  * LDS under 80 KB so that two 1024-thread blocks (8 waves per SIMD) share a CU: the gathers
  * are latency bound at lower occupancy. */
-template <int INTERP, bool CPLX, bool CW>
+/* VS: log2 of the tile extent along the transmit axis as a compile-time constant (0: read it
+ * from q) -- lets the table reads of a batch use immediate LDS offsets. */
+template <int INTERP, bool CPLX, bool CW, int VS>
 __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasArgs p, const BfSeparableArgs q)
 {
 	extern __shared__ __attribute__((aligned(16))) f32x4 sep_lds[];
-	const uint32_t U = 1u << q.u_shift, V = 1u << q.v_shift;
+	const uint32_t v_shift = VS ? (uint32_t)VS : q.v_shift;
+	const uint32_t U = 1u << q.u_shift, V = 1u << v_shift;
 	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
 	const int chunk = (int)q.channel_chunk;
 	f32x4 *R = sep_lds;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 
 	/* ---- transmit table: A x V entries, built once */
 	for (uint32_t e = threadIdx.x; e < (uint32_t)A * V; e += blockDim.x) {
-		uint32_t a = e >> q.v_shift, iv = e & (V - 1);
+		uint32_t a = e >> v_shift, iv = e & (V - 1);
 		float coord[3] = {0.f, 0.f, pz};
 		coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
 		float wx, wy, wz;
@@ -86,11 +90,11 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 			else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
 		}
 		float t_idx = (dist * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
-		f32x4 entry = {t_idx, 1.f, 0.f, 0.f};
+		f32x4 entry = {1.f, 0.f, t_idx, 0.f};
 		if constexpr (CPLX) {
 			float turns = phase_turns(phase_k, t_idx);
-			entry.y = hw_cos_turns(turns);
-			entry.z = hw_sin_turns(turns);
+			entry.x = hw_cos_turns(turns);
+			entry.y = hw_sin_turns(turns);
 		}
 		T[e] = entry;
 	}
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 	/* thread -> voxel: lanes run along the output's x axis */
 	uint32_t lu, lv;
 	if (u_axis == 0) { lu = threadIdx.x & (U - 1); lv = threadIdx.x >> q.u_shift; }
-	else             { lv = threadIdx.x & (V - 1); lu = threadIdx.x >> q.v_shift; }
+	else             { lv = threadIdx.x & (V - 1); lu = threadIdx.x >> v_shift; }
 	const uint32_t gu = tu * U + lu, gv = tv * V + lv;
 	const uint32_t x = u_axis == 0 ? gu : gv, y = u_axis == 0 ? gv : gu;
 	const bool inside = x < p.size[0] && y < p.size[1];
@@ -154,13 +158,55 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 			VT    sum = zero_sample<CPLX>();
 			float mag = 0.f;
 			uint32_t row = (uint32_t)(c0 + cl) * (uint32_t)A * row_bytes;
+			if constexpr (INTERP == BF_INTERP_LINEAR && CPLX) {
+				/* The headline case, written out so that every step is one instruction:
+				 *   idx = R + T; frac = v_fract(idx); k = v_cvt_flr_i32(idx);
+				 *   valid = (unsigned)k < S-1; offset = valid ? row + 8k : zero block
+				 *   s = (1-frac) s[k] + frac s[k+1]                       2 packed ops
+				 *   acc1 += s.re * (cos, sin)(T); acc2 += s.im * (cos, sin)(T)   2 packed FMAs
+				 * with sum = (acc1.x - acc2.y, acc1.y + acc2.x) formed once per channel.  Lanes whose
+				 * index falls outside the row read 16 zero bytes placed behind the RF by the host. */
+				constexpr int B = 4;
+				f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+				const uint32_t ulast = (uint32_t)(S - 1);
+				auto term = [&](f32x2 cs, float frac, f32x4 d) {
+					f32x2 sv = (1.f - frac) * f32x2{d.x, d.y} + frac * f32x2{d.z, d.w};
+					acc1 += sv.x * cs;
+					acc2 += sv.y * cs;
+					if constexpr (CW) { f32x2 sq = sv * sv; mag += hw_sqrt(sq.x + sq.y); }
+				};
+				auto offset_of = [&](float index, uint32_t row_offset, float &frac) {
+					frac = hw_fract(index);
+					uint32_t k = (uint32_t)cvt_floor_i32(index);
+					return k < ulast ? row_offset + (k << 3) : q.zero_offset;
+				};
+				int a = 0;
+				for (; a + B <= A; a += B, row += B * row_bytes) {
+					f32x4 t[B]; float frac[B]; uint32_t off[B]; f32x4 d[B];
+					#pragma unroll
+					for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k) * V];
+					#pragma unroll
+					for (int k = 0; k < B; k++) off[k] = offset_of(r.x + t[k].z, row + (uint32_t)k * row_bytes, frac[k]);
+					#pragma unroll
+					for (int k = 0; k < B; k++) d[k] = gather<f32x4_a8>(rf, off[k]);
+					#pragma unroll
+					for (int k = 0; k < B; k++) term(f32x2{t[k].x, t[k].y}, frac[k], d[k]);
+				}
+				for (; a < A; a++, row += row_bytes) {
+					const f32x4 t = Tl[(size_t)a * V];
+					float frac;
+					uint32_t off = offset_of(r.x + t.z, row, frac);
+					term(f32x2{t.x, t.y}, frac, gather<f32x4_a8>(rf, off));
+				}
+				sum = f32x2{acc1.x - acc2.y, acc1.y + acc2.x};
+			} else {
 			/* transmits in batches of B: B broadcast table reads, B index splits, B gathers in
 			 * flight, then B interpolate + rotate-accumulate steps */
 			constexpr int B = 4;
 			auto term = [&](const f32x4 &t, VT sv) {
 				if constexpr (CPLX) {
-					sum.x += sv.x * t.y - sv.y * t.z;
-					sum.y += sv.x * t.z + sv.y * t.y;
+					sum.x += sv.x * t.x - sv.y * t.y;
+					sum.y += sv.x * t.y + sv.y * t.x;
 					if constexpr (CW) mag += hw_sqrt(sv.x * sv.x + sv.y * sv.y);
 				} else {
 					sum += sv;
@@ -175,7 +221,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				#pragma unroll
 				for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k) * V];
 				#pragma unroll
-				for (int k = 0; k < B; k++) tap[k] = tap_setup<INTERP, CPLX>(r.x + t[k].x, fS, S - 1);
+				for (int k = 0; k < B; k++) tap[k] = tap_setup<INTERP, CPLX>(r.x + t[k].z, fS, S - 1);
 				#pragma unroll
 				for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, row + (uint32_t)k * row_bytes + tap[k].off);
 				#pragma unroll
@@ -183,7 +229,8 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 			}
 			for (; a < A; a++, row += row_bytes) {
 				const f32x4 t = Tl[(size_t)a * V];
-				term(t, interpolate<INTERP, CPLX>(rf, row, r.x + t.x, fS, S - 1));
+				term(t, interpolate<INTERP, CPLX>(rf, row, r.x + t.z, fS, S - 1));
+			}
 			}
 			if constexpr (CPLX) {
 				coherent.x += sum.x * r.y - sum.y * r.z;
@@ -201,12 +248,12 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 	reinterpret_cast<VT *>(p.out)[out_index] = coherent;
 }
 
-template <int INTERP, bool CPLX, bool CW>
+template <int INTERP, bool CPLX, bool CW, int VS>
 static hipError_t launch_sep(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
-	auto kernel = das_rca_separable_kernel<INTERP, CPLX, CW>;
+	auto kernel = das_rca_separable_kernel<INTERP, CPLX, CW, VS>;
 	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(q->threads), q->lds_bytes, s, *a, *q);
@@ -216,8 +263,22 @@ static hipError_t launch_sep(const BfDasArgs *a, const BfSeparableArgs *q, hipSt
 template <int INTERP>
 static hipError_t launch_sep_kind(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
-	if (a->complex_data) return a->coherency_weighting ? launch_sep<INTERP, true,  true>(a, q, s) : launch_sep<INTERP, true,  false>(a, q, s);
-	return a->coherency_weighting ? launch_sep<INTERP, false, true>(a, q, s) : launch_sep<INTERP, false, false>(a, q, s);
+	if (a->complex_data) {
+		if constexpr (INTERP == BF_INTERP_LINEAR) {
+			/* compile-time tile extents for the headline case */
+			if (a->coherency_weighting) switch (q->v_shift) {
+			case 4: return launch_sep<INTERP, true, true, 4>(a, q, s);
+			case 5: return launch_sep<INTERP, true, true, 5>(a, q, s);
+			case 6: return launch_sep<INTERP, true, true, 6>(a, q, s);
+			} else switch (q->v_shift) {
+			case 4: return launch_sep<INTERP, true, false, 4>(a, q, s);
+			case 5: return launch_sep<INTERP, true, false, 5>(a, q, s);
+			case 6: return launch_sep<INTERP, true, false, 6>(a, q, s);
+			}
+		}
+		return a->coherency_weighting ? launch_sep<INTERP, true, true, 0>(a, q, s) : launch_sep<INTERP, true, false, 0>(a, q, s);
+	}
+	return a->coherency_weighting ? launch_sep<INTERP, false, true, 0>(a, q, s) : launch_sep<INTERP, false, false, 0>(a, q, s);
 }
 
 extern "C" hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)

@@ -477,6 +477,11 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 			} else {
 				BfSeparableArgs sep{};
 				if (c.das_path_mode == 0 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
+					 * allocated with that much slack): the gather target of out-of-range lanes */
+					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
+					sep.zero_offset = (uint32_t)used;
+					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
 					ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
 					das_path = 1;
 				} else {
