@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 force the general DAS kernel")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 force the general DAS kernel, 3 prefer the LDS-staged kernel")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run the N-rank code path with every rank on GPU 0 and gloo for the "
                          "collectives (RCCL refuses two ranks per device); the value is NOT the metric")
@@ -177,13 +177,13 @@ def main():
                             f"-> Demodulate -> {X}x{Y}x{Z} complex voxels",
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": f"{world} z-slab(s), RF broadcast via RCCL" if distributed else "none",
-                "das_path": "separable-delay fast path" if das_path else "general kernel",
+                "das_path": ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel"][das_path],
                 "stage_ms": stage_ms,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK, "traffic": measured_traffic(args, world, das_path),
-                "kernel": "das_rca_separable_kernel" if das_path else "das_kernel", "kernel_ms": das_s * 1e3,
+                "kernel": ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel"][das_path], "kernel_ms": das_s * 1e3,
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
@@ -207,7 +207,7 @@ def measured_traffic(args, world, das_path):
     try:
         with open(os.path.join(ROOT, "profiles", "das_traffic.json")) as f:
             table = json.load(f)["config4_scale1_n1"]
-        return table["das_rca_separable_kernel" if das_path else "das_kernel"]["hbm_bytes_per_launch"]
+        return table[["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel"][das_path]]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 

@@ -71,7 +71,7 @@ typedef struct {
 	uint64_t das_voxels;
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
-	uint32_t das_path;         /* 0 general kernel, 1 separable-delay fast path */
+	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
@@ -84,8 +84,11 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_pair_counting(uint32_t enab
  * reference's shaders/min_max.glsl is dead code (beamformer_core.c:632-637). */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_frame_min_max(float out_min_max[2]);
 
-/* Select the DAS implementation: 0 = automatic (fast path when the geometry allows),
- * 1 = always the general kernel.  For parity testing of both paths. */
+/* Select the DAS implementation: 0 = automatic (general kernel, or the separable-delay
+ * gather kernel when the geometry allows), 1 = always the general kernel, 3 = prefer the
+ * LDS-staged variant of the separable kernel where its window bound holds (measured slower
+ * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
+ * For parity testing of every path. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 
 /* ---- host-side introspection (no device needed; used by tests/ to pin the host math

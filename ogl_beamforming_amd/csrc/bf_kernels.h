@@ -63,6 +63,7 @@ typedef struct {
 	uint32_t channel_chunk;   /* channels per receive-table rebuild */
 	uint32_t lds_bytes;       /* 16 * (channel_chunk << u_shift) + 16 * (transmits << v_shift) */
 	uint32_t tiles[3];        /* tiles along u, along v, z planes of the shard */
+	uint32_t window_shift;    /* staged kernel: log2 of the RF window (samples) copied to LDS per transmit */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes the host keeps behind
 	                             the DAS input: where out-of-range lanes gather from */
 } BfSeparableArgs;
@@ -115,6 +116,7 @@ hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s);
 hipError_t bf_launch_das(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
+hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
  * 2*1024 floats */
 hipError_t bf_launch_min_max(const void *frame, uint64_t voxels, int complex_data,

@@ -25,6 +25,11 @@
  */
 #include "das_common.h"
 
+/* (voxel, channel, transmit) terms whose gathers are in flight together per lane */
+#ifndef BF_SEP_BATCH
+#define BF_SEP_BATCH 4
+#endif
+
 /* demodulation phase of a partial sample index, in turns in [0,1): fract(k * index) with the
  * rounding error of the product recovered by an fma, so that splitting the phase in two
  * parts does not cost precision (Q3 of oracle/oracle.h: the phase is defined range-reduced) */
@@ -99,6 +104,29 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 		T[e] = entry;
 	}
 
+	/* tile-wide extremes of the transmit delay (for the range-test shortcut): every wave
+	 * reduces its share of the table, the block combines the per-wave results */
+	__shared__ f32x2 wave_range[16];
+	__syncthreads();
+	{
+		float lo = __builtin_inff(), hi = -__builtin_inff();
+		for (uint32_t e = threadIdx.x; e < (uint32_t)A * V; e += blockDim.x) {
+			float v = T[e].z;
+			lo = fminf(lo, v); hi = fmaxf(hi, v);
+		}
+		for (int off = 32; off > 0; off >>= 1) {
+			lo = fminf(lo, __shfl_xor(lo, off, 64));
+			hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+		}
+		if ((threadIdx.x & 63u) == 0) wave_range[threadIdx.x >> 6] = f32x2{lo, hi};
+	}
+	__syncthreads();
+	f32x2 range = wave_range[0];
+	for (uint32_t w = 1; w < (blockDim.x >> 6); w++) {
+		range.x = fminf(range.x, wave_range[w].x);
+		range.y = fmaxf(range.y, wave_range[w].y);
+	}
+
 	/* thread -> voxel: lanes run along the output's x axis */
 	uint32_t lu, lv;
 	if (u_axis == 0) { lu = threadIdx.x & (U - 1); lv = threadIdx.x >> q.u_shift; }
@@ -166,38 +194,44 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				 *   acc1 += s.re * (cos, sin)(T); acc2 += s.im * (cos, sin)(T)   2 packed FMAs
 				 * with sum = (acc1.x - acc2.y, acc1.y + acc2.x) formed once per channel.  Lanes whose
 				 * index falls outside the row read 16 zero bytes placed behind the RF by the host. */
-				constexpr int B = 4;
+				constexpr int B = BF_SEP_BATCH;
 				f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 				const uint32_t ulast = (uint32_t)(S - 1);
 				auto term = [&](f32x2 cs, float frac, f32x4 d) {
-					f32x2 sv = (1.f - frac) * f32x2{d.x, d.y} + frac * f32x2{d.z, d.w};
+					f32x2 s0 = {d.x, d.y}, s1 = {d.z, d.w};
+					f32x2 sv = s0 + frac * (s1 - s0);
 					acc1 += sv.x * cs;
 					acc2 += sv.y * cs;
 					if constexpr (CW) { f32x2 sq = sv * sv; mag += hw_sqrt(sq.x + sq.y); }
 				};
-				auto offset_of = [&](float index, uint32_t row_offset, float &frac) {
-					frac = hw_fract(index);
-					uint32_t k = (uint32_t)cvt_floor_i32(index);
-					return k < ulast ? row_offset + (k << 3) : q.zero_offset;
+				/* When every lane of the wave stays inside the RF row for every transmit of the tile
+				 * (r + min T >= 0 and r + max T < S - 1, the tile-wide extremes of T are in `range`),
+				 * the per-term range test and the zero-block select are dropped. */
+				const bool lane_safe = (r.x + range.x >= 0.f) && (r.x + range.y < (float)(S - 1));
+				const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
+				auto batches = [&](auto checked) {
+					constexpr bool CHECK = decltype(checked)::value;
+					for (int a = 0; a < A; a += B, row += B * row_bytes) {
+						f32x4 t[B]; float frac[B]; uint32_t off[B]; f32x4 d[B];
+						#pragma unroll
+						for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k < A ? a + k : A - 1) * V];
+						#pragma unroll
+						for (int k = 0; k < B; k++) {
+							float index = r.x + t[k].z;
+							frac[k] = hw_fract(index);
+							uint32_t ki = (uint32_t)cvt_floor_i32(index);
+							off[k] = row + (uint32_t)k * row_bytes + (ki << 3);
+							if constexpr (CHECK) off[k] = ki < ulast ? off[k] : q.zero_offset;
+							if (a + k >= A) off[k] = q.zero_offset;      /* wave-uniform: padding of the last batch */
+						}
+						#pragma unroll
+						for (int k = 0; k < B; k++) d[k] = gather<f32x4_a8>(rf, off[k]);
+						#pragma unroll
+						for (int k = 0; k < B; k++) term(f32x2{t[k].x, t[k].y}, frac[k], d[k]);
+					}
 				};
-				int a = 0;
-				for (; a + B <= A; a += B, row += B * row_bytes) {
-					f32x4 t[B]; float frac[B]; uint32_t off[B]; f32x4 d[B];
-					#pragma unroll
-					for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k) * V];
-					#pragma unroll
-					for (int k = 0; k < B; k++) off[k] = offset_of(r.x + t[k].z, row + (uint32_t)k * row_bytes, frac[k]);
-					#pragma unroll
-					for (int k = 0; k < B; k++) d[k] = gather<f32x4_a8>(rf, off[k]);
-					#pragma unroll
-					for (int k = 0; k < B; k++) term(f32x2{t[k].x, t[k].y}, frac[k], d[k]);
-				}
-				for (; a < A; a++, row += row_bytes) {
-					const f32x4 t = Tl[(size_t)a * V];
-					float frac;
-					uint32_t off = offset_of(r.x + t.z, row, frac);
-					term(f32x2{t.x, t.y}, frac, gather<f32x4_a8>(rf, off));
-				}
+				if (wave_safe) batches(std::false_type{});
+				else           batches(std::true_type{});
 				sum = f32x2{acc1.x - acc2.y, acc1.y + acc2.x};
 			} else {
 			/* transmits in batches of B: B broadcast table reads, B index splits, B gathers in

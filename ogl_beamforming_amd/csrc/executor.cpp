@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -331,6 +332,75 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
 	return true;
 }
 
+/* Upgrade a separable plan to the LDS-staged kernel (das_staged.hip) when the delay spread of a
+ * tile provably fits the staging window.  The receive delay is a distance, so it changes by at
+ * most one lateral voxel step (in samples) per voxel along u; the transmit delay likewise along
+ * v, scaled by max|sin(angle)| when every transmit is a plane wave. */
+static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
+                        uint32_t zcount, BfSeparableArgs &q)
+{
+	if (!a.complex_data || a.interpolation != 1) return false;
+	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
+	const int u_axis = (int)q.u_axis, v_axis = 1 - u_axis;
+	const int r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0, w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;
+	float m[16];
+	m4_mul(xdc, vox, m);
+	const float samples_per_metre = a.sampling_frequency * a.inv_speed_of_sound;
+	float step_u = std::fabs(m[4 * u_axis + r]) / (float)(a.size[u_axis] > 1 ? a.size[u_axis] - 1 : 1) * samples_per_metre;
+	float step_v = std::fabs(vox[4 * v_axis + w]) / (float)(a.size[v_axis] > 1 ? a.size[v_axis] - 1 : 1) * samples_per_metre;
+	bool all_plane = true; float max_sin = 0.f;
+	for (const BfTransmit &t : tx) {
+		all_plane &= (t.flags & BF_TX_PLANE) != 0;
+		max_sin = std::fmax(max_sin, std::fabs(t.sin_a));
+	}
+	if (tx[0].flags & BF_TX_NONE) step_v = 0.f;
+	else if (all_plane)           step_v *= max_sin;
+
+	const uint32_t lds_cu = 160u * 1024u;
+	uint32_t best_waves = 0, best_score = 0;
+	BfSeparableArgs best = q;
+	for (uint32_t threads_shift = 10; threads_shift >= 9; threads_shift--) {
+		for (uint32_t vs = 4; vs <= 6; vs++) {
+			if (vs + 4 > threads_shift) continue;
+			uint32_t us = threads_shift - vs;
+			if (us > 6) continue;
+			if ((u_axis == 0 ? us : vs) < 4) continue;
+			float spread = step_u * (float)((1u << us) - 1) + step_v * (float)((1u << vs) - 1);
+			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + 4;       /* + taps, floors, rounding slack */
+			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
+			if (!ws) continue;
+			if (((uint64_t)A << ws) > ((uint64_t)4 << threads_shift)) continue;   /* BF_STAGE_MAX_LOADS */
+			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
+				uint32_t cc = chunk < C ? chunk : C;
+				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A << vs)) + 8ull * (((uint64_t)A << ws) + 2) + 4ull * (A + cc);
+				lds = (lds + 15) & ~15ull;
+				if (lds > lds_cu) continue;
+				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = 2048u >> threads_shift;
+				if (blocks > by_waves) blocks = by_waves;
+				uint32_t waves = blocks << (threads_shift - 6);
+				uint32_t balance = us > vs ? us - vs : vs - us;
+				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (ws == 5 ? 500u : 0u);
+				if (waves > best_waves || (waves == best_waves && score > best_score)) {
+					best_waves = waves; best_score = score;
+					best.u_shift = us; best.v_shift = vs; best.threads = 1u << threads_shift;
+					best.channel_chunk = cc; best.lds_bytes = (uint32_t)lds; best.window_shift = ws;
+				}
+				if (cc == C) break;
+			}
+		}
+	}
+	if (std::getenv("BEAMFORMER_HIP_DEBUG"))
+		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u\n",
+		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_shift, best.channel_chunk, best.lds_bytes);
+	if (!best_waves) return false;
+	q = best;
+	uint32_t nu = a.size[u_axis], nv = a.size[v_axis];
+	q.tiles[0] = (nu + (1u << q.u_shift) - 1) >> q.u_shift;
+	q.tiles[1] = (nv + (1u << q.v_shift) - 1) >> q.v_shift;
+	q.tiles[2] = zcount;
+	return true;
+}
+
 static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
 {
 	return HIP_OK(hipEventRecord(t.events[index], s));
@@ -476,14 +546,19 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
 			} else {
 				BfSeparableArgs sep{};
-				if (c.das_path_mode == 0 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+				if (c.das_path_mode != 1 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
 					 * allocated with that much slack): the gather target of out-of-range lanes */
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					sep.zero_offset = (uint32_t)used;
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
-					das_path = 1;
+					if (c.das_path_mode == 3 && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+						ok &= HIP_OK(bf_launch_das_staged(&a, &sep, s));
+						das_path = 2;
+					} else {
+						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
+						das_path = 1;
+					}
 				} else {
 					ok &= HIP_OK(bf_launch_das(&a, s));
 				}

@@ -15,7 +15,8 @@ import numpy as np
 from . import params as P
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "libogl_beamformer_lib.so")
+# OGL_BEAMFORMER_LIB points at another build of the same library (kernel experiments)
+LIBRARY_PATH = os.environ.get("OGL_BEAMFORMER_LIB") or os.path.join(_HERE, "libogl_beamformer_lib.so")
 
 
 class BeamformerError(RuntimeError):

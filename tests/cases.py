@@ -37,6 +37,15 @@ def _cases():
     c["rca_sep_real_nearest"] = lambda: cfg.rca("rca_sep_real_nearest", 16, 3, 512, (19, 18, 3), LO3, HI3, seed=42,
                                                 interp=I.Nearest, orientation=0x21, demodulate=False,
                                                 angles=np.linspace(-5, 5, 3))
+    # LDS-staged kernel: a coarse grid whose delay spread needs the 64-sample window, one that
+    # fits no window (falls back to the gather kernel), and ragged tile edges
+    c["rca_staged_w64"] = lambda: cfg.rca("rca_staged_w64", 32, 4, 1024, (40, 40, 3), (-4e-3, -4e-3, 8e-3), (4e-3, 4e-3, 11e-3),
+                                          seed=43, orientation=0x12, cw=True, f_number=0.3, angles=np.linspace(-10, 10, 4))
+    c["rca_staged_too_wide"] = lambda: cfg.rca("rca_staged_too_wide", 16, 3, 1024, (24, 24, 2), (-14e-3, -14e-3, 6e-3),
+                                               (14e-3, 14e-3, 9e-3), seed=44, orientation=0x12, f_number=0.2,
+                                               angles=np.linspace(-10, 10, 3))
+    c["rca_staged_ragged"] = lambda: cfg.rca("rca_staged_ragged", 48, 7, 512, (45, 70, 2), LO3, HI3, seed=45,
+                                             orientation=0x21, cw=True, f_number=0.6, angles=np.linspace(-12, 12, 7))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

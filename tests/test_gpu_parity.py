@@ -41,7 +41,15 @@ def last_das_path(bflib):
 
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
 # them up on its own (das_separable.hip)
-SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest"}
+SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest",
+             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged"}
+# ... and of those, the linear-interpolation complex ones whose delay spread fits an LDS window
+# can run the LDS-staged variant (das_staged.hip, opt-in: it is slower on MI355X)
+STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged"}
+
+
+def expected_path(name):
+    return 1 if name in SEPARABLE else 0
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))
@@ -51,7 +59,7 @@ def test_frame_parity(name, bflib, oracle):
     ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
     bflib.library().beamformer_hip_set_das_path(0)
     gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-    assert last_das_path(bflib) == (1 if name in SEPARABLE else 0)
+    assert last_das_path(bflib) == expected_path(name)
     compare(gpu, ref, acq)
 
 
@@ -65,6 +73,22 @@ def test_general_kernel_on_separable_geometry(name, bflib, oracle):
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert last_das_path(bflib) == 0
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq)
+
+
+@pytest.mark.parametrize("name", sorted(SEPARABLE))
+def test_lds_staged_kernel(name, bflib, oracle):
+    """the opt-in LDS-staged variant; geometries outside its window bound fall back to the
+    gather kernel"""
+    acq = cases.make(name)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    lib.beamformer_hip_set_das_path(3)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == (2 if name in STAGED else 1)
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq)
