@@ -235,8 +235,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				sum = f32x2{acc1.x - acc2.y, acc1.y + acc2.x};
 			} else {
 			/* transmits in batches of B: B broadcast table reads, B index splits, B gathers in
-			 * flight, then B interpolate + rotate-accumulate steps */
-			constexpr int B = 4;
+			 * flight, then B interpolate + rotate-accumulate steps (cubic holds two 16-byte loads
+			 * and four weights per term: a smaller batch keeps it inside 64 VGPRs) */
+			constexpr int B = INTERP == BF_INTERP_CUBIC ? 2 : 4;
 			auto term = [&](const f32x4 &t, VT sv) {
 				if constexpr (CPLX) {
 					sum.x += sv.x * t.x - sv.y * t.y;

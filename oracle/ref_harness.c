@@ -19,6 +19,9 @@
 #include "/root/reference/util.h"
 #include "/root/reference/generated/beamformer.c"
 #include "/root/reference/base_linux.c"
+#include "/root/reference/util_os.c"
+#include "/root/reference/beamformer_compute_stats.c"
+#include "/root/reference/beamformer_shared_memory.c"
 
 #define REF_EXPORT __attribute__((visibility("default")))
 
@@ -172,6 +175,76 @@ REF_EXPORT int ref_describe_offsets(char *out, int cap)
 	int n = 0;
 	#define X(s, f) n += snprintf(out + n, cap - n, #s "." #f " %d\n", (int)offsetof(s, f));
 	REF_OFFSET_LIST
+	#undef X
+	return n;
+}
+
+/* shared-memory protocol v33 layout (beamformer_shared_memory.c:2-166) for the headless
+ * server (ogl_beamforming_amd/csrc/shm_server.cpp) */
+#define REF_SHM_LIST \
+	X("sizeof.BeamformerSharedMemory", sizeof(BeamformerSharedMemory)) \
+	X("sizeof.BeamformerParameterBlock", sizeof(BeamformerParameterBlock)) \
+	X("sizeof.BeamformWork", sizeof(BeamformWork)) \
+	X("sizeof.BeamformWorkQueue", sizeof(BeamformWorkQueue)) \
+	X("sizeof.BeamformerComputePipeline", sizeof(BeamformerComputePipeline)) \
+	X("sizeof.BeamformerComputeStatsTable", sizeof(BeamformerComputeStatsTable)) \
+	X("sizeof.Arena", sizeof(Arena)) \
+	X("Arena.position", offsetof(Arena, position)) \
+	X("Arena.reserved", offsetof(Arena, reserved)) \
+	X("shm.version", offsetof(BeamformerSharedMemory, version)) \
+	X("shm.invalid", offsetof(BeamformerSharedMemory, invalid)) \
+	X("shm.locks", offsetof(BeamformerSharedMemory, locks)) \
+	X("shm.reserved_parameter_blocks", offsetof(BeamformerSharedMemory, reserved_parameter_blocks)) \
+	X("shm.rf_block_rf_size", offsetof(BeamformerSharedMemory, rf_block_rf_size)) \
+	X("shm.beamformed_frame_buffer_size", offsetof(BeamformerSharedMemory, beamformed_frame_buffer_size)) \
+	X("shm.capabilities", offsetof(BeamformerSharedMemory, capabilities)) \
+	X("shm.capabilities.hilbert", offsetof(BeamformerSharedMemory, capabilities.hilbert)) \
+	X("shm.live_imaging_parameters", offsetof(BeamformerSharedMemory, live_imaging_parameters)) \
+	X("shm.live_imaging_dirty_flags", offsetof(BeamformerSharedMemory, live_imaging_dirty_flags)) \
+	X("shm.external_work_queue", offsetof(BeamformerSharedMemory, external_work_queue)) \
+	X("queue.work_items", offsetof(BeamformWorkQueue, work_items)) \
+	X("work.kind", offsetof(BeamformWork, kind)) \
+	X("work.lock", offsetof(BeamformWork, lock)) \
+	X("work.compute_context", offsetof(BeamformWork, compute_context)) \
+	X("work.create_filter.filter_slot", offsetof(BeamformWork, create_filter_context.filter_slot)) \
+	X("work.create_filter.parameter_block", offsetof(BeamformWork, create_filter_context.parameter_block)) \
+	X("work.export.kind", offsetof(BeamformWork, export_context.kind)) \
+	X("work.export.count", offsetof(BeamformWork, export_context.count)) \
+	X("work.export.size", offsetof(BeamformWork, export_context.size)) \
+	X("block.parameters", offsetof(BeamformerParameterBlock, parameters)) \
+	X("block.region_update_flags", offsetof(BeamformerParameterBlock, region_update_flags)) \
+	X("block.pipeline", offsetof(BeamformerParameterBlock, pipeline)) \
+	X("block.pipeline.parameters", offsetof(BeamformerParameterBlock, pipeline.parameters)) \
+	X("block.pipeline.shader_count", offsetof(BeamformerParameterBlock, pipeline.shader_count)) \
+	X("block.pipeline.data_kind", offsetof(BeamformerParameterBlock, pipeline.data_kind)) \
+	X("block.channel_mapping", offsetof(BeamformerParameterBlock, channel_mapping)) \
+	X("block.sparse_elements", offsetof(BeamformerParameterBlock, sparse_elements)) \
+	X("block.transmit_receive_orientations", offsetof(BeamformerParameterBlock, transmit_receive_orientations)) \
+	X("block.focal_vectors", offsetof(BeamformerParameterBlock, focal_vectors)) \
+	X("enum.WorkKind_Compute", BeamformerWorkKind_Compute) \
+	X("enum.WorkKind_ComputeIndirect", BeamformerWorkKind_ComputeIndirect) \
+	X("enum.WorkKind_CreateFilter", BeamformerWorkKind_CreateFilter) \
+	X("enum.WorkKind_ExportBuffer", BeamformerWorkKind_ExportBuffer) \
+	X("enum.Lock_ScratchSpace", BeamformerSharedMemoryLockKind_ScratchSpace) \
+	X("enum.Lock_UploadRF", BeamformerSharedMemoryLockKind_UploadRF) \
+	X("enum.Lock_ExportSync", BeamformerSharedMemoryLockKind_ExportSync) \
+	X("enum.Lock_DispatchCompute", BeamformerSharedMemoryLockKind_DispatchCompute) \
+	X("enum.Lock_Count", BeamformerSharedMemoryLockKind_Count) \
+	X("enum.Region_ComputePipeline", BeamformerParameterBlockRegion_ComputePipeline) \
+	X("enum.Region_ChannelMapping", BeamformerParameterBlockRegion_ChannelMapping) \
+	X("enum.Region_FocalVectors", BeamformerParameterBlockRegion_FocalVectors) \
+	X("enum.Region_Parameters", BeamformerParameterBlockRegion_Parameters) \
+	X("enum.Region_SparseElements", BeamformerParameterBlockRegion_SparseElements) \
+	X("enum.Region_TransmitReceiveOrientations", BeamformerParameterBlockRegion_TransmitReceiveOrientations) \
+	X("enum.RegionFlag_NotifyUI", BeamformerParameterRegionFlag_NotifyUI) \
+	X("enum.Export_BeamformedData", BeamformerExportKind_BeamformedData) \
+	X("enum.Export_Stats", BeamformerExportKind_Stats)
+
+REF_EXPORT int ref_describe_shm_layout(char *out, int cap)
+{
+	int n = 0;
+	#define X(name, value) n += snprintf(out + n, cap - n, "%s %d\n", name, (int)(value));
+	REF_SHM_LIST
 	#undef X
 	return n;
 }

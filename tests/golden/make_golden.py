@@ -124,6 +124,13 @@ def main():
     out["struct_offsets"] = np.frombuffer(buf.raw[:n], np.uint8)
     out["struct_sizes"] = np.array([r.ref_sizeof(i) for i in range(6)], np.int32)
 
+    # shared-memory protocol layout for the headless server (csrc/shm_server.cpp)
+    buf = C.create_string_buffer(8192)
+    n = r.ref_describe_shm_layout(buf, 8192)
+    with open(os.path.join(HERE, "shm_layout.txt"), "w") as f:
+        f.write("# shared-memory protocol v33 layout of the COMPILED reference (oracle/ref_harness.c: ref_describe_shm_layout)\n"
+                "# regenerate: make -C oracle ref && python tests/golden/make_golden.py\n" + buf.raw[:n].decode())
+
     np.savez_compressed(os.path.join(HERE, "host_math.npz"), **out)
     print("wrote", os.path.join(HERE, "host_math.npz"), os.path.getsize(os.path.join(HERE, "host_math.npz")), "bytes")
 
