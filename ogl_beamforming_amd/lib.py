@@ -25,11 +25,37 @@ class BeamformerError(RuntimeError):
         self.kind = P.LibError(kind)
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own libamdhip64.so.7
+    beside libtorch; the dynamic loader keys on the SONAME, so whichever copy is mapped first
+    serves both.  The system copy first and torch's HSA runtime second leaves torch without a
+    device ("No HIP GPUs are available"), so when torch is installed its copy is mapped before
+    the library, without importing torch.  C and MATLAB clients never see this: they link
+    the ROCm installation's runtime (csrc/Makefile rpath)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                  # already mapped by torch itself
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                # the ROCm installation's runtime serves alone
+
+
 def _load():
     if not os.path.exists(LIBRARY_PATH):
         raise ImportError(
             f"{LIBRARY_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU implementation to fall back to.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIBRARY_PATH)
     u32, i32, u64, vp = C.c_uint32, C.c_int32, C.c_uint64, C.c_void_p
     sig = {

@@ -1,0 +1,139 @@
+"""Behaviour of the C ABI on a device beyond single-frame parity: frame ring order and
+64-byte rounding (beamformer_core.c:440-466, :1474-1494), several parameter blocks, the
+one-shot call, data-size validation (lib/ogl_beamformer_lib.c:503-511), device-resident RF,
+sharding, the per-stage stats table (beamformer_compute_stats.c:3-10)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ogl_beamforming_amd import params as P
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+E = P.LibError
+
+
+def push(L, bflib, acq, slot=0):
+    for s, fp in enumerate(acq.filters):
+        assert L.beamformer_create_filter(C.byref(fp), s, slot), bflib.last_error()
+    assert L.beamformer_push_simple_parameters_at(C.byref(acq.bp), slot), bflib.last_error()
+    rf = np.ascontiguousarray(acq.rf)
+    assert L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, slot), bflib.last_error()
+
+
+def test_last_frames_are_returned_oldest_first_and_rounded_to_64_bytes(bflib, oracle):
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    a = cases.make("rca_cubic_real")          # 20 x 20 x 1 float32 = 1600 B -> 1600 (multiple of 64)
+    b = cases.make("hercules_real")           # 10 x 12 x 14 float32 = 6720 B -> 6720
+    c = cases.make("forces")                  # 20 x 1 x 20 float32 = 1600 B
+    refs = [oracle.beamform(x.bp, x.rf, x.filters)[0] for x in (a, b, c)]
+    for x in (a, b, c):
+        push(L, bflib, x)
+    sizes = [(r.size * 4 + 63) // 64 * 64 for r in refs]
+    out = np.zeros(sum(sizes) // 4, np.float32)
+    assert L.beamformer_get_last_frames(out.ctypes.data_as(C.c_void_p), out.nbytes, 3)
+    offset = 0
+    for ref, size in zip(refs, sizes):
+        got = out[offset // 4: offset // 4 + ref.size].reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+        offset += size
+    # a buffer with room for two frames gets the two OLDEST of the requested three (the most
+    # recent are dropped, lib/ogl_beamformer_lib_base.h:100-102)
+    out2 = np.zeros((sizes[0] + sizes[1]) // 4, np.float32)
+    assert L.beamformer_get_last_frames(out2.ctypes.data_as(C.c_void_p), out2.nbytes, 3)
+    assert np.abs(out2[: refs[0].size].reshape(refs[0].shape) - refs[0]).max() <= 1e-4 * np.abs(refs[0]).max()
+    # null / empty requests fail without touching the error (lib .c:700)
+    assert not L.beamformer_get_last_frames(None, 64, 1)
+    assert not L.beamformer_get_last_frames(out.ctypes.data_as(C.c_void_p), out.nbytes, 0)
+
+
+def test_two_parameter_blocks_keep_their_own_plans(bflib, oracle):
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    assert L.beamformer_reserve_parameter_blocks(2)
+    try:
+        a, b = cases.make("config1_small"), cases.make("uforces_sparse")
+        ra, rb = oracle.beamform(a.bp, a.rf, a.filters)[0], oracle.beamform(b.bp, b.rf, b.filters)[0]
+        push(L, bflib, a, 0)
+        push(L, bflib, b, 1)
+        rf = np.ascontiguousarray(a.rf)      # block 0 again, parameters untouched
+        assert L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0)
+        got = bflib.get_last_frame(a.bp)
+        assert np.abs(got - ra).max() <= 2e-3 * np.abs(ra).max()
+        rf = np.ascontiguousarray(b.rf)
+        assert L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 1)
+        got = bflib.get_last_frame(b.bp)
+        ok = ~np.isnan(rb)
+        assert np.array_equal(np.isnan(got), np.isnan(rb))
+        assert np.abs(got[ok] - rb[ok]).max() <= 1e-4 * np.abs(rb[ok]).max()
+        assert not L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 2)
+        assert bflib.last_error()[0] == E.ParameterBlockUnallocated
+    finally:
+        L.beamformer_reserve_parameter_blocks(1)
+
+
+def test_one_shot_beamform_data(bflib, oracle):
+    L = bflib.library()
+    acq = cases.make("config2_small")
+    assert L.beamformer_create_filter(C.byref(acq.filters[0]), 0, 0)
+    ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    out = np.zeros(ref.shape, np.complex64)
+    rf = np.ascontiguousarray(acq.rf)
+    assert L.beamformer_beamform_data(C.byref(acq.bp), rf.ctypes.data_as(C.c_void_p), rf.nbytes,
+                                      out.ctypes.data_as(C.c_void_p), 60000), bflib.last_error()
+    assert np.abs(out - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+def test_push_data_validation(bflib):
+    L = bflib.library()
+    acq = cases.make("config1_small")
+    push(L, bflib, acq)
+    rf = np.ascontiguousarray(acq.rf)
+    ptr = rf.ctypes.data_as(C.c_void_p)
+    assert not L.beamformer_push_data_with_compute(ptr, rf.nbytes, 7, 0) and bflib.last_error()[0] == E.InvalidImagePlane
+    assert not L.beamformer_push_data_with_compute(ptr, rf.nbytes - 2, 0, 0) and bflib.last_error()[0] == E.DataSizeMismatch
+    assert not L.beamformer_push_data_with_compute(ptr, rf.nbytes + 2, 0, 0) and bflib.last_error()[0] == E.DataSizeMismatch
+    # a channel mapping that names a raw row that does not exist would read out of bounds
+    bad = (C.c_int16 * 256)(*([acq.bp.raw_data_dimensions[1]] * 256))
+    assert L.beamformer_push_channel_mapping(bad, acq.bp.channel_count)
+    assert not L.beamformer_push_data_with_compute(ptr, rf.nbytes, 0, 0) and bflib.last_error()[0] == E.DataSizeMismatch
+    assert L.beamformer_maximum_rf_data_size() == (4 << 30) // 3
+
+
+def test_device_resident_rf_shards_and_stats(bflib, oracle):
+    import torch
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    acq = cases.make("config4_small")
+    ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    push(L, bflib, acq)                                  # parameters + one host-pushed frame
+    whole = bflib.get_last_frame(acq.bp)
+    rf = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    Z = acq.bp.output_points[2]
+    parts = []
+    for first, count in ((0, Z // 3), (Z // 3, Z - Z // 3)):
+        assert L.beamformer_hip_set_output_shard(0, first, count)
+        assert L.beamformer_hip_push_device_data_with_compute(C.c_void_p(rf.data_ptr()), rf.numel(), 0, 0), bflib.last_error()
+        parts.append(bflib.get_last_frame(acq.bp, shard_planes=count))
+        info = P.HipFrameInfo()
+        assert L.beamformer_hip_get_last_frame_info(C.byref(info)) and info.points[2] == count
+    assert L.beamformer_hip_set_output_shard(0, 0, 0)
+    assert not L.beamformer_hip_set_output_shard(0, Z - 1, 2) and bflib.last_error()[0] == E.FrameSizeOverflow
+    stitched = np.concatenate(parts, axis=0)
+    assert np.array_equal(stitched, whole, equal_nan=True)           # bit identical to the unsharded frame
+    ok = ~np.isnan(ref)
+    assert np.abs(whole[ok] - ref[ok]).max() <= 2e-3 * np.abs(ref[ok]).max()
+
+    stats = P.ComputeStatsTable()
+    assert L.beamformer_compute_timings(C.byref(stats), -1)
+    ids = [stats.shader_ids[i] for i in range(stats.shader_count)]
+    assert ids == [int(P.ShaderKind.Demodulate), int(P.ShaderKind.DAS), int(P.ShaderKind.CoherencyWeighting)]
+    info = P.HipFrameInfo()
+    L.beamformer_hip_get_last_frame_info(C.byref(info))
+    row = stats.times[info.frame_id % 32]
+    assert row[1] > 0 and row[0] > 0                                  # seconds per stage of the newest frame
+    t = P.HipFrameTimings()
+    assert L.beamformer_hip_get_last_frame_timings(C.byref(t)) and t.frame_ms > 0 and t.das_path == 1
