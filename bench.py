@@ -172,9 +172,11 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[{args.config - 1}]: 3-D row-column DAS + coherency weighting, "
-                            f"{bp.channel_count} ch x {bp.acquisition_count} plane waves, Int16 RF {bp.sample_count} samples "
-                            f"-> Demodulate -> {X}x{Y}x{Z} complex voxels",
+                "workload": f"BASELINE configs[{args.config - 1}] ({acq.name}): {P.AcquisitionKind(bp.acquisition_kind).name} "
+                            f"{bp.channel_count} ch x {bp.acquisition_count} tx, {P.DataKind(bp.data_kind).name} RF {bp.sample_count} samples"
+                            f" -> {' -> '.join(P.ShaderKind(v).name for v in bp.compute_stages[:bp.compute_stages_count])}"
+                            f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "
+                            f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": f"{world} z-slab(s), RF broadcast via RCCL" if distributed else "none",
                 "das_path": ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel"][das_path],

@@ -84,6 +84,14 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_pair_counting(uint32_t enab
  * reference's shaders/min_max.glsl is dead code (beamformer_core.c:632-637). */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_frame_min_max(float out_min_max[2]);
 
+/* Average of the `count` newest frames (all of one size and kind), written to host memory:
+ * the reference's Sum stage -- shaders/sum.glsl applied once per frame, oldest first, with
+ * prescale 1/count onto a cleared image (beamformer_core.c:1417-1448).  The reference's
+ * planner skips Sum in every pipeline (beamformer_core.c:632-637) and so does this
+ * library; the stage is offered here so frame averaging (output_points[3]) has a device
+ * implementation.  out_size >= the 64-byte-rounded frame size. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_sum_last_frames(uint32_t count, void *out, uint64_t out_size);
+
 /* Select the DAS implementation: 0 = automatic (general kernel, or the separable-delay
  * gather kernel when the geometry allows), 1 = always the general kernel, 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower

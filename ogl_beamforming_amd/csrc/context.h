@@ -85,7 +85,7 @@ struct Context {
 	uint64_t     ring_next_offset = 0, frame_counter = 0;
 	std::vector<FrameRecord> frames;                           /* BeamformerMaxBacklogFrames records */
 	TimingSlot   timing[kTimingSlots];
-	DeviceBuffer pair_counter, minmax_scratch;
+	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
 	hipEvent_t   last_rf_event = nullptr;
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;
@@ -103,6 +103,7 @@ bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t ti
 bool last_frame_timings(BeamformerHipFrameTimings *out);
 bool fill_stats_table(BeamformerComputeStatsTable *out);
 bool frame_min_max(float out[2]);
+bool sum_last_frames(uint32_t count, void *out, uint64_t out_size);
 void shutdown_device();
 
 } // namespace bf

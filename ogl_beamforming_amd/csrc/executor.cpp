@@ -109,7 +109,7 @@ void shutdown_device()
 	c.raw_staging.release();
 	for (auto &b : c.rf) b.release();
 	for (auto &b : c.scratch) b.release();
-	c.ring.release(); c.pair_counter.release(); c.minmax_scratch.release();
+	c.ring.release(); c.pair_counter.release(); c.minmax_scratch.release(); c.sum_scratch.release();
 	for (auto &t : c.timing) {
 		if (t.created) for (auto &e : t.events) if (e) (void)hipEventDestroy(e);
 		t = TimingSlot{};
@@ -213,6 +213,9 @@ static FrameRecord *next_frame(const uint32_t points[3], bool complex_frame, uin
 	if (c.ring_next_offset > c.ring.size - bytes) c.ring_next_offset = 0;
 	uint64_t id = c.frame_counter++;
 	FrameRecord *f = &c.frames[id % c.frames.size()];
+	/* records whose storage this frame reuses stop being exportable */
+	for (FrameRecord &old : c.frames)
+		if (old.bytes && old.offset < c.ring_next_offset + bytes && c.ring_next_offset < old.offset + old.bytes) old.bytes = 0;
 	f->offset = c.ring_next_offset; f->bytes = bytes;
 	f->points[0] = points[0]; f->points[1] = points[1]; f->points[2] = points[2];
 	f->data_kind = kind; f->id = (uint32_t)id; f->block = block;
@@ -689,7 +692,7 @@ bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t ti
 	bool ok = true;
 	for (uint64_t n = 0; n < req; n++, index++) {
 		const FrameRecord &f = c.frames[index % c.frames.size()];
-		if (exported + f.bytes <= out_size) {
+		if (f.bytes && exported + f.bytes <= out_size) {
 			ok &= HIP_OK(hipMemcpyAsync((char *)out + exported, (const char *)c.ring.ptr + f.offset, f.bytes,
 			                            hipMemcpyDeviceToHost, c.stream));
 			exported += f.bytes;
@@ -764,6 +767,36 @@ bool frame_min_max(float out[2])
 	bool ok = HIP_OK(bf_launch_min_max((const char *)c.ring.ptr + f.offset, voxels,
 	                                   f.data_kind == BeamformerDataKind_Float32Complex, scratch + 2, scratch, c.stream));
 	ok &= HIP_OK(hipMemcpyAsync(out, scratch, 2 * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+}
+
+/* Rolling average of the `count` newest frames as the reference's Sum stage specifies it
+ * (beamformer_core.c:1417-1448 + shaders/sum.glsl): cleared output, then one
+ * out += (1/count) * frame pass per frame, oldest first.  The reference's planner drops
+ * Sum from every pipeline (beamformer_core.c:632-637), so this is reachable only through
+ * the extension and never changes what get_last_frames returns. */
+bool sum_last_frames(uint32_t count, void *out, uint64_t out_size)
+{
+	Context &c = g_context;
+	if (!c.device_ready || c.frame_counter == 0 || count == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (count > c.frame_counter || count > c.frames.size()) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	const FrameRecord &newest = c.frames[(c.frame_counter - 1) % c.frames.size()];
+	for (uint64_t id = c.frame_counter - count; id < c.frame_counter; id++) {
+		const FrameRecord &f = c.frames[id % c.frames.size()];
+		if (!f.bytes || f.bytes != newest.bytes || f.data_kind != newest.data_kind ||
+		    f.points[0] != newest.points[0] || f.points[1] != newest.points[1] || f.points[2] != newest.points[2])
+			return set_error(BeamformerLibErrorKind_DataSizeMismatch);
+	}
+	if (out_size < newest.bytes) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
+	if (!c.sum_scratch.ensure(newest.bytes)) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	bool ok = HIP_OK(hipMemsetAsync(c.sum_scratch.ptr, 0, newest.bytes, c.stream));
+	float prescale = 1.0f / (float)count;
+	for (uint64_t id = c.frame_counter - count; ok && id < c.frame_counter; id++) {
+		const FrameRecord &f = c.frames[id % c.frames.size()];
+		ok &= HIP_OK(bf_launch_sum(c.sum_scratch.ptr, (const char *)c.ring.ptr + f.offset, prescale, f.bytes, c.stream));
+	}
+	ok &= HIP_OK(hipMemcpyAsync(out, c.sum_scratch.ptr, newest.bytes, hipMemcpyDeviceToHost, c.stream));
 	ok &= HIP_OK(hipStreamSynchronize(c.stream));
 	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 }

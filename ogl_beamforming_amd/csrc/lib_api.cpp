@@ -421,6 +421,13 @@ uint32_t beamformer_hip_frame_min_max(float out_min_max[2])
 	return frame_min_max(out_min_max);
 }
 
+uint32_t beamformer_hip_sum_last_frames(uint32_t count, void *out, uint64_t out_size)
+{
+	if (!out) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (!ensure_device()) return 0;
+	return sum_last_frames(count, out, out_size);
+}
+
 uint32_t beamformer_hip_set_das_path(uint32_t mode) { ctx().das_path_mode = mode; return 1; }
 
 uint32_t beamformer_hip_host_hadamard(uint32_t order, float *out)

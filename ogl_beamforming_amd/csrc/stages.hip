@@ -13,6 +13,7 @@
 #include "bf_kernels.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 /* ------------------------------------------------------------------ element access */
 
@@ -337,6 +338,33 @@ extern "C" hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s)
 	bool f16 = (a->in_kind >> 1) != 1;
 	if (f16) hipLaunchKernelGGL((filter_kernel<true>),  grid, dim3(256), lds, s, *a);
 	else     hipLaunchKernelGGL((filter_kernel<false>), grid, dim3(256), lds, s, *a);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------ sum */
+
+/* shaders/sum.glsl:7-12: out += prescale * in over every component of the frame.  The
+ * reference's dispatch (beamformer_core.c:1417-1448, dead code there) clears the output and
+ * applies this once per input frame, oldest first, with prescale = 1/frame_count; the
+ * order of the additions is kept.  Frames are whole multiples of 64 bytes. */
+__global__ __launch_bounds__(256) void sum_kernel(f32x4 *out, const f32x4 *in, float prescale, uint64_t count4)
+{
+	#pragma clang fp contract(off)
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (uint64_t)gridDim.x * 256) {
+		f32x4 o = out[i], v = __builtin_nontemporal_load(in + i);
+		o.x = o.x + prescale * v.x; o.y = o.y + prescale * v.y;
+		o.z = o.z + prescale * v.z; o.w = o.w + prescale * v.w;
+		out[i] = o;
+	}
+}
+
+extern "C" hipError_t bf_launch_sum(void *out, const void *in, float prescale, uint64_t bytes, hipStream_t s)
+{
+	uint64_t count4 = bytes / 16;
+	uint64_t blocks = (count4 + 255) / 256;
+	if (blocks > 256 * 16) blocks = 256 * 16;
+	if (!blocks) return hipSuccess;
+	hipLaunchKernelGGL(sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, (f32x4 *)out, (const f32x4 *)in, prescale, count4);
 	return hipGetLastError();
 }
 

@@ -103,6 +103,7 @@ def _load():
         "beamformer_hip_get_last_frame_timings": (u32, [C.POINTER(P.HipFrameTimings)]),
         "beamformer_hip_enable_pair_counting": (u32, [u32]),
         "beamformer_hip_frame_min_max": (u32, [C.POINTER(C.c_float)]),
+        "beamformer_hip_sum_last_frames": (u32, [u32, vp, u64]),
         "beamformer_hip_set_das_path": (u32, [u32]),
         "beamformer_hip_host_hadamard": (u32, [u32, C.POINTER(C.c_float)]),
         "beamformer_hip_host_filter": (i32, [C.POINTER(P.FilterParameters), C.POINTER(C.c_float), u32,

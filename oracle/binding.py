@@ -85,6 +85,10 @@ def library():
         lib.oracle_das_transform.argtypes = [fp, fp, C.POINTER(C.c_int), fp]
         lib.oracle_das_transform_2d.argtypes = [C.c_int, fp, fp, C.c_float, fp]
         lib.oracle_das_transform_3d.argtypes = [fp, fp, fp]
+        lib.oracle_sum.argtypes = [fp, fp, C.c_float, C.c_uint64]
+        lib.oracle_sum.restype = None
+        lib.oracle_min_max.argtypes = [fp, C.c_uint64, C.c_int, fp]
+        lib.oracle_min_max.restype = None
         lib.oracle_filter_create.restype = C.c_int
         lib.oracle_filter_create.argtypes = [C.POINTER(P.FilterParameters), fp, C.c_int, fp]
         _lib = lib
@@ -145,3 +149,26 @@ def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None):
         timing["das_seconds"] = das_seconds.value
     frame = out.view(np.complex64) if p.iq_pipeline else out
     return frame.reshape(nz, ny, pts[0]), int(pairs.value)
+
+
+def sum_frames(frames):
+    """The reference's Sum stage over `frames` (oldest first): cleared image, then one
+    sum.glsl pass per frame with prescale 1/len(frames) (beamformer_core.c:1417-1448)."""
+    lib = library()
+    first = np.ascontiguousarray(frames[0])
+    out = np.zeros(first.shape, first.dtype)
+    fp = C.POINTER(C.c_float)
+    prescale = np.float32(1.0) / np.float32(len(frames))
+    for f in frames:
+        f = np.ascontiguousarray(f, dtype=first.dtype)
+        lib.oracle_sum(out.ctypes.data_as(fp), f.ctypes.data_as(fp), C.c_float(float(prescale)), out.nbytes // 4)
+    return out
+
+
+def min_max(frame):
+    lib = library()
+    frame = np.ascontiguousarray(frame)
+    out = np.zeros(2, np.float32)
+    fp = C.POINTER(C.c_float)
+    lib.oracle_min_max(frame.ctypes.data_as(fp), frame.size, int(np.iscomplexobj(frame)), out.ctypes.data_as(fp))
+    return out

@@ -109,6 +109,9 @@ void oracle_filter(const OracleFilter *f, const void *in, void *out, uint32_t ou
 void oracle_coherency_weighting(float *coherent, const float *incoherent, uint32_t voxels,
                                 int complex_data, float scale);
 
+/* sum.glsl:7-12, one pass: out += prescale * in over `floats` components */
+void oracle_sum(float *out, const float *in, float prescale, uint64_t floats);
+
 /* build-defined reduction (shaders/min_max.glsl is dead code in the reference):
  * min and max over voxels of |v| (complex) or v (real).  PARITY UNPINNED. */
 void oracle_min_max(const float *frame, uint64_t voxels, int complex_data, float *out2);

@@ -254,6 +254,11 @@ void oracle_coherency_weighting(float *coherent, const float *incoherent, uint32
 		}
 }
 
+void oracle_sum(float *out, const float *in, float prescale, uint64_t floats)
+{
+	for (uint64_t i = 0; i < floats; i++) out[i] = out[i] + prescale * in[i];
+}
+
 void oracle_min_max(const float *frame, uint64_t voxels, int complex_data, float *out2)
 {
 	float lo = INFINITY, hi = -INFINITY;

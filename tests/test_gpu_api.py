@@ -137,3 +137,35 @@ def test_device_resident_rf_shards_and_stats(bflib, oracle):
     assert row[1] > 0 and row[0] > 0                                  # seconds per stage of the newest frame
     t = P.HipFrameTimings()
     assert L.beamformer_hip_get_last_frame_timings(C.byref(t)) and t.frame_ms > 0 and t.das_path == 1
+
+
+def test_sum_of_last_frames_matches_the_sum_stage(bflib, oracle):
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    acq = cases.make("config2_small")
+    push(L, bflib, acq)
+    frames = [bflib.get_last_frame(acq.bp).copy()]
+    rng = np.random.default_rng(5)
+    for _ in range(2):                                    # three different frames of one geometry
+        rf = np.ascontiguousarray((acq.rf.astype(np.float32) * rng.uniform(0.5, 2.0)
+                                   + rng.standard_normal(acq.rf.shape).astype(np.float32)).astype(acq.rf.dtype))
+        assert L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0), bflib.last_error()
+        frames.append(bflib.get_last_frame(acq.bp).copy())
+    for count in (1, 2, 3):
+        ref = oracle.sum_frames(frames[-count:])
+        out = np.zeros((frames[0].nbytes + 63) // 64 * 16, np.float32)
+        assert L.beamformer_hip_sum_last_frames(count, out.ctypes.data_as(C.c_void_p), out.nbytes), bflib.last_error()
+        got = out[: ref.size * 2].view(np.complex64).reshape(ref.shape)
+        assert np.array_equal(got, ref)                   # same additions in the same order: bit exact
+    mm = (C.c_float * 2)()
+    assert L.beamformer_hip_frame_min_max(mm)
+    assert np.array_equal(np.array(mm[:], np.float32), oracle.min_max(frames[-1]))
+    # frames of another size cannot be averaged with these; undersized output is refused
+    other = cases.make("hercules_real")
+    push(L, bflib, other)
+    out = np.zeros(1 << 20, np.float32)
+    assert not L.beamformer_hip_sum_last_frames(2, out.ctypes.data_as(C.c_void_p), out.nbytes)
+    assert bflib.last_error()[0] == E.DataSizeMismatch
+    assert not L.beamformer_hip_sum_last_frames(1, out.ctypes.data_as(C.c_void_p), 16)
+    assert bflib.last_error()[0] == E.ExportSpaceOverflow
+    assert not L.beamformer_hip_sum_last_frames(0, out.ctypes.data_as(C.c_void_p), out.nbytes)
