@@ -34,6 +34,15 @@ struct FrameRecord {
 	int      timing_slot = -1;
 };
 
+/* one RF frame in flight on the upload side (beamformer_rf_upload's slot, beamformer_core.c:1756-1805) */
+struct UploadSlot {
+	void      *pinned = nullptr;         /* hipHostMalloc staging the caller's bytes land in */
+	size_t     pinned_size = 0;
+	hipEvent_t copied = nullptr;         /* H2D of this slot finished (copy stream) */
+	hipEvent_t consumed = nullptr;       /* the frame that read this slot's device buffers finished (compute stream) */
+	bool       copy_pending = false, consume_pending = false;
+};
+
 struct TimingSlot {
 	hipEvent_t events[BEAMFORMER_HIP_MAX_TIMED_STAGES + 1]{};
 	uint32_t   kinds[BEAMFORMER_HIP_MAX_TIMED_STAGES]{};
@@ -77,7 +86,9 @@ struct Context {
 	bool         device_ready = false;
 	hipStream_t  own_stream = nullptr, stream = nullptr;
 	PlanState    plans[BeamformerMaxParameterBlocks];
-	DeviceBuffer raw_staging;
+	DeviceBuffer raw_staging[BeamformerMaxRawDataFramesInFlight];
+	UploadSlot   upload[BeamformerMaxRawDataFramesInFlight];
+	hipStream_t  copy_stream = nullptr;                        /* H2D of frame n+1 overlaps compute of frame n */
 	DeviceBuffer rf[BeamformerMaxRawDataFramesInFlight];     /* beamformer.meta:8: 3 in flight */
 	uint64_t     rf_index = 0;
 	DeviceBuffer scratch[2];                                   /* ping-pong (reference: 3 slots of one buffer) */
@@ -86,7 +97,6 @@ struct Context {
 	std::vector<FrameRecord> frames;                           /* BeamformerMaxBacklogFrames records */
 	TimingSlot   timing[kTimingSlots];
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
-	hipEvent_t   last_rf_event = nullptr;
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;
 };

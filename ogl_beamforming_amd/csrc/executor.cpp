@@ -2,8 +2,9 @@
  * launches, frame ring, export, timings.
  *
  * Replaces the reference's two worker loops and their Vulkan plumbing:
- *   beamformer_rf_upload        (beamformer_core.c:1756-1805)  -> push_rf_and_compute: one async
- *                                                                H2D copy + the ingest kernel
+ *   beamformer_rf_upload        (beamformer_core.c:1756-1805)  -> push_rf_and_compute: pinned
+ *                                                                slot + H2D on a copy stream
+ *                                                                + the ingest kernel
  *   complete_queue / Compute    (beamformer_core.c:1519-1677)  -> run_frame: stage launches in
  *                                                                stream order, one pass over
  *                                                                all channels
@@ -86,6 +87,8 @@ bool ensure_device()
 	if (!HIP_OK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking)))
 		return set_error(BeamformerLibErrorKind_SharedMemory);
 	if (!c.stream) c.stream = c.own_stream;
+	if (!HIP_OK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking)))
+		return set_error(BeamformerLibErrorKind_SharedMemory);
 	if (!c.frame_ring_bytes) c.frame_ring_bytes = default_frame_ring_bytes();
 	if (!c.ring.ensure(c.frame_ring_bytes)) return set_error(BeamformerLibErrorKind_SharedMemory);
 	c.frames.assign(BeamformerMaxBacklogFrames, FrameRecord{});
@@ -106,7 +109,15 @@ void shutdown_device()
 		for (auto &t : p.taps) t.release();
 		p.taps.clear(); p.valid = false;
 	}
-	c.raw_staging.release();
+	for (auto &b : c.raw_staging) b.release();
+	for (auto &u : c.upload) {
+		if (u.pinned) (void)hipHostFree(u.pinned);
+		if (u.copied) (void)hipEventDestroy(u.copied);
+		if (u.consumed) (void)hipEventDestroy(u.consumed);
+		u = UploadSlot{};
+	}
+	if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+	c.copy_stream = nullptr;
 	for (auto &b : c.rf) b.release();
 	for (auto &b : c.scratch) b.release();
 	c.ring.release(); c.pair_counter.release(); c.minmax_scratch.release(); c.sum_scratch.release();
@@ -628,18 +639,61 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	(void)hipEventRecord(t.events[0], s);
 
-	bool ok = true;
-	if (identity && !a1s2 && in_row == out_row) {
-		/* the mapped layout is the raw layout: one copy straight into the RF slot */
-		ok &= HIP_OK(hipMemcpyAsync(c.rf[slot].ptr, data, rf_size,
-		                            data_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-	} else {
-		const void *raw = data;
-		if (!data_on_device) {
-			if (!c.raw_staging.ensure(round_up(size, 64) + 64)) return set_error(BeamformerLibErrorKind_BufferOverflow);
-			ok &= HIP_OK(hipMemcpyAsync(c.raw_staging.ptr, data, size, hipMemcpyHostToDevice, s));
-			raw = c.raw_staging.ptr;
+	UploadSlot &u = c.upload[slot];
+	if (!u.copied && (!HIP_OK(hipEventCreateWithFlags(&u.copied, hipEventDisableTiming)) ||
+	                  !HIP_OK(hipEventCreateWithFlags(&u.consumed, hipEventDisableTiming))))
+		return set_error(BeamformerLibErrorKind_SharedMemory);
+
+	bool ok = true, overlap = false;
+	const bool direct = identity && !a1s2 && in_row == out_row;
+	const void *raw = data;
+	if (!data_on_device) {
+		/* Host data: the caller's bytes are copied into a pinned slot (after which the caller
+		 * may reuse its buffer, as with the reference's copy into shared memory), the H2D runs
+		 * on the copy stream and the compute stream waits for it -- so the upload of frame n+1
+		 * overlaps the kernels of frame n, which one stream and pageable memory cannot do.
+		 * A copy-engine transfer and each cross-queue dependency cost 40-60 us of latency on
+		 * this runtime (build/h2d_probe.cpp: 0.26 MB pinned H2D + a kernel = 114 us per frame),
+		 * more than a small frame's compute, so frames under kOverlapBytes skip the copy engine:
+		 * the ingest kernel reads the pinned slot in place over PCIe, in order on the compute
+		 * stream. */
+		constexpr uint32_t kOverlapBytes = 8u << 20;
+		overlap = size >= kOverlapBytes;
+		if (u.copy_pending) { (void)hipEventSynchronize(u.copied); u.copy_pending = false; }
+		if (u.pinned_size < size) {
+			if (u.pinned) (void)hipHostFree(u.pinned);
+			u.pinned = nullptr; u.pinned_size = 0;
+			if (!HIP_OK(hipHostMalloc(&u.pinned, round_up(size, 4096), hipHostMallocDefault))) {
+				u.pinned = nullptr;
+				return set_error(BeamformerLibErrorKind_BufferOverflow);
+			}
+			u.pinned_size = round_up(size, 4096);
 		}
+		std::memcpy(u.pinned, data, size);
+		if (overlap) {
+			void *dst = c.rf[slot].ptr;
+			if (!direct) {
+				if (!c.raw_staging[slot].ensure(round_up(size, 64) + 64)) return set_error(BeamformerLibErrorKind_BufferOverflow);
+				dst = c.raw_staging[slot].ptr;
+			}
+			/* the device buffers of this slot were last read by the frame three pushes ago */
+			if (u.consume_pending) ok &= HIP_OK(hipStreamWaitEvent(c.copy_stream, u.consumed, 0));
+			ok &= HIP_OK(hipMemcpyAsync(dst, u.pinned, direct ? rf_size : (uint64_t)size, hipMemcpyHostToDevice, c.copy_stream));
+			ok &= HIP_OK(hipEventRecord(u.copied, c.copy_stream));
+			u.copy_pending = true;
+			ok &= HIP_OK(hipStreamWaitEvent(s, u.copied, 0));
+			raw = dst;
+		} else {
+			void *mapped = nullptr;
+			if (!HIP_OK(hipHostGetDevicePointer(&mapped, u.pinned, 0))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+			raw = mapped;
+		}
+	}
+	const bool zero_copy = !data_on_device && !overlap;
+	if (direct && !zero_copy) {
+		/* the mapped layout is the raw layout: one copy straight into the RF slot */
+		if (data_on_device) ok &= HIP_OK(hipMemcpyAsync(c.rf[slot].ptr, data, rf_size, hipMemcpyDeviceToDevice, s));
+	} else {
 		PlanState *ps = commit_block(block);
 		if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
 		BfIngestArgs a{};
@@ -649,6 +703,10 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 		a.a1s2 = a1s2; a.base = bf_kind_base[pb.data_kind];
 		a.a1s2_scalars = bp.sample_count * (uint32_t)bf_kind_element_count[pb.data_kind];
 		ok &= HIP_OK(bf_launch_ingest(&a, s));
+		if (zero_copy) {                   /* the pinned slot is free again once this kernel has run */
+			ok &= HIP_OK(hipEventRecord(u.copied, s));
+			u.copy_pending = true;
+		}
 	}
 	if (!ok) return set_error(BeamformerLibErrorKind_InvalidAccess);
 
@@ -659,7 +717,9 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	c.last_push_time = now;
 
-	return run_frame(block, slot, true);
+	bool done = run_frame(block, slot, true);
+	u.consume_pending = HIP_OK(hipEventRecord(u.consumed, s));
+	return done;
 }
 
 /* the reference waits on futex locks with a timeout (lib .c:192-198, :679);

@@ -169,3 +169,28 @@ def test_sum_of_last_frames_matches_the_sum_stage(bflib, oracle):
     assert not L.beamformer_hip_sum_last_frames(1, out.ctypes.data_as(C.c_void_p), 16)
     assert bflib.last_error()[0] == E.ExportSpaceOverflow
     assert not L.beamformer_hip_sum_last_frames(0, out.ctypes.data_as(C.c_void_p), out.nbytes)
+
+
+def test_pipelined_host_pushes_keep_their_own_data(bflib):
+    """Host pushes go through three pinned slots and a copy stream; nine back-to-back pushes
+    of alternating RF (x1, x2: exact in every stage) must come out as F, 2F, F, ... with no
+    slot read before its upload landed or overwritten before its frame finished."""
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    for name in ("config1_small", "rca_shuffled_padded"):      # direct copy / ingest-kernel path
+        acq = cases.make(name)
+        push(L, bflib, acq)
+        base = bflib.get_last_frame(acq.bp).copy()
+        assert np.abs(acq.rf).max() < 16000
+        rfs = [np.ascontiguousarray(acq.rf), np.ascontiguousarray(acq.rf * 2)]
+        for n in range(9):
+            rf = rfs[n & 1]
+            assert L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0), bflib.last_error()
+        size = (base.nbytes + 63) // 64 * 64
+        out = np.zeros(4 * size // 4, np.float32)
+        assert L.beamformer_get_last_frames(out.ctypes.data_as(C.c_void_p), out.nbytes, 4)
+        for k in range(4):                                      # frames 5..8 -> x2, x1, x2, x1
+            got = out[k * size // 4: k * size // 4 + base.size * (2 if np.iscomplexobj(base) else 1)]
+            got = got.view(base.dtype).reshape(base.shape)
+            scale = 2 if (5 + k) & 1 else 1
+            assert np.array_equal(got, base * scale, equal_nan=True), (name, k)
