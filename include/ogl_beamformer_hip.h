@@ -96,7 +96,9 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_sum_last_frames(uint32_t count, vo
  * gather kernel when the geometry allows), 1 = always the general kernel, 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower
  * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
- * For parity testing of every path. */
+ * Adding 0x10 keeps the general kernel at one thread per voxel for frames it would otherwise
+ * split over channels (frames under ~4096 waves of voxels: K waves share 64 voxels, each
+ * sums C/K channels, partial sums meet in LDS).  For parity testing of every path. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 
 /* ---- host-side introspection (no device needed; used by tests/ to pin the host math

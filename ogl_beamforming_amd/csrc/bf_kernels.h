@@ -51,7 +51,8 @@ typedef struct {
 	uint32_t size[3];                 /* whole output grid */
 	uint32_t z_first, z_count;        /* shard of the grid computed by this launch */
 	uint32_t readi_group_count, readi_group;
-	uint32_t tile_shift[3];           /* log2 of the 256-thread block's extent per axis */
+	uint32_t tile_shift[3];           /* log2 of the block's voxel tile extent per axis (256 voxels, or 64 with a channel split) */
+	uint32_t split_shift;             /* log2 K: K waves of a block share 64 voxels, each summing C/K channels */
 	uint32_t blocks[3];               /* blocks per axis */
 } BfDasArgs;
 

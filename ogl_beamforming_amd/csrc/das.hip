@@ -131,11 +131,11 @@ __device__ __forceinline__ float sample_index(float distance, const BfDasArgs &p
 /* das.glsl:204-231 */
 template <int INTERP, bool CPLX, bool CW, bool COUNT>
 __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, float wx, float wy, float wz,
-                                        Accumulator<CPLX, CW, COUNT> &acc)
+                                        int ch0, int ch1, Accumulator<CPLX, CW, COUNT> &acc)
 {
 	float xx, xy, xz;
 	m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
-	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+	const int S = p.sample_count, A = p.acquisition_count;
 	const float inv_abs_z = hw_rcp(__builtin_fabsf(xz));
 	const float zz = xz * xz;
 
@@ -147,8 +147,8 @@ __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, floa
 		const float tx_dist = transmit_distance(t, wx, wy, wz);
 		const float f_over_z = p.f_number * inv_abs_z;
 
-		int rf_offset = acquisition * S;
-		for (int channel = 0; channel < C; channel++) {
+		int rf_offset = acquisition * S + ch0 * S * A;
+		for (int channel = ch0; channel < ch1; channel++) {
 			float dx    = lateral - (float)channel * pitch;
 			float a_arg = __builtin_fabsf(dx * f_over_z);
 			bool  pass  = a_arg < 0.5f;
@@ -166,11 +166,11 @@ __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, floa
 /* das.glsl:233-286 */
 template <int INTERP, bool CPLX, bool CW, bool COUNT>
 __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf, float wx, float wy, float wz,
-                                             Accumulator<CPLX, CW, COUNT> &acc)
+                                             int ch0, int ch1, Accumulator<CPLX, CW, COUNT> &acc)
 {
 	float xx, xy, xz;
 	m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
-	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+	const int S = p.sample_count, A = p.acquisition_count;
 	const int sparse = p.sparse != 0;
 	const BfTransmit t0 = p.transmits[0];
 	const bool  rx_cols = (t0.flags & BF_RX_COLUMNS) != 0;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 	const float fs_over_c        = p.sampling_frequency * p.inv_speed_of_sound;
 	const float first_weight     = hw_rsq((float)A);
 
-	for (int channel = 0; channel < C; channel++) {
+	for (int channel = ch0; channel < ch1; channel++) {
 		int rf_offset = channel * S * A + sparse * S;
 		/* squared lateral distance to the receive element along the receive axis */
 		float rx_delta = rx_cols ? xx - (float)channel * p.pitch[0] : xy - (float)channel * p.pitch[1];
@@ -210,7 +210,7 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
  * pre-multiplies the voxel transform (beamformer_core.c:913-915). */
 template <int INTERP, bool CPLX, bool CW, bool COUNT, bool READI>
 __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, float xx, float xy, float xz,
-                                           Accumulator<CPLX, CW, COUNT> &acc)
+                                           int ch0, int ch1, Accumulator<CPLX, CW, COUNT> &acc)
 {
 	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
 	const int sparse = p.sparse != 0;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 	const float f_over_z            = p.f_number * hw_rcp(xz);
 	const int   hadamard_offset     = (int)p.readi_group * (int)p.readi_group_count;
 
-	for (int channel = 0; channel < C; channel++) {
+	for (int channel = ch0; channel < ch1; channel++) {
 		float receive_x_delta = xx - (float)channel * p.pitch[0];
 		float a_arg           = __builtin_fabsf(receive_x_delta * f_over_z);
 		const bool pass       = a_arg < 0.5f;
@@ -265,10 +265,15 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 	}
 }
 
-/* das.glsl:368-407.  Grid: p.blocks[0]*p.blocks[1]*p.blocks[2] blocks of 256 threads; a
- * block is a (1<<tile_shift[0]) x (1<<tile_shift[1]) x (1<<tile_shift[2]) voxel tile. */
+/* das.glsl:368-407.  Grid: p.blocks[0]*p.blocks[1]*p.blocks[2] blocks; a block is a
+ * (1<<tile_shift[0]) x (1<<tile_shift[1]) x (1<<tile_shift[2]) voxel tile: 256 voxels and
+ * 256 threads, or -- for frames too small to fill the chip -- 64 voxels and K = 1<<split_shift
+ * waves that each sum a contiguous range of C/K channels and combine through LDS. */
+#ifndef BF_DAS_MAX_THREADS
+#define BF_DAS_MAX_THREADS 1024
+#endif
 template <int FAMILY, int INTERP, bool CPLX, bool CW, bool COUNT>
-__global__ __launch_bounds__(256) void das_kernel(const BfDasArgs p)
+__global__ __launch_bounds__(BF_DAS_MAX_THREADS) void das_kernel(const BfDasArgs p)
 {
 	/* blockIdx -> tile: consecutive block ids go round-robin over the 8 XCDs, so ids that
 	 * share (id % 8) share an L2.  Deal the tile list out so that each XCD walks a
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(256) void das_kernel(const BfDasArgs p)
 	uint32_t tid = threadIdx.x;
 	uint32_t lx  = tid & ((1u << p.tile_shift[0]) - 1u);
 	uint32_t ly  = (tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u);
-	uint32_t lz  = tid >> (p.tile_shift[0] + p.tile_shift[1]);
+	uint32_t lz  = (tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u);
+	uint32_t split = tid >> (p.tile_shift[0] + p.tile_shift[1] + p.tile_shift[2]);   /* wave-uniform when K > 1 */
 	uint32_t x = (bx << p.tile_shift[0]) + lx;
 	uint32_t y = (by << p.tile_shift[1]) + ly;
 	uint32_t zl = (bz << p.tile_shift[2]) + lz;       /* z inside the shard */
@@ -305,11 +311,37 @@ __global__ __launch_bounds__(256) void das_kernel(const BfDasArgs p)
 		float wx, wy, wz;
 		m4_point(p.voxel_transform, px, py, pz, wx, wy, wz);
 		const char *rf = (const char *)p.rf;
+		const int C   = p.channel_count;
+		const int per = (C + (1 << p.split_shift) - 1) >> p.split_shift;
+		const int ch0 = (int)split * per;
+		const int ch1 = ch0 + per < C ? ch0 + per : C;
 
-		if constexpr (FAMILY == BF_DAS_RCA)           das_rca<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, acc);
-		else if constexpr (FAMILY == BF_DAS_HERCULES) das_hercules<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, acc);
-		else if constexpr (FAMILY == BF_DAS_FORCES)   das_forces<INTERP, CPLX, CW, COUNT, false>(p, rf, wx, wy, wz, acc);
-		else                                          das_forces<INTERP, CPLX, CW, COUNT, true>(p, rf, wx, wy, wz, acc);
+		if constexpr (FAMILY == BF_DAS_RCA)           das_rca<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, ch0, ch1, acc);
+		else if constexpr (FAMILY == BF_DAS_HERCULES) das_hercules<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, ch0, ch1, acc);
+		else if constexpr (FAMILY == BF_DAS_FORCES)   das_forces<INTERP, CPLX, CW, COUNT, false>(p, rf, wx, wy, wz, ch0, ch1, acc);
+		else                                          das_forces<INTERP, CPLX, CW, COUNT, true>(p, rf, wx, wy, wz, ch0, ch1, acc);
+	}
+
+	if constexpr (!COUNT) {
+		if (p.split_shift) {
+			/* partial sums of waves 1..K-1 go through LDS; wave 0 adds them in split order */
+			extern __shared__ float partial[];                 /* [K-1][3][64] */
+			const uint32_t lane = tid & 63u;
+			if (split) {
+				float *row = partial + (split - 1) * 192 + lane;
+				if constexpr (CPLX) { row[0] = acc.coherent.x; row[64] = acc.coherent.y; }
+				else                { row[0] = acc.coherent; }
+				if constexpr (CW) row[128] = acc.incoherent;
+			}
+			__syncthreads();
+			if (split) return;
+			for (uint32_t k = 1; k < (1u << p.split_shift); k++) {
+				const float *row = partial + (k - 1) * 192 + lane;
+				if constexpr (CPLX) { acc.coherent.x += row[0]; acc.coherent.y += row[64]; }
+				else                { acc.coherent += row[0]; }
+				if constexpr (CW) acc.incoherent += row[128];
+			}
+		}
 	}
 
 	if constexpr (COUNT) {
@@ -331,7 +363,9 @@ static hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
 {
 	uint32_t total = a->blocks[0] * a->blocks[1] * a->blocks[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
-	hipLaunchKernelGGL((das_kernel<FAMILY, INTERP, CPLX, CW, COUNT>), dim3(grid), dim3(256), 0, s, *a);
+	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
+	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
+	hipLaunchKernelGGL((das_kernel<FAMILY, INTERP, CPLX, CW, COUNT>), dim3(grid), dim3(threads), lds, s, *a);
 	return hipGetLastError();
 }
 

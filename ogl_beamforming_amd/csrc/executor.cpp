@@ -236,11 +236,11 @@ static FrameRecord *next_frame(const uint32_t points[3], bool complex_frame, uin
 
 static uint32_t ceil_log2(uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; }
 
-/* Shape of the 256-voxel block of the DAS launch.  The axis along which the transducer-space
+/* Shape of the 2^tile_log2-voxel block of the DAS launch.  The axis along which the transducer-space
  * depth changes fastest gets extent 1: sample indices move ~2 samples per voxel along depth
  * but only a fraction of a sample per voxel laterally, so a depth-flat tile keeps the 64 lanes
  * of a wave within a few cache lines of every (channel, transmit) row. */
-static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3])
+static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3], uint32_t tile_log2 = 8)
 {
 	uint32_t extent[3] = {size[0], size[1], zcount};
 	uint32_t full[3]   = {size[0], size[1], size[2]};
@@ -250,11 +250,11 @@ static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint3
 		float step = std::fabs(voxel_to_xdc[4 * i + 2]) / (float)(full[i] > 1 ? full[i] - 1 : 1);
 		if (step > best) { best = step; depth = i; }
 	}
-	uint32_t cap[3], left = 8;
+	uint32_t cap[3], left = tile_log2;
 	for (int i = 0; i < 3; i++) { cap[i] = ceil_log2(extent[i]); shift[i] = 0; }
 	int lateral[2], nl = 0;
 	for (int i = 0; i < 3; i++) if (i != depth && extent[i] > 1) lateral[nl++] = i;
-	uint32_t first = nl == 2 ? 4 : 8;
+	uint32_t first = nl == 2 ? tile_log2 / 2 : tile_log2;
 	for (int k = 0; k < nl; k++) {
 		uint32_t give = cap[lateral[k]] < first ? cap[lateral[k]] : first;
 		if (give > left) give = left;
@@ -269,7 +269,7 @@ static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint3
 		uint32_t give = cap[depth] < left ? cap[depth] : left;
 		shift[depth] = give; left -= give;
 	}
-	shift[0] += left;   /* fewer than 256 voxels in total: idle lanes */
+	shift[0] += left;   /* fewer voxels in total than the tile: idle lanes */
 }
 
 /* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
@@ -552,21 +552,27 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 			float to_xdc[16];
 			if (a.family == BF_DAS_FORCES || a.family == BF_DAS_READI) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
 			else m4_mul(bp.xdc_transform, plan.das_voxel_transform, to_xdc);
-			choose_tile(to_xdc, a.size, zcount, a.tile_shift);
 			uint32_t ext[3] = {a.size[0], a.size[1], zcount};
+			/* Small frames (real-time 2-D imaging) do not fill 256 CUs with one thread per voxel:
+			 * split the channel loop over K waves of a block (wave-level partial sums, combined
+			 * through LDS in split order) until the launch has ~16 waves per CU. */
+			uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
+			a.split_shift = 0;
+			while (!(c.das_path_mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
+			choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
 			for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 
 			if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
 			} else {
 				BfSeparableArgs sep{};
-				if (c.das_path_mode != 1 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+				if ((c.das_path_mode & 0xF) != 1 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
 					 * allocated with that much slack): the gather target of out-of-range lanes */
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					sep.zero_offset = (uint32_t)used;
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					if (c.das_path_mode == 3 && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+					if ((c.das_path_mode & 0xF) == 3 && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 						ok &= HIP_OK(bf_launch_das_staged(&a, &sep, s));
 						das_path = 2;
 					} else {

@@ -94,6 +94,22 @@ def test_lds_staged_kernel(name, bflib, oracle):
     compare(gpu, ref, acq)
 
 
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_general_kernel_without_channel_split(name, bflib, oracle):
+    """These acquisitions are small, so the default launch splits the channel loop over waves;
+    0x11 forces the one-thread-per-voxel form of the same kernel that full-size frames use."""
+    acq = cases.make(name)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    lib.beamformer_hip_set_das_path(0x11)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == 0
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq)
+
+
 def test_pair_count_matches_oracle(bflib, oracle):
     """G of the roofline model: the geometry-only count kernel agrees with the oracle's tally
     of taken apodization branches (exactly, up to aperture-edge rounding)."""
