@@ -101,6 +101,38 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_sum_last_frames(uint32_t count, vo
  * sums C/K channels, partial sums meet in LDS).  For parity testing of every path. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 
+/* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----
+ * Host only, no device needed.  The reference keeps this loader in its throughput harness;
+ * it lives in the library here so every binding gets it. */
+typedef struct {
+	uint32_t major;                   /* header version: 1 or 2 */
+	uint32_t data_kind;               /* BeamformerDataKind of the RF payload */
+	uint32_t compression_kind;        /* 0 = none, 1 = zstd (ZBP_DataCompressionKind) */
+	uint32_t reserved;
+	uint64_t offset, size;            /* payload inside the file; size 0: the payload is the side file <name>_NN.zst */
+} BeamformerHipZbpPayload;
+
+/* Fill `out` from the bytes of a .bp file exactly as beamformer_simple_parameters_from_zbp_file
+ * (tests/throughput.c:150-374) does: geometry, channel map, per-transmit focal data, emission;
+ * the caller still chooses the output grid, f-number, interpolation and compute stages.
+ * Every offset in the file is bounds checked.  Returns 0 on failure (see ..._zbp_last_error). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_zbp_parameters(const void *file_bytes, uint64_t file_size,
+                                                            BeamformerSimpleParameters *out,
+                                                            BeamformerHipZbpPayload *payload);
+/* Read <path> (.bp), fill `out`, and return frame `frame_number`'s RF, decompressed, in a
+ * malloc'ed buffer (*rf, *rf_size) to be released with beamformer_hip_zbp_free.  zstd payloads
+ * need libzstd.so.1 at run time. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_zbp_load(const char *path, uint32_t frame_number,
+                                                      BeamformerSimpleParameters *out, void **rf, uint64_t *rf_size);
+BEAMFORMER_LIB_EXPORT void        beamformer_hip_zbp_free(void *rf);
+BEAMFORMER_LIB_EXPORT const char *beamformer_hip_zbp_last_error(void);
+
+/* The voxel-grid transform the reference's callers build with das_transform (math.c:831-920):
+ * 1-D line, 2-D x-z plane, or 3-D box depending on how many of points[0..2] exceed 1; points
+ * are clamped to >= 1 in place.  out16 is column major. */
+BEAMFORMER_LIB_EXPORT void beamformer_hip_host_das_transform(const float min_coordinate[3], const float max_coordinate[3],
+                                                            int32_t points[3], float out16[16]);
+
 /* ---- host-side introspection (no device needed; used by tests/ to pin the host math
  * against the compiled reference and to check the planner) ---- */
 

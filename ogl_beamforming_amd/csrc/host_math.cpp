@@ -192,4 +192,45 @@ void m4_mul(const float *a, const float *b, float *out)
 	std::memcpy(out, r, sizeof(r));
 }
 
+/* das_transform (math.c:906-920) with das_output_dimension (:799-829): the grid keeps its
+ * extents but is renumbered so that a line is (n,1,1) and a plane is (a,b,1); a plane is the
+ * world x-z plane at y = 0 (das_transform_2d_xz :872-877 -> das_transform_2d_with_normal
+ * :844-870 with N = +y: U = x, V = U x N = z), min/max giving (x, z) in their first two
+ * components; a box maps the unit cube onto [min, max] (:894-904); a line runs from min to
+ * max (:831-842).  Column major. */
+void das_transform(const float mn[3], const float mx[3], int32_t points[3], float out[16])
+{
+	for (int i = 0; i < 3; i++) if (points[i] < 1) points[i] = 1;
+	const int dim = (points[0] > 1) + (points[1] > 1) + (points[2] > 1);
+	for (int i = 0; i < 16; i++) out[i] = 0.0f;
+	if (dim == 1) {
+		if (points[1] > 1) points[0] = points[1];
+		if (points[2] > 1) points[0] = points[2];
+		points[1] = points[2] = 1;
+		for (int i = 0; i < 3; i++) { out[i] = mx[i] - mn[i]; out[12 + i] = mn[i]; }
+		out[15] = 1.0f;
+	} else if (dim == 2) {
+		if (points[0] > 1) { if (points[2] > 1) points[1] = points[2]; }
+		else               { points[0] = points[2]; }
+		points[2] = 1;
+		const float U[3] = {1.0f, 0.0f, 0.0f}, N[3] = {0.0f, 1.0f, 0.0f};
+		const float V[3] = {U[1] * N[2] - U[2] * N[1], U[2] * N[0] - U[0] * N[2], U[0] * N[1] - U[1] * N[0]};
+		float lo[3], extent[3];
+		for (int i = 0; i < 3; i++) {
+			lo[i]     = U[i] * mn[0] + V[i] * mn[1];
+			extent[i] = (U[i] * mx[0] + V[i] * mx[1]) - lo[i];
+		}
+		const float ue = U[0] * extent[0] + U[1] * extent[1] + U[2] * extent[2];
+		const float ve = V[0] * extent[0] + V[1] * extent[1] + V[2] * extent[2];
+		for (int i = 0; i < 3; i++) {
+			out[i] = U[i] * ue; out[4 + i] = V[i] * ve; out[8 + i] = N[i];
+			out[12 + i] = N[i] * 0.0f + lo[i];
+		}
+		out[15] = 1.0f;
+	} else if (dim == 3) {
+		out[0] = mx[0] - mn[0]; out[5] = mx[1] - mn[1]; out[10] = mx[2] - mn[2];
+		out[12] = mn[0]; out[13] = mn[1]; out[14] = mn[2]; out[15] = 1.0f;
+	}
+}
+
 } // namespace bf

@@ -22,6 +22,7 @@ std::vector<float> baseband_chirp(float fmin, float fmax, float fs, int length, 
 float              filter_first_moment(const std::vector<float> &h, bool complex_taps, float fs);
 bool               filter_create(const BeamformerFilterParameters &fp, Filter &out);
 void               m4_mul(const float *a, const float *b, float *out);
+void               das_transform(const float mn[3], const float mx[3], int32_t points[3], float out16[16]);
 
 } // namespace bf
 #endif

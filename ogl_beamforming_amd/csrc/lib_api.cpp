@@ -430,6 +430,12 @@ uint32_t beamformer_hip_sum_last_frames(uint32_t count, void *out, uint64_t out_
 
 uint32_t beamformer_hip_set_das_path(uint32_t mode) { ctx().das_path_mode = mode; return 1; }
 
+void beamformer_hip_host_das_transform(const float min_coordinate[3], const float max_coordinate[3],
+                                       int32_t points[3], float out16[16])
+{
+	das_transform(min_coordinate, max_coordinate, points, out16);
+}
+
 uint32_t beamformer_hip_host_hadamard(uint32_t order, float *out)
 {
 	std::vector<float> h = hadamard_transpose((int)order);

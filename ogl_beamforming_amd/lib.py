@@ -105,6 +105,11 @@ def _load():
         "beamformer_hip_frame_min_max": (u32, [C.POINTER(C.c_float)]),
         "beamformer_hip_sum_last_frames": (u32, [u32, vp, u64]),
         "beamformer_hip_set_das_path": (u32, [u32]),
+        "beamformer_hip_zbp_parameters": (u32, [vp, u64, C.POINTER(P.SimpleParameters), C.POINTER(P.HipZbpPayload)]),
+        "beamformer_hip_zbp_load": (u32, [C.c_char_p, u32, C.POINTER(P.SimpleParameters), C.POINTER(vp), C.POINTER(u64)]),
+        "beamformer_hip_zbp_free": (None, [vp]),
+        "beamformer_hip_zbp_last_error": (C.c_char_p, []),
+        "beamformer_hip_host_das_transform": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(C.c_float)]),
         "beamformer_hip_host_hadamard": (u32, [u32, C.POINTER(C.c_float)]),
         "beamformer_hip_host_filter": (i32, [C.POINTER(P.FilterParameters), C.POINTER(C.c_float), u32,
                                         C.POINTER(C.c_float), C.POINTER(u32)]),
@@ -186,3 +191,18 @@ def get_last_frame(bp, shard_planes=None):
     if complex_out:
         return raw[: 2 * voxels].view(np.complex64).reshape(shape)
     return raw[:voxels].reshape(shape)
+
+
+def load_zbp(path, frame_number=0):
+    """(SimpleParameters, raw RF bytes as a numpy uint8 array) from a ZBP .bp file, through the
+    library's loader (tests/throughput.c:150-374 of the reference)."""
+    lib = library()
+    bp = P.SimpleParameters()
+    rf, size = C.c_void_p(), C.c_uint64()
+    if not lib.beamformer_hip_zbp_load(os.fsencode(path), frame_number, C.byref(bp), C.byref(rf), C.byref(size)):
+        raise ValueError(f"{path}: {lib.beamformer_hip_zbp_last_error().decode()}")
+    try:
+        data = np.ctypeslib.as_array(C.cast(rf, C.POINTER(C.c_uint8)), shape=(size.value,)).copy()
+    finally:
+        lib.beamformer_hip_zbp_free(rf)
+    return bp, data

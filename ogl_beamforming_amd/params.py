@@ -227,6 +227,11 @@ class HipPlan(C.Structure):
                 ("das_voxel_transform", C.c_float * 16)]
 
 
+class HipZbpPayload(C.Structure):
+    _fields_ = [("major", C.c_uint32), ("data_kind", C.c_uint32), ("compression_kind", C.c_uint32),
+                ("reserved", C.c_uint32), ("offset", C.c_uint64), ("size", C.c_uint64)]
+
+
 assert C.sizeof(Parameters) == 264
 assert C.sizeof(SimpleParameters) == 3728
 assert C.sizeof(FilterParameters) == 24

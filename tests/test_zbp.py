@@ -1,0 +1,208 @@
+"""ZBP acquisition files: the library's loader (csrc/zbp.cpp) against the CPU
+restatement of the reference's loader (oracle/zbp.py, tests/throughput.c:150-374) on synthetic
+files of both header versions, compressed and not; hostile files; the throughput tool."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import zbp as ozbp
+from ogl_beamforming_amd import params as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+TOOL = os.path.join(ROOT, "ogl_beamforming_amd", "ogl_beamformer_throughput")
+GOLDEN = np.load(os.path.join(HERE, "golden", "host_math.npz"))
+
+RNG = np.random.default_rng(33)
+XDC = np.eye(4, dtype=np.float32)
+XDC[3, 0] = 9.45e-3                                   # column major translation
+XDC = XDC.reshape(-1)
+
+
+def v2_files():
+    C_, A = 48, 12
+    common = dict(decode_mode=1, sampling_mode=0, dims=(A * 640, 64), samples=640, channels=C_, events=A,
+                  pitch=(0.3e-3, 0.25e-3), transform=XDC, speed_of_sound=1540.0, sampling_frequency=25e6,
+                  demodulation_frequency=5.2e6, time_offset=-1.3e-6)
+    mapping = RNG.permutation(64)[:C_].astype(np.int16)
+    sparse = np.sort(RNG.choice(128, A, replace=False)).astype(np.int16)
+    orient = RNG.choice([0x12, 0x21], A).astype(np.uint8)
+    files = {
+        "forces": ozbp.write_v2(ozbp.FORCES, 0, emission=("sine", 2.5, 5.2e6), **common),
+        "hercules_chirp_mapped": ozbp.write_v2(ozbp.HERCULES, 4, emission=("chirp", 18e-6, 2.5e6, 7.5e6),
+                                               focus=(-25e-3, 3.0, 0.5e-3, 0x21), channel_mapping=mapping, **common),
+        "uforces": ozbp.write_v2(ozbp.UFORCES, 0, emission=("sine", 2.0, 5.2e6), sparse_elements=sparse, **common),
+        "uhercules": ozbp.write_v2(ozbp.UHERCULES, 1, emission=("sine", 3.0, 5.0e6), focus=(np.inf, 0.0, 0.0, 0x12),
+                                   sparse_elements=sparse, **common),
+        "tpw": ozbp.write_v2(ozbp.RCA_TPW, 0, emission=("sine", 2.0, 5.2e6), tilting_angles=np.linspace(-12, 12, A),
+                             orientations=orient, **dict(common, sampling_mode=1)),
+        "vls": ozbp.write_v2(ozbp.RCA_VLS, 2, emission=("sine", 2.0, 5.2e6),
+                             focal_depths=np.r_[np.linspace(-40e-3, -20e-3, A // 2), np.linspace(15e-3, 30e-3, A - A // 2)],
+                             origin_offsets=np.linspace(-6e-3, 6e-3, A), orientations=orient, **common),
+    }
+    return files
+
+
+def v1_files():
+    C_, A = 32, 8
+    common = dict(decode_mode=1, dims=(A * 512, 32), samples=512, channels=C_, events=A, pitch=(0.2e-3, 0.2e-3),
+                  transform=XDC, channel_mapping=RNG.permutation(C_).astype(np.int16),
+                  steering_angles=np.linspace(-9, 9, A).astype(np.float32), focal_depths=np.full(A, np.inf, np.float32),
+                  sparse_elements=np.arange(0, 2 * A, 2, dtype=np.int16), speed_of_sound=1480.0,
+                  sampling_frequency=40e6, time_offset=2e-7)
+    return {f"v1_kind{kind}_mode{mode}": ozbp.write_v1(kind, transmit_mode=mode, **common)
+            for kind, mode in ((ozbp.FORCES, 0), (ozbp.UFORCES, 1), (ozbp.HERCULES, 2), (ozbp.UHERCULES, 3),
+                               (ozbp.RCA_TPW, 1), (ozbp.RCA_VLS, 2))}
+
+
+FILES = {**v2_files(), **v1_files()}
+
+
+def load_parameters(bflib, raw):
+    L = bflib.library()
+    bp, payload = P.SimpleParameters(), P.HipZbpPayload()
+    buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+    ok = L.beamformer_hip_zbp_parameters(buf, len(raw), C.byref(bp), C.byref(payload))
+    return ok, bp, payload, L.beamformer_hip_zbp_last_error().decode()
+
+
+@pytest.mark.parametrize("name", sorted(FILES))
+def test_loader_matches_the_reference_mapping(name, bflib):
+    raw = FILES[name]
+    ref = ozbp.parameters(raw)
+    ok, bp, payload, err = load_parameters(bflib, raw)
+    assert ok, err
+    Cn, A = ref["channel_count"], ref["acquisition_count"]
+    for field in ("sample_count", "channel_count", "acquisition_count", "sampling_mode", "acquisition_kind",
+                  "decode_mode", "data_kind"):
+        assert int(getattr(bp, field)) == ref[field], field
+    for field in ("sampling_frequency", "demodulation_frequency", "speed_of_sound", "time_offset"):
+        assert np.float32(getattr(bp, field)) == ref[field], field
+    assert list(bp.channel_mapping[:Cn]) == ref["channel_mapping"].tolist()
+    assert np.array_equal(np.array(bp.xdc_transform[:], np.float32), ref["xdc_transform"])
+    assert np.array_equal(np.array(bp.xdc_element_pitch[:], np.float32), ref["xdc_element_pitch"])
+    assert list(bp.raw_data_dimensions[:]) == ref["raw_data_dimensions"].tolist()
+    assert int(bp.contrast_mode) == ref.get("contrast_mode", 0)
+    assert int(bp.single_focus) == ref.get("single_focus", 0) and int(bp.single_orientation) == ref.get("single_orientation", 0)
+    assert int(bp.transmit_receive_orientation) == ref.get("transmit_receive_orientation", 0)
+    assert np.array_equal(np.array(bp.focal_vector[:], np.float32), ref.get("focal_vector", np.zeros(2, np.float32)))
+    assert list(bp.sparse_elements[:A]) == ref.get("sparse_elements", np.zeros(A, np.int16)).tolist()
+    assert list(bp.transmit_receive_orientations[:A]) == ref.get("transmit_receive_orientations", np.zeros(A, np.uint8)).tolist()
+    # bit-for-bit, including the VLS atan2/sqrt conversion and the TPW infinities
+    assert np.array_equal(np.array(bp.steering_angles[:A], np.float32), ref.get("steering_angles", np.zeros(A, np.float32)))
+    assert np.array_equal(np.array(bp.focal_depths[:A], np.float32), ref.get("focal_depths", np.zeros(A, np.float32)))
+    kind, *values = ref["emission"]
+    assert int(bp.emission_parameters.kind) == (0 if kind == "sine" else 1)
+    got = bp.emission_parameters.sine if kind == "sine" else bp.emission_parameters.chirp
+    fields = ("cycles", "frequency") if kind == "sine" else ("duration", "min_frequency", "max_frequency")
+    assert [np.float32(getattr(got, f)) for f in fields] == [np.float32(v) for v in values]
+    assert (int(payload.data_kind), int(payload.compression_kind), int(payload.offset), int(payload.size)) == ref["payload"]
+    # nothing else is set: stages, grid, f-number stay zero for the caller to fill
+    assert int(bp.compute_stages_count) == 0 and list(bp.output_points[:]) == [0, 0, 0, 0] and bp.f_number == 0
+
+
+def test_hostile_files_fail_cleanly(bflib):
+    raw = bytearray(FILES["vls"])
+    assert not load_parameters(bflib, raw[:15])[0]
+    assert not load_parameters(bflib, raw[:100])[0]                  # shorter than the v2 header
+    bad = bytearray(raw); bad[0] ^= 0xFF
+    assert not load_parameters(bflib, bad)[0]                        # magic
+    bad = bytearray(raw); bad[8:12] = (7).to_bytes(4, "little")
+    assert not load_parameters(bflib, bad)[0]                        # version
+    h = np.frombuffer(bytes(raw[:ozbp.V2.itemsize]), ozbp.V2, 1)[0].copy()
+    for field, value in (("acquisition_parameters_offset", len(raw) - 4), ("emission_descriptors_offset", 1 << 30),
+                         ("channel_mapping_offset", len(raw) - 2), ("channel_count", 257), ("receive_event_count", 4096),
+                         ("raw_data_kind", 9), ("acquisition_mode", 6), ("sampling_mode", 3)):
+        hh = h.copy(); hh[field] = value
+        ok, _, _, err = load_parameters(bflib, hh.tobytes() + bytes(raw[ozbp.V2.itemsize:]))
+        assert not ok and err, field
+    # array offsets inside the acquisition record pointing past the end
+    rec = int(h["acquisition_parameters_offset"])
+    bad = bytearray(raw); bad[rec: rec + 4] = (len(raw) - 8).to_bytes(4, "little")
+    assert not load_parameters(bflib, bad)[0]
+    # uncompressed payload larger than the file
+    payload = np.zeros(64, np.int16).tobytes()
+    f = ozbp.write_v2(ozbp.FORCES, 0, decode_mode=0, sampling_mode=0, dims=(640, 64), samples=640, channels=48, events=1,
+                      pitch=(1e-4, 1e-4), transform=XDC, speed_of_sound=1540.0, sampling_frequency=25e6,
+                      demodulation_frequency=5e6, time_offset=0.0, emission=("sine", 2.0, 5e6), data=payload)
+    assert not load_parameters(bflib, f)[0]
+    v1 = FILES["v1_kind0_mode0"]
+    assert not load_parameters(bflib, v1[:3000])[0]
+    bad = bytearray(v1); bad[3720:3724] = (4).to_bytes(4, "little")
+    assert not load_parameters(bflib, bad)[0]                        # transmit mode
+
+
+def acquisition_file(tmp_path, compressed, name="acq.bp"):
+    """config 1 (shrunk) written as a v2 TPW file with its RF embedded"""
+    from ogl_beamforming_amd import configs
+    acq = configs.config(1, 0.25)
+    bp = acq.bp
+    A = bp.acquisition_count
+    rf = np.ascontiguousarray(acq.rf)
+    data = rf.tobytes()
+    raw = ozbp.write_v2(ozbp.RCA_TPW, int(bp.data_kind), int(bp.decode_mode), 0,
+                        (bp.raw_data_dimensions[0], bp.raw_data_dimensions[1]), bp.sample_count, bp.channel_count, A,
+                        tuple(bp.xdc_element_pitch), np.array(bp.xdc_transform[:], np.float32), bp.speed_of_sound,
+                        bp.sampling_frequency, bp.demodulation_frequency, bp.time_offset,
+                        ("sine", 2.0, bp.demodulation_frequency), tilting_angles=[bp.focal_vector[0]] * A,
+                        orientations=[bp.transmit_receive_orientation] * A,
+                        data=ozbp.zstd_compress(data) if compressed else data, compressed=compressed)
+    path = tmp_path / name
+    path.write_bytes(raw)
+    return acq, rf, str(path)
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_load_returns_the_rf_payload(compressed, bflib, tmp_path):
+    acq, rf, path = acquisition_file(tmp_path, compressed)
+    bp, data = bflib.load_zbp(path)
+    assert data.tobytes() == rf.tobytes()
+    assert bp.channel_count == acq.bp.channel_count and bp.sample_count == acq.bp.sample_count
+    with pytest.raises(ValueError):
+        bflib.load_zbp(str(tmp_path / "missing.bp"))
+
+
+def test_v1_side_file(bflib, tmp_path):
+    rf = RNG.integers(-2000, 2000, 8 * 512 * 32).astype(np.int16)
+    (tmp_path / "study.bp").write_bytes(FILES["v1_kind4_mode1"])
+    (tmp_path / "study_03.zst").write_bytes(ozbp.zstd_compress(rf.tobytes()))
+    bp, data = bflib.load_zbp(str(tmp_path / "study.bp"), frame_number=3)
+    assert data.tobytes() == rf.tobytes() and int(bp.data_kind) == 0
+    with pytest.raises(ValueError):
+        bflib.load_zbp(str(tmp_path / "study.bp"), frame_number=4)
+
+
+def test_das_transform_matches_the_compiled_reference(bflib):
+    L = bflib.library()
+    fp = C.POINTER(C.c_float)
+    for i in range(len(GOLDEN["das_transform"])):
+        pts = (C.c_int32 * 3)(*[int(v) for v in GOLDEN["das_transform_points_in"][i]])
+        lo, hi = GOLDEN["das_transform_lo"][i].astype(np.float32).copy(), GOLDEN["das_transform_hi"][i].astype(np.float32).copy()
+        out = np.zeros(16, np.float32)
+        L.beamformer_hip_host_das_transform(lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), pts, out.ctypes.data_as(fp))
+        assert list(pts) == GOLDEN["das_transform_points_out"][i].tolist()
+        assert np.array_equal(out, GOLDEN["das_transform"][i]), i
+
+
+def test_throughput_tool_usage():
+    assert os.path.exists(TOOL), "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    r = subprocess.run([TOOL], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "parameters_file" in r.stderr
+    r = subprocess.run([TOOL, "/nonexistent.bp"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "failed to load" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compressed", [False, True])
+def test_throughput_tool_beamforms_a_file(compressed, tmp_path):
+    acq, rf, path = acquisition_file(tmp_path, compressed)
+    r = subprocess.run([TOOL, "--frames", "20", "--points", "64", "1", "96", "--lateral", "-0.005", "0.005",
+                        "--axial", "0.004", "0.012", path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("total: 20 frames"), r.stdout
+    hi = float(last.rsplit(",", 1)[1].strip(" ]"))
+    assert np.isfinite(hi) and hi > 0                                # a real image came out
