@@ -92,6 +92,14 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_frame_min_max(float out_min_max[2]
  * implementation.  out_size >= the 64-byte-rounded frame size. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_sum_last_frames(uint32_t count, void *out, uint64_t out_size);
 
+/* Display reduction of the newest frame, the step on the far side of the path: the per-voxel
+ * intensity the reference's render shader computes (sample_value, shaders/render_3d.frag.glsl:
+ * 50-73; defaults threshold 55 dB, gamma 1, dynamic range 50 dB, ui.c:880-883): |v| clamped to
+ * 10^(threshold_db/20), normalised, raised to gamma, and -- when db_cutoff > 0 (log scale) --
+ * mapped through a db_cutoff-wide dB window.  Writes one float in [0,1] per voxel (x fastest). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold_db, float gamma, float db_cutoff,
+                                                                float *out, uint64_t out_floats);
+
 /* Select the DAS implementation: 0 = automatic (general kernel, or the separable-delay
  * gather kernel when the geometry allows), 1 = always the general kernel, 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower

@@ -114,6 +114,7 @@ bool last_frame_timings(BeamformerHipFrameTimings *out);
 bool fill_stats_table(BeamformerComputeStatsTable *out);
 bool frame_min_max(float out[2]);
 bool sum_last_frames(uint32_t count, void *out, uint64_t out_size);
+bool display_last_frame(float threshold_db, float gamma, float db_cutoff, float *out, uint64_t out_floats);
 void shutdown_device();
 
 } // namespace bf

@@ -867,4 +867,20 @@ bool sum_last_frames(uint32_t count, void *out, uint64_t out_size)
 	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 }
 
+/* Display intensities of the newest frame (render_3d.frag.glsl:50-73), one float per voxel. */
+bool display_last_frame(float threshold_db, float gamma, float db_cutoff, float *out, uint64_t out_floats)
+{
+	Context &c = g_context;
+	if (!c.device_ready || c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	const FrameRecord &f = c.frames[(c.frame_counter - 1) % c.frames.size()];
+	uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
+	if (out_floats < voxels) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
+	if (!c.sum_scratch.ensure(voxels * sizeof(float))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	bool ok = HIP_OK(bf_launch_display((const char *)c.ring.ptr + f.offset, voxels, f.data_kind == BeamformerDataKind_Float32Complex,
+	                                   threshold_db, gamma, db_cutoff, (float *)c.sum_scratch.ptr, c.stream));
+	ok &= HIP_OK(hipMemcpyAsync(out, c.sum_scratch.ptr, voxels * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+}
+
 } // namespace bf

@@ -428,6 +428,13 @@ uint32_t beamformer_hip_sum_last_frames(uint32_t count, void *out, uint64_t out_
 	return sum_last_frames(count, out, out_size);
 }
 
+uint32_t beamformer_hip_display_last_frame(float threshold_db, float gamma, float db_cutoff, float *out, uint64_t out_floats)
+{
+	if (!out) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (!ensure_device()) return 0;
+	return display_last_frame(threshold_db, gamma, db_cutoff, out, out_floats);
+}
+
 uint32_t beamformer_hip_set_das_path(uint32_t mode) { ctx().das_path_mode = mode; return 1; }
 
 void beamformer_hip_host_das_transform(const float min_coordinate[3], const float max_coordinate[3],

@@ -368,6 +368,41 @@ extern "C" hipError_t bf_launch_sum(void *out, const void *in, float prescale, u
 	return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------ display reduction */
+
+/* sample_value of shaders/render_3d.frag.glsl:50-73, the step on the far side of the path:
+ * magnitude -> clamp to 10^(threshold/20) -> normalise -> gamma -> optional dB window
+ * 1 - clamp(20 log10 v, -cutoff, 0) / -cutoff.  One float in [0, 1] per voxel. */
+__global__ __launch_bounds__(256) void display_kernel(const float *frame, uint64_t voxels, int cplx, float threshold_value,
+                                                      float gamma, float db_cutoff, float *out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < voxels; i += (uint64_t)gridDim.x * 256) {
+		float v;
+		if (cplx) { f32x2 c = ((const f32x2 *)frame)[i]; v = __builtin_sqrtf(c.x * c.x + c.y * c.y); }
+		else      { v = __builtin_fabsf(frame[i]); }
+		v = fminf(fmaxf(v, 0.0f), threshold_value);
+		v = v / threshold_value;
+		v = powf(v, gamma);
+		if (db_cutoff > 0) {
+			v = 20.0f * logf(v) / logf(10.0f);
+			v = fminf(fmaxf(v, -db_cutoff), 0.0f) / -db_cutoff;
+			v = 1.0f - v;
+		}
+		out[i] = v;
+	}
+}
+
+extern "C" hipError_t bf_launch_display(const void *frame, uint64_t voxels, int complex_data, float threshold_db,
+                                        float gamma, float db_cutoff, float *out, hipStream_t s)
+{
+	uint64_t blocks = (voxels + 255) / 256;
+	if (blocks > 256 * 16) blocks = 256 * 16;
+	if (!blocks) return hipSuccess;
+	hipLaunchKernelGGL(display_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, (const float *)frame, voxels, complex_data,
+	                   powf(10.0f, threshold_db / 20.0f), gamma, db_cutoff, out);
+	return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------ min / max */
 
 /* Build-defined reduction (the reference's shaders/min_max.glsl is never dispatched,

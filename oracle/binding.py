@@ -87,6 +87,8 @@ def library():
         lib.oracle_das_transform_3d.argtypes = [fp, fp, fp]
         lib.oracle_sum.argtypes = [fp, fp, C.c_float, C.c_uint64]
         lib.oracle_sum.restype = None
+        lib.oracle_display.argtypes = [fp, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_float, fp]
+        lib.oracle_display.restype = None
         lib.oracle_min_max.argtypes = [fp, C.c_uint64, C.c_int, fp]
         lib.oracle_min_max.restype = None
         lib.oracle_filter_create.restype = C.c_int
@@ -171,4 +173,15 @@ def min_max(frame):
     out = np.zeros(2, np.float32)
     fp = C.POINTER(C.c_float)
     lib.oracle_min_max(frame.ctypes.data_as(fp), frame.size, int(np.iscomplexobj(frame)), out.ctypes.data_as(fp))
+    return out
+
+
+def display(frame, threshold_db=55.0, gamma=1.0, db_cutoff=0.0):
+    """render_3d.frag.glsl:50-73 on a frame: float32 intensities in [0, 1]"""
+    lib = library()
+    frame = np.ascontiguousarray(frame)
+    out = np.zeros(frame.shape, np.float32)
+    fp = C.POINTER(C.c_float)
+    lib.oracle_display(frame.ctypes.data_as(fp), frame.size, int(np.iscomplexobj(frame)), threshold_db, gamma, db_cutoff,
+                       out.ctypes.data_as(fp))
     return out

@@ -112,6 +112,10 @@ void oracle_coherency_weighting(float *coherent, const float *incoherent, uint32
 /* sum.glsl:7-12, one pass: out += prescale * in over `floats` components */
 void oracle_sum(float *out, const float *in, float prescale, uint64_t floats);
 
+/* sample_value of render_3d.frag.glsl:50-73 on one frame: out[i] in [0,1] */
+void oracle_display(const float *frame, uint64_t voxels, int complex_data, float threshold_db, float gamma,
+                    float db_cutoff, float *out);
+
 /* build-defined reduction (shaders/min_max.glsl is dead code in the reference):
  * min and max over voxels of |v| (complex) or v (real).  PARITY UNPINNED. */
 void oracle_min_max(const float *frame, uint64_t voxels, int complex_data, float *out2);

@@ -259,6 +259,25 @@ void oracle_sum(float *out, const float *in, float prescale, uint64_t floats)
 	for (uint64_t i = 0; i < floats; i++) out[i] = out[i] + prescale * in[i];
 }
 
+void oracle_display(const float *frame, uint64_t voxels, int complex_data, float threshold_db, float gamma,
+                    float db_cutoff, float *out)
+{
+	float threshold_val = powf(10.0f, threshold_db / 20.0f);
+	for (uint64_t i = 0; i < voxels; i++) {
+		float result = complex_data ? sqrtf(frame[2 * i] * frame[2 * i] + frame[2 * i + 1] * frame[2 * i + 1])
+		                            : fabsf(frame[i]);
+		result = fminf(fmaxf(result, 0.0f), threshold_val);
+		result = result / threshold_val;
+		result = powf(result, gamma);
+		if (db_cutoff > 0) {
+			result = 20 * logf(result) / logf(10);
+			result = fminf(fmaxf(result, -db_cutoff), 0) / -db_cutoff;
+			result = 1 - result;
+		}
+		out[i] = result;
+	}
+}
+
 void oracle_min_max(const float *frame, uint64_t voxels, int complex_data, float *out2)
 {
 	float lo = INFINITY, hi = -INFINITY;

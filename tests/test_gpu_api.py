@@ -194,3 +194,24 @@ def test_pipelined_host_pushes_keep_their_own_data(bflib):
             got = got.view(base.dtype).reshape(base.shape)
             scale = 2 if (5 + k) & 1 else 1
             assert np.array_equal(got, base * scale, equal_nan=True), (name, k)
+
+
+def test_display_reduction_matches_the_render_shader_maths(bflib, oracle):
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    for name in ("config2_small", "hercules_real"):
+        acq = cases.make(name)
+        push(L, bflib, acq)
+        frame = bflib.get_last_frame(acq.bp)
+        peak_db = 20 * np.log10(np.nanmax(np.abs(frame)))
+        for threshold, gamma, cutoff in ((peak_db - 6, 1.0, 0.0), (peak_db, 0.5, 0.0), (peak_db - 3, 1.0, 50.0), (55.0, 1.0, 50.0)):
+            ref = oracle.display(frame, threshold, gamma, cutoff)
+            out = np.zeros(frame.size, np.float32)
+            assert L.beamformer_hip_display_last_frame(threshold, gamma, cutoff, out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+            got = out.reshape(frame.shape)
+            ok = ~np.isnan(ref)
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            assert got[ok].min() >= 0 and got[ok].max() <= 1
+            assert np.abs(got[ok] - ref[ok]).max() <= 2e-6, (name, threshold, gamma, cutoff)   # pow/log differ by ulps
+        assert not L.beamformer_hip_display_last_frame(55.0, 1.0, 0.0, out.ctypes.data_as(C.POINTER(C.c_float)), frame.size - 1)
+        assert bflib.last_error()[0] == E.ExportSpaceOverflow
