@@ -179,13 +179,13 @@ def main():
                             f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": f"{world} z-slab(s), RF broadcast via RCCL" if distributed else "none",
-                "das_path": ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel"][das_path],
+                "das_path": PATH_NAMES[das_path],
                 "stage_ms": stage_ms,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK, "traffic": measured_traffic(args, world, das_path),
-                "kernel": ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel"][das_path], "kernel_ms": das_s * 1e3,
+                "kernel": KERNEL_NAMES[das_path], "kernel_ms": das_s * 1e3,
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
@@ -201,6 +201,10 @@ def main():
         dist.destroy_process_group()
 
 
+PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel"]
+KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel"]
+
+
 def measured_traffic(args, world, das_path):
     """HBM bytes per DAS launch from the committed rocprofv3 PMC passes of this same command
     (profiles/das_traffic.json); None when this run's configuration was not profiled."""
@@ -209,7 +213,7 @@ def measured_traffic(args, world, das_path):
     try:
         with open(os.path.join(ROOT, "profiles", "das_traffic.json")) as f:
             table = json.load(f)["config4_scale1_n1"]
-        return table[["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel"][das_path]]["hbm_bytes_per_launch"]
+        return table[KERNEL_NAMES[das_path]]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 

@@ -71,7 +71,7 @@ typedef struct {
 	uint64_t das_voxels;
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
-	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel */
+	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
@@ -100,8 +100,10 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_sum_last_frames(uint32_t count, vo
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold_db, float gamma, float db_cutoff,
                                                                 float *out, uint64_t out_floats);
 
-/* Select the DAS implementation: 0 = automatic (general kernel, or the separable-delay
- * gather kernel when the geometry allows), 1 = always the general kernel, 3 = prefer the
+/* Select the DAS implementation: 0 = automatic (the separable-delay gather kernel when the
+ * geometry allows, else the per-voxel factored kernel for RCA-family and FORCES frames with
+ * three or more transmits, else the general kernel), 1 = always the general kernel, 4 = the
+ * factored kernel wherever it applies (also ahead of the gather kernel), 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower
  * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
  * Adding 0x10 keeps the general kernel at one thread per voxel for frames it would otherwise

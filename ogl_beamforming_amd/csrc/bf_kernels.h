@@ -54,6 +54,8 @@ typedef struct {
 	uint32_t tile_shift[3];           /* log2 of the block's voxel tile extent per axis (256 voxels, or 64 with a channel split) */
 	uint32_t split_shift;             /* log2 K: K waves of a block share 64 voxels, each summing C/K channels */
 	uint32_t blocks[3];               /* blocks per axis */
+	uint32_t zero_offset;             /* factored kernel: byte offset (from rf) of >= 32 zero bytes the host keeps
+	                                     behind the DAS input, the gather target of out-of-range lanes */
 } BfDasArgs;
 
 /* tile geometry of the separable-delay fast path (das_separable.hip) */
@@ -120,6 +122,7 @@ hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q,
 hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
  * 2*1024 floats */
+hipError_t bf_launch_das_factored(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_sum(void *out, const void *in, float prescale, uint64_t bytes, hipStream_t s);
 hipError_t bf_launch_display(const void *frame, uint64_t voxels, int complex_data, float threshold_db,
                              float gamma, float db_cutoff, float *out, hipStream_t s);

@@ -1,0 +1,354 @@
+/* das_factored.hip -- delay-and-sum for gfx950 (MI355X), per-voxel factored path.
+ *
+ * Same result as das.hip's general kernel (shaders/das.glsl RCA :204-231, FORCES :288-321)
+ * for the families whose sample index is a SUM of a receive term and a transmit term for
+ * every voxel:
+ *
+ *     RCA / TPW / VLS / Flash   index = [ (d_tx(a) / c + t0) fs ] + [ d_rx(ch) / c * fs ]
+ *     FORCES / UFORCES          index = [ d_tx(a) fs / c ]        + [ (d_rx(ch) / c + t0) fs ]
+ *
+ * The general kernel spends ~45 VALU slots per (voxel, channel, transmit) triple, most of it
+ * on work that depends on only one of the two loop variables: a square root and the cos^2
+ * apodization per channel, and -- for IQ data -- the sin/cos of the demodulation phase, which
+ * is e^{j phi(T + R)} = e^{j phi(T)} e^{j phi(R)}.  Here a thread (one voxel) keeps the receive
+ * factors of CH channels in registers {R index, apod e^{j phi(R)}, apod}, walks the transmits
+ * once per chunk computing {T index, e^{j phi(T)}} per transmit, and for each of the CH
+ * triples of a transmit does only: one add, the interpolation, a complex multiply-accumulate
+ * into that channel's partial sum and |sample| for coherency weighting.  The receive factor is
+ * applied once per channel when the chunk is folded into the voxel's accumulators.
+ * No LDS tables and no constraint on how the voxel grid lies relative to the array, unlike
+ * das_separable.hip: this is the path of 2-D plane-wave compounding (tx and rx on the same
+ * axis), tilted volumes and FORCES.  HERCULES (joint square root) and READI stay on das.hip.
+ *
+ * The CH gathers of a transmit are independent and issued back to back (tap_setup -> tap_load
+ * x CH -> tap_finish, das_common.h); a chunk none of whose channels passes the f-number test
+ * for any lane of the wave is skipped.  Summation order differs from the shader's (per channel
+ * over transmits, then over channels): results agree to float rounding, tests state the
+ * tolerance.  Channel split for small frames as in das.hip.
+ */
+#include "das_common.h"
+
+#ifndef BF_FACTORED_CHUNK
+#define BF_FACTORED_CHUNK 4
+#endif
+
+namespace {
+
+template <bool CPLX, bool CW>
+struct ChannelFactor {
+	float index;           /* receive part of the sample index; -1e9 when the channel fails the f-number test */
+	float re, im;          /* apod * e^{j phi(R)} (CPLX) -- re alone holds apod for real data */
+	float apod;            /* for the incoherent sum */
+};
+
+/* das.glsl:187-202 with the per-transmit constants precomputed (same as das.hip) */
+__device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx, float wy, float wz)
+{
+	float result = 0.f;
+	if (!(t.flags & BF_TX_NONE)) {
+		float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+		if (t.flags & BF_TX_PLANE) {
+			result = px * t.sin_a + wz * t.cos_a;
+		} else {
+			float dx = px - t.focus_x, dz = wz - t.focus_z;
+			result = hw_sqrt(dx * dx + dz * dz);
+		}
+	}
+	return result;
+}
+
+template <int FAMILY, int INTERP, bool CPLX, bool CW>
+__global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
+{
+	constexpr int      CH = BF_FACTORED_CHUNK;
+	constexpr uint32_t ES = CPLX ? 8 : 4;
+
+	/* blockIdx -> tile and thread -> voxel exactly as das.hip */
+	uint32_t total = p.blocks[0] * p.blocks[1] * p.blocks[2];
+	uint32_t bid   = blockIdx.x;
+	uint32_t per   = (total + 7u) / 8u;
+	uint32_t tile  = (bid & 7u) * per + (bid >> 3);
+	if (tile >= total) return;
+	uint32_t bx = tile % p.blocks[0];
+	uint32_t by = (tile / p.blocks[0]) % p.blocks[1];
+	uint32_t bz = tile / (p.blocks[0] * p.blocks[1]);
+
+	uint32_t tid = threadIdx.x;
+	uint32_t lx  = tid & ((1u << p.tile_shift[0]) - 1u);
+	uint32_t ly  = (tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u);
+	uint32_t lz  = (tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u);
+	uint32_t split = tid >> (p.tile_shift[0] + p.tile_shift[1] + p.tile_shift[2]);
+	uint32_t x = (bx << p.tile_shift[0]) + lx;
+	uint32_t y = (by << p.tile_shift[1]) + ly;
+	uint32_t zl = (bz << p.tile_shift[2]) + lz;
+	bool inside = x < p.size[0] && y < p.size[1] && zl < p.z_count;
+
+	sample_t<CPLX> coherent = zero_sample<CPLX>();
+	float          incoherent = 0.f;
+
+	if (inside) {
+		uint32_t z = p.z_first + zl;
+		float px = (float)x / fmaxf(1.0f, (float)p.size[0] - 1.0f);       /* das.glsl:374-376 */
+		float py = (float)y / fmaxf(1.0f, (float)p.size[1] - 1.0f);
+		float pz = (float)z / fmaxf(1.0f, (float)p.size[2] - 1.0f);
+		float wx, wy, wz;
+		m4_point(p.voxel_transform, px, py, pz, wx, wy, wz);
+
+		const char *rf = (const char *)p.rf;
+		const int   S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+		const int   last = S - 1;
+		const float Sf = (float)S;
+		const float fs_over_c = p.sampling_frequency * p.inv_speed_of_sound;
+		const float turns_per_sample = p.demodulation_frequency * p.inv_sampling_frequency;
+
+		/* transducer-space point; FORCES voxels arrive already transformed (beamformer_core.c:913-915) */
+		float xx, xy, xz;
+		if constexpr (FAMILY == BF_DAS_RCA) m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+		else { xx = wx; xy = wy; xz = wz; }
+		const float zz = xz * xz;
+
+		/* receive geometry: one orientation for all transmits (the host checks) */
+		float lateral, pitch, f_over_z;
+		if constexpr (FAMILY == BF_DAS_RCA) {
+			const bool rx_rows = (p.transmits[0].flags & BF_RX_ROWS) != 0;
+			lateral  = rx_rows ? xy : xx;
+			pitch    = rx_rows ? p.pitch[1] : p.pitch[0];
+			f_over_z = p.f_number * hw_rcp(__builtin_fabsf(xz));
+		} else {
+			lateral  = xx;
+			pitch    = p.pitch[0];
+			f_over_z = p.f_number * hw_rcp(xz);
+		}
+		/* FORCES transmit geometry (das.glsl:292-296) */
+		const int   first_transmit = FAMILY == BF_DAS_RCA ? 0 : (p.sparse != 0);
+		float transmit_yz_squared = 0.f;
+		if constexpr (FAMILY != BF_DAS_RCA) {
+			float dy = xy - p.pitch[1] * (float)C * 0.5f;
+			transmit_yz_squared = dy * dy + zz;
+		}
+
+		const int per_split = (C + (1 << p.split_shift) - 1) >> p.split_shift;
+		const int ch_begin  = (int)split * per_split;
+		const int ch_end    = ch_begin + per_split < C ? ch_begin + per_split : C;
+
+		for (int c0 = ch_begin; c0 < ch_end; c0 += CH) {
+			ChannelFactor<CPLX, CW> R[CH];
+			bool any = false;
+			#pragma unroll
+			for (int k = 0; k < CH; k++) {
+				int   channel = c0 + k;
+				float dx      = lateral - (float)channel * pitch;
+				float a_arg   = __builtin_fabsf(dx * f_over_z);
+				bool  pass    = a_arg < 0.5f && channel < ch_end;
+				float dist    = hw_sqrt(dx * dx + zz);
+				/* RCA: the time offset rides with the transmit term; FORCES: with the receive term
+				 * (sample_index, das.glsl:126-130) */
+				float index   = FAMILY == BF_DAS_RCA ? dist * fs_over_c
+				                                     : (dist * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+				float apod    = pass ? apodize(a_arg) : 0.f;
+				R[k].index = pass ? index : -1.0e9f;
+				R[k].apod  = apod;
+				if constexpr (CPLX) {
+					float turns = hw_fract(turns_per_sample * index);
+					R[k].re = apod * hw_cos_turns(turns);
+					R[k].im = apod * hw_sin_turns(turns);
+				} else {
+					R[k].re = apod; R[k].im = 0.f;
+				}
+				any |= pass;
+			}
+			if (!__builtin_amdgcn_ballot_w64(any)) continue;          /* wave-uniform */
+
+			sample_t<CPLX> part[CH];
+			float          part_abs[CH];
+			#pragma unroll
+			for (int k = 0; k < CH; k++) { part[k] = zero_sample<CPLX>(); part_abs[k] = 0.f; }
+			/* IQ data, linear / cubic: the rotate-accumulate runs as two packed FMAs per triple on
+			 *   acc1 += s.re (cos, sin)(T),  acc2 += s.im (cos, sin)(T),
+			 * combined as (acc1.x - acc2.y, acc1.y + acc2.x) when the chunk is folded */
+			constexpr bool PACKED = CPLX && INTERP != BF_INTERP_NEAREST;
+			f32x2 acc1[CH], acc2[CH];
+			#pragma unroll
+			for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; }
+
+			for (int a = first_transmit; a < A; a++) {
+				float t_index;
+				if constexpr (FAMILY == BF_DAS_RCA) {
+					const BfTransmit t = p.transmits[a];
+					t_index = (transmit_distance(t, wx, wy, wz) * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+				} else {
+					float tx_channel = p.sparse ? (float)p.sparse_elements[a - first_transmit] : (float)a;
+					float tdx        = xx - p.pitch[0] * tx_channel;
+					t_index = hw_sqrt(transmit_yz_squared + tdx * tdx) * fs_over_c;
+				}
+				float tc = 1.f, ts = 0.f;
+				if constexpr (CPLX) {
+					float turns = hw_fract(turns_per_sample * t_index);
+					tc = hw_cos_turns(turns); ts = hw_sin_turns(turns);
+				}
+
+				const uint32_t row0 = ((uint32_t)c0 * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES;
+				const uint32_t row_step = (uint32_t)A * (uint32_t)S * ES;
+				if constexpr (PACKED) {
+					/* Written out so that every step is one instruction: index = T + R;
+					 * frac = v_fract; k = v_cvt_flr_i32; offset = in range ? row + 8k : zero block
+					 * (lanes outside the row, channels outside the aperture and the padding of a
+					 * ragged chunk all gather zeros), then the interpolation on packed pairs. */
+					const f32x2 cs = {tc, ts};
+					float frac[CH]; uint32_t off[CH];
+					#pragma unroll
+					for (int k = 0; k < CH; k++) {
+						float index = t_index + R[k].index;
+						frac[k] = hw_fract(index);
+						if constexpr (INTERP == BF_INTERP_LINEAR) {
+							uint32_t ki = (uint32_t)cvt_floor_i32(index);                 /* valid: 0 <= index < S-1 */
+							off[k] = ki < (uint32_t)(S - 1) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+						} else {
+							uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
+							off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+						}
+					}
+					if constexpr (INTERP == BF_INTERP_LINEAR) {
+						f32x4 d[CH];
+						#pragma unroll
+						for (int k = 0; k < CH; k++) d[k] = gather<f32x4_a8>(rf, off[k]);
+						#pragma unroll
+						for (int k = 0; k < CH; k++) {
+							f32x2 s0 = {d[k].x, d[k].y}, s1 = {d[k].z, d[k].w};
+							f32x2 sv = s0 + frac[k] * (s1 - s0);
+							acc1[k] += sv.x * cs;
+							acc2[k] += sv.y * cs;
+							if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
+						}
+					} else {
+						f32x4 d0[CH], d1[CH];
+						#pragma unroll
+						for (int k = 0; k < CH; k++) { d0[k] = gather<f32x4_a8>(rf, off[k]); d1[k] = gather<f32x4_a8>(rf, off[k] + 16); }
+						#pragma unroll
+						for (int k = 0; k < CH; k++) {
+							/* Catmull-Rom Hermite (das.glsl:67-97) as a cubic in t by Horner:
+							 * p = s1 + t (T1 + t (c2 + t c3)),  T1 = (s2-s0)/2, T2 = (s3-s1)/2,
+							 * c3 = T1 + T2 - 2 (s2-s1),  c2 = (s2-s1) - T1 - c3 */
+							f32x2 s0 = {d0[k].x, d0[k].y}, s1 = {d0[k].z, d0[k].w}, s2 = {d1[k].x, d1[k].y}, s3 = {d1[k].z, d1[k].w};
+							f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
+							f32x2 c3 = (T1 + T2) - 2.0f * D;
+							f32x2 c2 = (D - T1) - c3;
+							float t  = frac[k];
+							f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
+							acc1[k] += sv.x * cs;
+							acc2[k] += sv.y * cs;
+							if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
+						}
+					}
+					continue;
+				}
+				Tap<INTERP>           tap[CH];
+				TapData<INTERP, CPLX> data[CH];
+				#pragma unroll
+				for (int k = 0; k < CH; k++) tap[k] = tap_setup<INTERP, CPLX>(t_index + R[k].index, Sf, last);
+				#pragma unroll
+				for (int k = 0; k < CH; k++) {
+					/* rows past the last channel of a ragged chunk are not read: their weights are
+					 * zero, so any legal row will do */
+					uint32_t row = c0 + k < C ? row0 + (uint32_t)k * row_step : row0;
+					data[k] = tap_load<INTERP, CPLX>(rf, row + tap[k].off);
+				}
+				#pragma unroll
+				for (int k = 0; k < CH; k++) {
+					sample_t<CPLX> s = tap_finish<INTERP, CPLX>(tap[k], data[k]);
+					if constexpr (CPLX) {
+						part[k].x += tc * s.x - ts * s.y;                /* rotate_iq, das.glsl:54-61 */
+						part[k].y += ts * s.x + tc * s.y;
+						if constexpr (CW) part_abs[k] += hw_sqrt(s.x * s.x + s.y * s.y);
+					} else {
+						part[k] += s;
+						if constexpr (CW) part_abs[k] += __builtin_fabsf(s);
+					}
+				}
+			}
+
+			#pragma unroll
+			for (int k = 0; k < CH; k++) {
+				if constexpr (PACKED) part[k] = f32x2{acc1[k].x - acc2[k].y, acc1[k].y + acc2[k].x};
+				if constexpr (CPLX) {
+					coherent.x += R[k].re * part[k].x - R[k].im * part[k].y;
+					coherent.y += R[k].im * part[k].x + R[k].re * part[k].y;
+				} else {
+					coherent += R[k].re * part[k];
+				}
+				if constexpr (CW) incoherent += R[k].apod * part_abs[k];
+			}
+		}
+	}
+
+	if (p.split_shift) {
+		/* partial sums of waves 1..K-1 go through LDS; wave 0 adds them in split order */
+		extern __shared__ float partial[];                         /* [K-1][3][64] */
+		const uint32_t lane = tid & 63u;
+		if (split) {
+			float *row = partial + (split - 1) * 192 + lane;
+			if constexpr (CPLX) { row[0] = coherent.x; row[64] = coherent.y; }
+			else                { row[0] = coherent; }
+			if constexpr (CW) row[128] = incoherent;
+		}
+		__syncthreads();
+		if (split) return;
+		for (uint32_t k = 1; k < (1u << p.split_shift); k++) {
+			const float *row = partial + (k - 1) * 192 + lane;
+			if constexpr (CPLX) { coherent.x += row[0]; coherent.y += row[64]; }
+			else                { coherent += row[0]; }
+			if constexpr (CW) incoherent += row[128];
+		}
+	}
+
+	if (inside) {
+		uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
+		sample_t<CPLX> v = coherent;
+		if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
+		reinterpret_cast<sample_t<CPLX> *>(p.out)[out_index] = v;
+	}
+}
+
+template <int FAMILY, int INTERP, bool CPLX, bool CW>
+hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
+{
+	uint32_t total   = a->blocks[0] * a->blocks[1] * a->blocks[2];
+	uint32_t grid    = ((total + 7u) / 8u) * 8u;
+	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
+	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
+	hipLaunchKernelGGL((das_factored_kernel<FAMILY, INTERP, CPLX, CW>), dim3(grid), dim3(threads), lds, s, *a);
+	return hipGetLastError();
+}
+
+template <int FAMILY, int INTERP>
+hipError_t launch_kind(const BfDasArgs *a, hipStream_t s)
+{
+	if (a->complex_data) return a->coherency_weighting ? launch_one<FAMILY, INTERP, true,  true >(a, s)
+	                                                   : launch_one<FAMILY, INTERP, true,  false>(a, s);
+	else                 return a->coherency_weighting ? launch_one<FAMILY, INTERP, false, true >(a, s)
+	                                                   : launch_one<FAMILY, INTERP, false, false>(a, s);
+}
+
+template <int FAMILY>
+hipError_t launch_interp(const BfDasArgs *a, hipStream_t s)
+{
+	switch (a->interpolation) {
+	case BF_INTERP_NEAREST: return launch_kind<FAMILY, BF_INTERP_NEAREST>(a, s);
+	case BF_INTERP_LINEAR:  return launch_kind<FAMILY, BF_INTERP_LINEAR >(a, s);
+	case BF_INTERP_CUBIC:   return launch_kind<FAMILY, BF_INTERP_CUBIC  >(a, s);
+	}
+	return hipErrorInvalidValue;
+}
+
+} // namespace
+
+/* RCA-family and FORCES/UFORCES frames only; the caller has checked that all transmits share
+ * one receive orientation (RCA). */
+extern "C" hipError_t bf_launch_das_factored(const BfDasArgs *a, hipStream_t s)
+{
+	switch (a->family) {
+	case BF_DAS_RCA:    return launch_interp<BF_DAS_RCA>(a, s);
+	case BF_DAS_FORCES: return launch_interp<BF_DAS_FORCES>(a, s);
+	}
+	return hipErrorInvalidValue;
+}

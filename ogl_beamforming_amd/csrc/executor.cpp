@@ -415,6 +415,22 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 	return true;
 }
 
+/* Can the per-voxel factored kernel (das_factored.hip) take this frame?  It needs the sample
+ * index to be a receive term plus a transmit term: RCA-family frames whose transmits all share
+ * one receive orientation, and FORCES/UFORCES.  With fewer than three transmits per channel
+ * chunk the receive factors are not amortised and the general kernel is as fast. */
+static bool factored_applies(const BfDasArgs &a, const std::vector<BfTransmit> &tx, uint32_t mode)
+{
+	if (mode == 1) return false;
+	int transmits = a.acquisition_count - (a.family == BF_DAS_FORCES && a.sparse ? 1 : 0);
+	if (transmits < 3 && mode != 4) return false;
+	if (a.family == BF_DAS_FORCES) return true;
+	if (a.family != BF_DAS_RCA || tx.empty()) return false;
+	for (const BfTransmit &t : tx)
+		if ((t.flags & BF_RX_ROWS) != (tx[0].flags & BF_RX_ROWS)) return false;
+	return true;
+}
+
 static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
 {
 	return HIP_OK(hipEventRecord(t.events[index], s));
@@ -566,7 +582,7 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
 			} else {
 				BfSeparableArgs sep{};
-				if ((c.das_path_mode & 0xF) != 1 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+				if ((c.das_path_mode & 0xF) != 1 && (c.das_path_mode & 0xF) != 4 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
 					 * allocated with that much slack): the gather target of out-of-range lanes */
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
@@ -579,6 +595,12 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
 						das_path = 1;
 					}
+				} else if (factored_applies(a, ps->transmit_table, c.das_path_mode & 0xF)) {
+					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
+					a.zero_offset = (uint32_t)used;             /* as for the gather kernel above */
+					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
+					ok &= HIP_OK(bf_launch_das_factored(&a, s));
+					das_path = 3;
 				} else {
 					ok &= HIP_OK(bf_launch_das(&a, s));
 				}

@@ -48,8 +48,24 @@ SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_rea
 STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged"}
 
 
-def expected_path(name):
-    return 1 if name in SEPARABLE else 0
+def factored_applies(bp):
+    """host rule of executor.cpp: the sample index splits into a receive and a transmit term"""
+    kind = P.AcquisitionKind(bp.acquisition_kind)
+    if kind in (P.AcquisitionKind.FORCES, P.AcquisitionKind.UFORCES):
+        return bp.readi_group_count <= 1
+    if kind in (P.AcquisitionKind.RCA_TPW, P.AcquisitionKind.RCA_VLS, P.AcquisitionKind.Flash):
+        if bp.single_orientation:
+            return True
+        rx = {int(o) & 0xF for o in bp.transmit_receive_orientations[: bp.acquisition_count]}
+        return len(rx) == 1
+    return False
+
+
+def expected_path(name, bp):
+    if name in SEPARABLE:
+        return 1
+    transmits = bp.acquisition_count - (1 if P.AcquisitionKind(bp.acquisition_kind) == P.AcquisitionKind.UFORCES else 0)
+    return 3 if factored_applies(bp) and transmits >= 3 else 0
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))
@@ -59,7 +75,7 @@ def test_frame_parity(name, bflib, oracle):
     ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
     bflib.library().beamformer_hip_set_das_path(0)
     gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-    assert last_das_path(bflib) == expected_path(name)
+    assert last_das_path(bflib) == expected_path(name, acq.bp)
     compare(gpu, ref, acq)
 
 
@@ -105,6 +121,27 @@ def test_general_kernel_without_channel_split(name, bflib, oracle):
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert last_das_path(bflib) == 0
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq)
+
+
+FACTORED = sorted(n for n in cases.CASES if factored_applies(cases.make(n).bp))
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("name", FACTORED)
+def test_factored_kernel(name, split, bflib, oracle):
+    """das_factored.hip wherever the index factorises -- also on the geometries the gather
+    kernel would take and with fewer transmits than the automatic rule asks for -- with the
+    channel split these small frames get by default and without it"""
+    acq = cases.make(name)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    lib.beamformer_hip_set_das_path(0x04 if split else 0x14)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == 3
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq)
