@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 force the general DAS kernel, 3 prefer the LDS-staged kernel")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run the N-rank code path with every rank on GPU 0 and gloo for the "
                          "collectives (RCCL refuses two ranks per device); the value is NOT the metric")

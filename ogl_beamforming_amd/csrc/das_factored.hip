@@ -28,8 +28,11 @@
  */
 #include "das_common.h"
 
+/* channels per register-resident chunk.  Measured on MI355X (config 4 geometry, 64 planes):
+ * 2 -> 172 ms, 4 -> 160, 6 -> 154, 8 -> 154 with spills; cubic holds twice the gather data
+ * per triple and is best at 4 (108 VGPRs). */
 #ifndef BF_FACTORED_CHUNK
-#define BF_FACTORED_CHUNK 4
+#define BF_FACTORED_CHUNK(interp) ((interp) == BF_INTERP_LINEAR ? 6 : 4)
 #endif
 
 namespace {
@@ -60,7 +63,7 @@ __device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx
 template <int FAMILY, int INTERP, bool CPLX, bool CW>
 __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 {
-	constexpr int      CH = BF_FACTORED_CHUNK;
+	constexpr int      CH = BF_FACTORED_CHUNK(INTERP);
 	constexpr uint32_t ES = CPLX ? 8 : 4;
 
 	/* blockIdx -> tile and thread -> voxel exactly as das.hip */
