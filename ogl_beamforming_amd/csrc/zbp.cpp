@@ -16,6 +16,7 @@
 #include "bf_kernels.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,10 +78,12 @@ bool fail(const char *what) { g_error = what; return false; }
 
 struct Bytes {
 	const uint8_t *data; uint64_t size;
-	/* pointer to `count` records of `record` bytes at `offset`, or null when outside the file */
+	/* pointer to `count` records of `record` bytes at `offset`, or null when outside the file
+	 * or not aligned for the record (the format aligns offsets to 4, zemp_bp.h:24) */
 	const void *at(int64_t offset, uint64_t record, uint64_t count) const
 	{
 		if (offset < 0 || (uint64_t)offset > size) return nullptr;
+		if ((record >= 4 && offset % 4) || (record == 2 && offset % 2)) return nullptr;
 		if (record && count > (size - (uint64_t)offset) / record) return nullptr;
 		return data + offset;
 	}
