@@ -179,3 +179,45 @@ def test_planner_agrees_with_oracle(name, L, oracle):
     assert ours.das_samples == ref.input_sample_count
     assert ours.das_time_offset == pytest.approx(ref.das_time_offset, rel=1e-6, abs=1e-12)
     assert np.allclose(np.array(ours.das_voxel_transform[:]), np.array(ref.das_voxel_transform[:]), rtol=1e-6, atol=1e-12)
+
+
+def test_planner_agrees_with_oracle_on_random_pipelines(L, oracle):
+    """Differential test of the two independent restatements of plan_compute_pipeline
+    (csrc/planner.cpp, oracle/oracle_plan.c) over 1500 random client-valid pipelines: any data
+    kind, repeated and oddly ordered stages, decode on/off, decimation, sampling mode, coherency
+    weighting.  16 channels = one reference chunk, so strides must agree exactly."""
+    rng = np.random.default_rng(7)
+    base = cfg.rca("fz", 16, 4, 256, (8, 8, 1), (-1e-3, 0, 5e-3), (1e-3, 0, 9e-3), seed=1)
+    pool = [int(S.Decode), int(S.Filter), int(S.Demodulate), int(S.DAS)]
+    filters = [base.filters[0], base.filters[0]]
+    for slot, fp in enumerate(filters):
+        assert L.beamformer_create_filter(C.byref(fp), slot, 0)
+    for it in range(1500):
+        bp = P.SimpleParameters.from_buffer_copy(bytes(base.bp))
+        stages = [int(rng.choice([int(S.Decode), int(S.Demodulate)]))] + [int(rng.choice(pool)) for _ in range(int(rng.integers(0, 5)))]
+        stages.append(int(S.DAS))
+        bp.data_kind = int(rng.integers(0, 6))
+        if bp.data_kind in (int(D.Int16Complex), int(D.Float32Complex), int(D.Float16Complex)):   # lib .c:285-296
+            stages = [s if s != int(S.Demodulate) else int(S.Filter) for s in stages]
+            stages[0] = int(S.Decode)
+        bp.compute_stages_count = len(stages)
+        for i, s in enumerate(stages):
+            bp.compute_stages[i] = s
+            bp.compute_stage_parameters[i] = int(rng.integers(0, 2))
+        bp.decode_mode = int(rng.integers(0, 2))
+        bp.decimation_rate = int(rng.integers(0, 4))
+        bp.sampling_mode = int(rng.integers(0, 2))
+        bp.coherency_weighting = int(rng.integers(0, 2))
+        bp.acquisition_count = int(rng.choice([1, 2, 4, 8, 12]))
+        bp.raw_data_dimensions[0] = bp.sample_count * bp.acquisition_count
+        assert L.beamformer_push_simple_parameters(C.byref(bp)), (it, stages)
+        ours = P.HipPlan()
+        assert L.beamformer_hip_describe_plan(0, C.byref(ours)), (it, stages)
+        ref = oracle.plan(bp, filters)
+        assert ref is not None and ours.stage_count == ref.stage_count, (it, stages)
+        for i in range(ours.stage_count):
+            a, b = ours.stages[i], ref.stages[i]
+            assert (a.kind, a.in_kind, a.out_kind) == (b.kind, b.in_kind, b.out_kind), (it, stages, i)
+            assert list(a.in_stride) == list(b.in_stride) and list(a.out_stride) == list(b.out_stride), (it, stages, i)
+        assert ours.das_samples == ref.input_sample_count and ours.iq_pipeline == ref.iq_pipeline
+        assert ours.das_time_offset == pytest.approx(ref.das_time_offset, rel=1e-6, abs=1e-12)
