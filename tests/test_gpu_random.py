@@ -1,0 +1,88 @@
+"""Randomised parity: 48 seeded small acquisitions drawn over family x geometry x interpolation
+x element kind x stages x f-number x coherency weighting x per-transmit orientations / focal
+depths, each beamformed through the C ABI on the automatic DAS path and compared with the
+oracle (same tolerances as tests/test_gpu_parity.py).  Complements the named cases: the
+combinations here are not hand-picked."""
+import numpy as np
+import pytest
+
+from ogl_beamforming_amd import configs as cfg, params as P
+from tests import cases
+from tests.test_gpu_parity import compare, last_das_path
+
+pytestmark = pytest.mark.gpu
+S, D, I, K = P.ShaderKind, P.DataKind, P.InterpolationMode, P.AcquisitionKind
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda *v: v[int(rng.integers(0, len(v)))]
+    interp = pick(I.Nearest, I.Linear, I.Linear, I.Cubic)
+    cw = bool(rng.integers(0, 2))
+    f_number = pick(0.0, 0.5, 1.0, 2.0)
+    C = int(pick(8, 12, 16, 24, 40))
+    samples = int(pick(256, 384, 512))
+    family = pick("rca2d", "rca3d", "rca3d", "vls", "hercules", "forces", "uforces")
+    common = dict(seed=seed, interp=interp, cw=cw, f_number=f_number)
+    path = 0.40 * samples / 25e6 * 1540.0
+    z0, z1 = 0.15 * path, 0.40 * path
+    if family in ("rca2d", "rca3d", "vls"):
+        A = int(pick(1, 2, 3, 5, 9))
+        kind = pick(D.Int16, D.Float16, D.Float32, D.Int16Complex, D.Float32Complex)
+        demod = kind in (D.Int16, D.Float16, D.Float32) and bool(rng.integers(0, 2))
+        if family == "rca2d":
+            points, lo, hi, orientation = (int(pick(12, 20, 33)), int(pick(12, 17)), 1), (-2e-3, 0, z0), (2e-3, 0, z1), 0x22
+        else:
+            points = (int(pick(6, 9, 16)), int(pick(6, 10)), int(pick(3, 5)))
+            lo, hi, orientation = (-2e-3, -2e-3, z0), (2e-3, 2e-3, z1), pick(0x12, 0x21)
+        depths = None
+        if family == "vls":
+            depths = rng.uniform(1.5 * z1, 4.0 * z1, A) * rng.choice([-1.0, 1.0], A)
+        acq = cfg.rca(f"random{seed}", C, A, samples, points, lo, hi, data_kind=kind, orientation=orientation,
+                      demodulate=demod, depths=depths, angles=rng.uniform(-12, 12, A) if A > 1 else None,
+                      kind=K.RCA_VLS if family == "vls" else K.RCA_TPW, **common)
+        bp = acq.bp
+        if family == "rca3d" and A > 1 and rng.integers(0, 3) == 0:
+            # per-transmit TRANSMIT orientation varies (receive fixed): still factorises
+            for a in range(A):
+                tx = int(pick(1, 2, 0))
+                bp.transmit_receive_orientations[a] = (tx << 4) | (orientation & 0xF)
+        elif family == "rca3d" and A > 1 and rng.integers(0, 4) == 0:
+            # receive orientation varies too: general kernel only
+            for a in range(A):
+                bp.transmit_receive_orientations[a] = int(pick(0x12, 0x21))
+        return acq
+    A = int(pick(4, 8, 12, 16))
+    kind = pick(D.Int16, D.Float16, D.Float32)
+    stages = pick((S.Decode, S.DAS), (S.Demodulate, S.Decode, S.DAS))
+    if family == "hercules":
+        return cfg.hercules(f"random{seed}", C, A, samples, (int(pick(6, 9)), int(pick(6, 8)), int(pick(4, 6))),
+                            (-1.5e-3, -1.5e-3, z0), (1.5e-3, 1.5e-3, z1), data_kind=kind, stages=stages,
+                            orientation=pick(0x12, 0x21), focal=pick((0.0, np.inf), (0.0, -4.0 * z1), (4.0, np.inf)), **common)
+    sparse = None
+    akind = K.FORCES
+    if family == "uforces":
+        akind = K.UFORCES
+        sparse = np.sort(rng.choice(C, A - 1, replace=False))
+    return cfg.forces(f"random{seed}", C, A, samples, (int(pick(12, 20, 31)), 1, int(pick(10, 16))), (-2e-3, 0, z0), (2e-3, 0, z1),
+                      data_kind=kind, stages=stages, kind=akind, sparse=sparse, **common)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_acquisition(seed, bflib, oracle):
+    acq = draw(seed)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ok = ~np.isnan(ref)
+    if not ok.any() or np.max(np.abs(ref[ok])) == 0:
+        pytest.skip("the draw produced an empty image (aperture closed everywhere)")
+    bflib.library().beamformer_hip_set_das_path(0)
+    gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    compare(gpu, ref, acq)
+    # and the general kernel on the same input, whatever the automatic choice was
+    if last_das_path(bflib) != 0:
+        bflib.library().beamformer_hip_set_das_path(1)
+        try:
+            gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        finally:
+            bflib.library().beamformer_hip_set_das_path(0)
+        compare(gpu, ref, acq)
