@@ -93,7 +93,13 @@ def main():
     rf_dev = torch.empty(rf_host.numel(), dtype=torch.uint8, device=device)
     if rank == 0:
         rf_dev.copy_(rf_host)
-    stream = torch.cuda.current_stream(device)
+    torch.cuda.synchronize(device)
+    # One explicit stream carries the RCCL broadcast and every kernel of the library, so a frame's
+    # DAS is ordered behind its broadcast without host synchronisation.  (torch's default stream
+    # has handle 0, which the library reads as "use your own stream": never pass that.)
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     assert L.beamformer_hip_set_stream(C.c_void_p(stream.cuda_stream)), lib.last_error()
 
     rf_bounce = torch.empty(rf_host.numel(), dtype=torch.uint8) if (distributed and rehearse) else None
@@ -178,7 +184,7 @@ def main():
                             f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "
                             f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
-                "f_number": bp.f_number, "sharding": f"{world} z-slab(s), RF broadcast via RCCL" if distributed else "none",
+                "f_number": bp.f_number, "sharding": (f"{world} z-slab(s), RF broadcast via " + ("gloo through the host (one-GPU rehearsal)" if rehearse else "RCCL")) if distributed else "none",
                 "das_path": PATH_NAMES[das_path],
                 "stage_ms": stage_ms,
             },
