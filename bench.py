@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
     ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies")
+    ap.add_argument("--serial-broadcast", action="store_true",
+                    help="multi-GPU: broadcast and compute back to back on one stream instead of pipelined")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run the N-rank code path with every rank on GPU 0 and gloo for the "
                          "collectives (RCCL refuses two ranks per device); the value is NOT the metric")
@@ -102,18 +104,59 @@ def main():
     assert stream.cuda_stream != 0
     assert L.beamformer_hip_set_stream(C.c_void_p(stream.cuda_stream)), lib.last_error()
 
+    # Multi-GPU schedule: the broadcast of frame n+1 runs on its own stream into the
+    # other of two RF buffers while the kernels of frame n run; events order "broadcast landed ->
+    # compute" and "frame that read this buffer finished -> next broadcast into it".  A step is
+    # one broadcast issued plus one frame computed; the pipeline is primed before the timed region.
+    pipelined = distributed and not args.serial_broadcast
     rf_bounce = torch.empty(rf_host.numel(), dtype=torch.uint8) if (distributed and rehearse) else None
+    if pipelined:
+        comm = torch.cuda.Stream(device=device)
+        bufs = [torch.empty_like(rf_dev), torch.empty_like(rf_dev)]
+        landed = [torch.cuda.Event(), torch.cuda.Event()]
+        released = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in released:
+            e.record(stream)
+        state = {"issued": 0, "computed": 0}
 
-    def step():
-        if distributed and rehearse:               # gloo has no device tensors: bounce through the host
+    def broadcast_into(buf):
+        if rehearse:                               # gloo has no device tensors: bounce through the host
             if rank == 0:
                 rf_bounce.copy_(rf_dev)
             sharding.broadcast_rf(rf_bounce, src=0)
-            rf_dev.copy_(rf_bounce)
-        elif distributed:
-            sharding.broadcast_rf(rf_dev, src=0)   # RCCL over xGMI; same stream as the kernels
-        ok = L.beamformer_hip_push_device_data_with_compute(C.c_void_p(rf_dev.data_ptr()), rf_dev.numel(), 0, 0)
+            buf.copy_(rf_bounce)
+        else:
+            if rank == 0 and buf.data_ptr() != rf_dev.data_ptr():
+                buf.copy_(rf_dev, non_blocking=True)
+            sharding.broadcast_rf(buf, src=0)      # RCCL over xGMI
+
+    def issue_broadcast():
+        k = state["issued"] % 2
+        with torch.cuda.stream(comm):
+            comm.wait_event(released[k])
+            broadcast_into(bufs[k])
+            landed[k].record(comm)
+        state["issued"] += 1
+
+    def push(buf):
+        ok = L.beamformer_hip_push_device_data_with_compute(C.c_void_p(buf.data_ptr()), buf.numel(), 0, 0)
         assert ok, lib.last_error()
+
+    def step():
+        if pipelined:
+            k = state["computed"] % 2
+            stream.wait_event(landed[k])
+            push(bufs[k])
+            released[k].record(stream)
+            state["computed"] += 1
+            issue_broadcast()                      # next frame's RF, overlapping this frame's kernels
+            return
+        if distributed:
+            broadcast_into(rf_dev)                 # same stream as the kernels
+        push(rf_dev)
+
+    if pipelined:
+        issue_broadcast()                          # prime: frame 0's RF
 
     def fence():
         torch.cuda.synchronize(device)
@@ -140,6 +183,19 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # Multi-GPU runs check what the schedule delivered: the slab of the last timed frame must be
+    # bit-identical to a recomputation from the same RF buffer after a full fence (a broadcast
+    # that had not landed, or a buffer overwritten early, would show here).  Outside the timed region.
+    verified = None
+    if distributed:
+        last_buf = bufs[(state["computed"] - 1) % 2] if pipelined else rf_dev
+        first = lib.get_last_frame(bp, shard_planes=z_count).copy()
+        push(last_buf)
+        fence()
+        again = lib.get_last_frame(bp, shard_planes=z_count)
+        verified = bool(np.array_equal(first.view(np.uint32), again.view(np.uint32)))
+        assert verified, f"rank {rank}: the pipelined frame differs from its recomputation"
+
     # DAS kernel duration: HIP event pairs recorded by the library on the stream it launches
     # on (beamformer_compute_timings = the reference's per-stage stats table)
     stats = P.ComputeStatsTable()
@@ -149,7 +205,7 @@ def main():
     das_col = ids.index(int(P.ShaderKind.DAS))
     info = P.HipFrameInfo()
     L.beamformer_hip_get_last_frame_info(C.byref(info))
-    last_id = int(info.frame_id)
+    last_id = int(info.frame_id) - (1 if distributed else 0)      # skip the verification frame
     rows = [(last_id - k) % 32 for k in range(args.steps)]
     das_s = float(np.mean([stats.times[r][das_col] for r in rows]))
     stage_ms = {P.ShaderKind(ids[i]).name: float(np.mean([stats.times[r][i] for r in rows])) * 1e3 for i in range(n_stage)}
@@ -184,8 +240,9 @@ def main():
                             f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "
                             f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
-                "f_number": bp.f_number, "sharding": (f"{world} z-slab(s), RF broadcast via " + ("gloo through the host (one-GPU rehearsal)" if rehearse else "RCCL")) if distributed else "none",
-                "das_path": PATH_NAMES[das_path],
+                "f_number": bp.f_number, "sharding": (f"{world} z-slab(s), RF broadcast via " + ("gloo through the host (one-GPU rehearsal)" if rehearse else "RCCL")
+                             + (", broadcast of frame n+1 overlaps frame n" if pipelined else ", serial")) if distributed else "none",
+                "das_path": PATH_NAMES[das_path], "slab_verified": verified,
                 "stage_ms": stage_ms,
             },
             "roofline": {
