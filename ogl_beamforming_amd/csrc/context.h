@@ -41,13 +41,16 @@ struct UploadSlot {
 	hipEvent_t copied = nullptr;         /* H2D of this slot finished (copy stream) */
 	hipEvent_t consumed = nullptr;       /* the frame that read this slot's device buffers finished (compute stream) */
 	bool       copy_pending = false, consume_pending = false;
+	bool       unfenced_reader = false;  /* a frame read this slot's device buffers without recording `consumed` */
 };
 
 struct TimingSlot {
 	hipEvent_t events[BEAMFORMER_HIP_MAX_TIMED_STAGES + 1]{};
 	uint32_t   kinds[BEAMFORMER_HIP_MAX_TIMED_STAGES]{};
 	uint32_t   count = 0;
-	bool       created = false, used = false;
+	bool       created = false;
+	bool       sampled = true;       /* false: this frame recorded no events; events_slot names the slot whose events stand in */
+	uint32_t   events_slot = 0;
 	uint64_t   das_voxels = 0;
 	uint32_t   das_taps = 0, das_sample_bytes = 0, das_path = 0;
 	bool       counted = false;
@@ -96,6 +99,9 @@ struct Context {
 	uint64_t     ring_next_offset = 0, frame_counter = 0;
 	std::vector<FrameRecord> frames;                           /* BeamformerMaxBacklogFrames records */
 	TimingSlot   timing[kTimingSlots];
+	uint64_t     last_sampled_frame = 0;                       /* frame id whose events are the newest real ones */
+	uint32_t     last_sampled_block = 0;
+	bool         have_sample = false;
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;
