@@ -39,9 +39,10 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_output_shard(uint32_t paramete
                                                                uint32_t z_first, uint32_t z_count);
 
 /* beamformer_push_data_with_compute() for RF that already resides on the library's device
- * (same layout and size rules).  The copy out of `device_data` is ordered on the library's
- * current stream; the caller may reuse the buffer once work it enqueues later on that
- * stream runs, or after beamformer_hip_synchronize(). */
+ * (same layout and size rules).  The frame reads `device_data` on the library's current stream
+ * -- in place by its first stage when no channel map / contrast reduction / row padding has to
+ * be applied, through a copy into the RF ring otherwise; the caller may overwrite the buffer
+ * from work it enqueues later on that stream, or after beamformer_hip_synchronize(). */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_push_device_data_with_compute(const void *device_data, uint32_t size,
                                                                             uint32_t image_plane_tag,
                                                                             uint32_t parameter_slot);

@@ -446,7 +446,7 @@ static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
 	return HIP_OK(hipEventRecord(t.events[index], s));
 }
 
-static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
+static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ingest_timed)
 {
 	Context &c = g_context;
 	PlanState *ps = commit_block(block);
@@ -474,8 +474,8 @@ static bool run_frame(uint32_t block, uint32_t rf_slot, bool ingest_timed)
 	else              record(t, 0, s);
 
 	const uint32_t C = plan.channels, A = plan.acquisitions, Sd = plan.das_samples;
-	const void *cur = c.rf[rf_slot].ptr;
-	int64_t cur_elements_bytes = (int64_t)c.rf[rf_slot].size;
+	const void *cur = rf;
+	int64_t cur_elements_bytes = rf_bytes;
 	int toggle = 0;
 	bool ok = true, das_segment_done = false;
 	uint32_t das_path = 0;
@@ -744,9 +744,19 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 		}
 	}
 	const bool zero_copy = !data_on_device && !overlap;
+	/* Device-resident RF already in the mapped layout is read in place by the first stage (no
+	 * copy into the RF ring): the caller keeps it unchanged until the frame has run, which stream
+	 * order gives for free when its producer is on the library's stream.  Plans that start with
+	 * DAS still copy: the DAS input needs the library's zero block behind it. */
+	bool borrowed = false;
+	if (data_on_device && direct) {
+		PlanState *ps = commit_block(block);
+		if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
+		borrowed = !ps->plan.stages.empty() && ps->plan.stages[0].kind != BeamformerShaderKind_DAS;
+	}
 	if (direct && !zero_copy) {
 		/* the mapped layout is the raw layout: one copy straight into the RF slot */
-		if (data_on_device) ok &= HIP_OK(hipMemcpyAsync(c.rf[slot].ptr, data, rf_size, hipMemcpyDeviceToDevice, s));
+		if (data_on_device && !borrowed) ok &= HIP_OK(hipMemcpyAsync(c.rf[slot].ptr, data, rf_size, hipMemcpyDeviceToDevice, s));
 	} else {
 		PlanState *ps = commit_block(block);
 		if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
@@ -771,7 +781,8 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	c.last_push_time = now;
 
-	bool done = run_frame(block, slot, true);
+	bool done = borrowed ? run_frame(block, data, (int64_t)rf_size, true)
+	                     : run_frame(block, c.rf[slot].ptr, (int64_t)c.rf[slot].size, true);
 	if (overlap) { u.consume_pending = HIP_OK(hipEventRecord(u.consumed, s)); u.unfenced_reader = false; }
 	else         { u.consume_pending = false; u.unfenced_reader = true; }
 	return done;
