@@ -102,6 +102,7 @@ struct Context {
 	uint64_t     last_sampled_frame = 0;                       /* frame id whose events are the newest real ones */
 	uint32_t     last_sampled_block = 0;
 	bool         have_sample = false;
+	uint64_t     replan_frame = 0;                             /* first frame of the current plan */
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;

@@ -130,7 +130,7 @@ void shutdown_device()
 	c.own_stream = nullptr;
 	c.frames.clear();
 	c.ring_next_offset = 0; c.frame_counter = 0; c.rf_index = 0;
-	c.have_sample = false; c.last_sampled_frame = 0; c.last_sampled_block = 0;
+	c.have_sample = false; c.last_sampled_frame = 0; c.last_sampled_block = 0; c.replan_frame = 0;
 	c.device_ready = false; c.device = -1;
 	for (auto &b : c.blocks) b.dirty |= Dirty_Parameters;   /* plans are rebuilt on next use */
 }
@@ -680,7 +680,9 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	const bool small = rf_size < kSmallFrameBytes &&
 	                   (uint64_t)bp.output_points[0] * (uint64_t)(bp.output_points[1] > 1 ? bp.output_points[1] : 1) *
 	                   (uint64_t)(bp.output_points[2] > 1 ? bp.output_points[2] : 1) < (4ull << 20);
-	t.sampled = !small || !c.have_sample || c.count_pairs || pb.dirty != 0 || block != c.last_sampled_block ||
+	if (!c.have_sample || pb.dirty != 0 || block != c.last_sampled_block) c.replan_frame = c.frame_counter;
+	/* the first frames of a plan are all sampled: the very first carries one-off launch costs */
+	t.sampled = !small || c.count_pairs || c.frame_counter - c.replan_frame < 3 ||
 	            c.frame_counter - c.last_sampled_frame >= kTimingSamplePeriod;
 	if (t.sampled) {
 		c.have_sample = true; c.last_sampled_frame = c.frame_counter; c.last_sampled_block = block;
