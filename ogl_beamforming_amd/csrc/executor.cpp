@@ -706,7 +706,7 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 		 * on the copy stream and the compute stream waits for it -- so the upload of frame n+1
 		 * overlaps the kernels of frame n, which one stream and pageable memory cannot do.
 		 * A copy-engine transfer and each cross-queue dependency cost 40-60 us of latency on
-		 * this runtime (build/h2d_probe.cpp: 0.26 MB pinned H2D + a kernel = 114 us per frame),
+		 * this runtime (tools/h2d_probe.cpp: 0.26 MB pinned H2D + a kernel = 114 us per frame),
 		 * more than a small frame's compute, so frames under kOverlapBytes skip the copy engine:
 		 * the ingest kernel reads the pinned slot in place over PCIe, in order on the compute
 		 * stream. */
