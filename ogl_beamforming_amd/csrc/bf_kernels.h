@@ -98,7 +98,6 @@ typedef struct {
 typedef struct {
 	const void *in; void *out;
 	const float *coefficients;
-	const int16_t *channel_mapping;   /* unused (ingest owns the mapping) */
 	uint32_t filter_length, decimation, sample_count, batch_sample_count;
 	int32_t  complex_filter, demodulate;
 	float    sampling_frequency, demodulation_frequency;
