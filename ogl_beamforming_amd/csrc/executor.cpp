@@ -640,6 +640,16 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 		}
 		if (!(st.kind == BeamformerShaderKind_DAS && das_segment_done)) segment((uint32_t)st.kind);
 	}
+	if (plan.das_index < 0 && ok) {
+		/* no DAS in the pipeline: the frame exists and stays zero (the reference clears it,
+		 * beamformer_core.c:1573-1585, and nothing writes it) */
+		uint32_t points[3] = {plan.output_points[0], plan.output_points[1], plan.output_points[2]};
+		FrameRecord *f = next_frame(points, plan.iq_pipeline, block);
+		if (!f) return set_error(BeamformerLibErrorKind_FrameSizeOverflow);
+		f->timing_slot = (int)(f->id % kTimingSlots);
+		ok &= HIP_OK(hipMemsetAsync((char *)c.ring.ptr + f->offset, 0, f->bytes, s));
+		t.das_voxels = 0; t.das_taps = 0; t.das_sample_bytes = 0; t.das_path = 0; t.frame_id = f->id;
+	}
 	if (!ok) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	return true;
 }

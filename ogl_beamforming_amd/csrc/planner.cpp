@@ -28,6 +28,7 @@ constexpr int kDontCare = BeamformerDataKind_Count;
 
 struct Node {
 	int     kind = -1, user_index = -1;
+	bool    stand_in = false;          /* DAS node added for resolution only (pipelines without DAS) */
 	int     in_kind = kDontCare, out_kind = kDontCare;
 	int64_t in_stride[3]{}, out_stride[3]{};
 };
@@ -114,6 +115,24 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 		}
 	}
 
+	/* A pipeline without DAS (the reference's decode benchmark, tests/decode.c:236-238, pushes
+	 * {Decode} alone) is legal: its stages run and the frame stays zero.  The reference leaves the
+	 * last stage's output strides unresolved (0, :741-742 only fixes the kind), so that stage
+	 * writes every element to index 0; here the last stage gets the layout and element kind DAS
+	 * would have asked for -- same work, a defined buffer -- by resolving against a stand-in DAS
+	 * node that is not planned. */
+	bool has_das = false;
+	for (const Node &n : nodes) has_das |= n.kind == BeamformerShaderKind_DAS;
+	if (!has_das) {
+		Node n;
+		n.kind = BeamformerShaderKind_DAS; n.stand_in = true;
+		n.in_kind = n.out_kind = das_kind;
+		n.in_stride[0] = 1; n.in_stride[1] = (int64_t)samples * A; n.in_stride[2] = samples;
+		n.out_stride[0] = 1; n.out_stride[1] = plan.output_points[0];
+		n.out_stride[2] = (int64_t)plan.output_points[0] * plan.output_points[1];
+		nodes.push_back(n);
+	}
+
 	/* pass 2: propagate don't-cares, insert Reshape on mismatch (:685-739) */
 	std::vector<Node> order;
 	order.push_back(nodes[0]);
@@ -150,6 +169,7 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 	size_t widest = 0;
 	for (size_t i = 1; i < order.size(); i++) {
 		const Node &n = order[i];
+		if (n.stand_in) continue;
 		Stage st;
 		st.kind = n.kind; st.in_kind = n.in_kind; st.out_kind = n.out_kind;
 		copy3(st.in_stride, n.in_stride); copy3(st.out_stride, n.out_stride);
@@ -197,7 +217,6 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 	}
 	plan.intermediate_bytes = widest;
 
-	if (plan.das_index < 0) { error = "pipeline has no DAS stage"; return false; }
 	/* the gather kernels index the DAS input with 32-bit byte offsets */
 	if ((uint64_t)C * A * samples * (plan.iq_pipeline ? 8 : 4) >= (1ull << 32)) {
 		error = "DAS input exceeds 4 GiB";

@@ -215,3 +215,19 @@ def test_display_reduction_matches_the_render_shader_maths(bflib, oracle):
             assert np.abs(got[ok] - ref[ok]).max() <= 2e-6, (name, threshold, gamma, cutoff)   # pow/log differ by ulps
         assert not L.beamformer_hip_display_last_frame(55.0, 1.0, 0.0, out.ctypes.data_as(C.POINTER(C.c_float)), frame.size - 1)
         assert bflib.last_error()[0] == E.ExportSpaceOverflow
+
+
+def test_decode_benchmark_harness_runs(tmp_path):
+    """ogl_beamformer_decode_bench (csrc/decode_bench.c, C11): the reference's tests/decode.c study
+    -- Decode-only pipelines for Hadamard orders 2..256 -- end to end through the C ABI."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ogl_beamforming_amd", "ogl_beamformer_decode_bench")
+    r = subprocess.run([exe, "--warmup", "2", "--dump", str(tmp_path / "stats")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("decode")]
+    assert [int(l.split()[1]) for l in lines] == [2, 4, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256]
+    for l in lines:
+        assert float(l.split("Decode kernel")[1].split()[0]) > 0            # the stage ran and was timed
+    table = np.fromfile(tmp_path / "stats" / "decode_256.bin", dtype=np.uint8)
+    assert table.size == 2248                                              # sizeof(BeamformerComputeStatsTable)

@@ -221,3 +221,28 @@ def test_planner_agrees_with_oracle_on_random_pipelines(L, oracle):
             assert list(a.in_stride) == list(b.in_stride) and list(a.out_stride) == list(b.out_stride), (it, stages, i)
         assert ours.das_samples == ref.input_sample_count and ours.iq_pipeline == ref.iq_pipeline
         assert ours.das_time_offset == pytest.approx(ref.das_time_offset, rel=1e-6, abs=1e-12)
+
+
+def test_pipeline_without_das_is_planned(L, bflib):
+    """tests/decode.c of the reference pushes {Decode} alone (:236-238): legal, the frame stays
+    zero.  The last stage gets the layout and kind DAS would have asked for."""
+    bp = P.Parameters()
+    bp.decode_mode = 1                                                # BeamformerDecodeMode_Hadamard
+    bp.sample_count, bp.channel_count, bp.acquisition_count = 4096, 12, 12
+    bp.raw_data_dimensions[0], bp.raw_data_dimensions[1] = 4096 * 12, 256
+    assert L.beamformer_push_parameters(C.byref(bp)), bflib.last_error()
+    mapping = (C.c_int16 * 256)(*[(i * 167 + 13) & 255 for i in range(256)])
+    assert L.beamformer_push_channel_mapping(mapping, 256)
+    stage = (C.c_int32 * 1)(int(S.Decode))
+    assert L.beamformer_push_pipeline(stage, 1, int(D.Int16)), bflib.last_error()
+    plan = P.HipPlan()
+    assert L.beamformer_hip_describe_plan(0, C.byref(plan))
+    kinds = [(plan.stages[i].kind, plan.stages[i].in_kind, plan.stages[i].out_kind) for i in range(plan.stage_count)]
+    assert kinds == [(S.Reshape, D.Int16, D.Int16), (S.Decode, D.Int16, D.Float32)]
+    assert list(plan.stages[1].in_stride) == [12 * 12, 12, 1]                 # decode layout (beamformer_core.c:645-664)
+    assert list(plan.stages[1].out_stride) == [1, 4096 * 12, 4096]            # what DAS would read
+    # decode switched off: nothing to run at all
+    bp.decode_mode = 0
+    assert L.beamformer_push_parameters(C.byref(bp))
+    assert L.beamformer_hip_describe_plan(0, C.byref(plan))
+    assert [plan.stages[i].kind for i in range(plan.stage_count)] in ([], [S.Reshape])
