@@ -109,7 +109,8 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold
  * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
  * Adding 0x10 keeps the general kernel at one thread per voxel for frames it would otherwise
  * split over channels (frames under ~4096 waves of voxels: K waves share 64 voxels, each
- * sums C/K channels, partial sums meet in LDS).  For parity testing of every path. */
+ * sums C/K channels, partial sums meet in LDS); adding 0x20 keeps Decode on the O(T^2) kernel
+ * where it would run as a fast Walsh-Hadamard transform.  For parity testing of every path. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 
 /* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----

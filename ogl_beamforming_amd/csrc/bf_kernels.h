@@ -90,6 +90,8 @@ typedef struct {
 typedef struct {
 	const void *in; void *out;
 	const float *hadamard_t;          /* T*T floats, transposed on the host: HtT[T*i + j] = Ht[T*j + i] */
+	const float *hadamard_base;       /* base*base floats B[i*base + j] when HtT = Sylvester(T/base) (x) B, else null */
+	uint32_t     hadamard_base_order; /* 1, 12 or 20; 0: no such structure found, dense kernel only */
 	uint32_t transmit_count, channel_count, sample_count;
 	int64_t  out_stride[3];           /* sample, channel, transmit */
 	int32_t  in_kind, out_kind;

@@ -60,7 +60,7 @@ struct TimingSlot {
 struct PlanState {
 	Plan         plan;
 	bool         valid = false;
-	DeviceBuffer hadamard_t, readi_hadamard, transmits, sparse, mapping;
+	DeviceBuffer hadamard_t, hadamard_base, readi_hadamard, transmits, sparse, mapping;
 	std::vector<DeviceBuffer> taps;     /* per stage */
 	std::vector<BfTransmit>   transmit_table;
 	std::vector<uint16_t>     readi_bits;

@@ -104,7 +104,7 @@ void shutdown_device()
 	(void)hipSetDevice(c.device);
 	(void)hipDeviceSynchronize();
 	for (auto &p : c.plans) {
-		p.hadamard_t.release(); p.readi_hadamard.release(); p.transmits.release();
+		p.hadamard_t.release(); p.hadamard_base.release(); p.readi_hadamard.release(); p.transmits.release();
 		p.sparse.release(); p.mapping.release();
 		for (auto &t : p.taps) t.release();
 		p.taps.clear(); p.valid = false;
@@ -191,6 +191,8 @@ static PlanState *commit_block(uint32_t block)
 
 	if (!ps.plan.hadamard_t.empty())
 		ok &= upload(ps.hadamard_t, ps.plan.hadamard_t.data(), sizeof(float) * ps.plan.hadamard_t.size(), s);
+	if (!ps.plan.hadamard_base.empty())
+		ok &= upload(ps.hadamard_base, ps.plan.hadamard_base.data(), sizeof(float) * ps.plan.hadamard_base.size(), s);
 	ps.readi_bits.clear();
 	for (float v : ps.plan.readi_hadamard) ps.readi_bits.push_back(half_bits_pm1(v));
 	if (!ps.readi_bits.empty())
@@ -499,6 +501,8 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			BfDecodeArgs a{};
 			a.in = cur; a.out = c.scratch[toggle].ptr;
 			a.hadamard_t = (const float *)ps->hadamard_t.ptr;
+			a.hadamard_base_order = (c.das_path_mode & 0x20) ? 0 : plan.hadamard_base_order;
+			a.hadamard_base = a.hadamard_base_order ? (const float *)ps->hadamard_base.ptr : nullptr;
 			a.transmit_count = A; a.channel_count = C; a.sample_count = Sd;
 			for (int k = 0; k < 3; k++) a.out_stride[k] = st.out_stride[k];
 			a.in_kind = st.in_kind; a.out_kind = st.out_kind;

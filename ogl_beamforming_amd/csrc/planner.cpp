@@ -183,6 +183,30 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 			for (uint32_t j = 0; j < A; j++)
 				for (uint32_t k = 0; k < A; k++)
 					plan.hadamard_t[(size_t)k * A + j] = h[(size_t)j * A + k];
+			/* math.c:35-134 grows the matrix by Kronecker doubling from a 1x1, 12x12 or 20x20
+			 * block, i.e. M = Sylvester(T/b) (x) B with the Sylvester index as the slow one.  When
+			 * the uploaded matrix has exactly that form (checked entry for entry, so nothing is
+			 * assumed about the construction) Decode may run as a fast Walsh-Hadamard transform
+			 * over the slow index plus a dense b x b transform (stages.hip). */
+			plan.hadamard_base_order = 0; plan.hadamard_base.clear();
+			for (uint32_t b : {1u, 12u, 20u}) {
+				if (A % b) continue;
+				uint32_t n = A / b;
+				if (n & (n - 1)) continue;
+				const std::vector<float> &M = plan.hadamard_t;
+				bool match = true;
+				for (uint32_t i = 0; i < A && match; i++)
+					for (uint32_t j = 0; j < A; j++) {
+						float sign = (__builtin_popcount((i / b) & (j / b)) & 1) ? -1.0f : 1.0f;
+						if (M[(size_t)i * A + j] != sign * M[(size_t)(i % b) * A + (j % b)]) { match = false; break; }
+					}
+				if (!match) continue;
+				plan.hadamard_base_order = b;
+				plan.hadamard_base.resize((size_t)b * b);
+				for (uint32_t i = 0; i < b; i++)
+					for (uint32_t j = 0; j < b; j++) plan.hadamard_base[(size_t)i * b + j] = M[(size_t)i * A + j];
+				break;
+			}
 		}break;
 		case BeamformerShaderKind_Filter:
 		case BeamformerShaderKind_Demodulate:{

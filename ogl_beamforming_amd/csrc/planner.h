@@ -59,6 +59,8 @@ struct Plan {
 	float    das_voxel_transform[16]{};
 	bool     das_sparse = false;
 	std::vector<float> hadamard_t;       /* decode: HtT[T*i + j] */
+	std::vector<float> hadamard_base;    /* B (base x base) when HtT == Sylvester (x) B entry for entry; base 1 holds {1} */
+	uint32_t           hadamard_base_order = 0;
 	std::vector<float> readi_hadamard;   /* G*G, row major, +-1 */
 	size_t   intermediate_bytes = 0;     /* largest inter-stage buffer */
 };

@@ -10,6 +10,7 @@
  * These stages are bandwidth bound (< 2 % of a frame); no MFMA.
  */
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bf_kernels.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -225,6 +226,83 @@ __global__ __launch_bounds__(256) void decode_kernel(const BfDecodeArgs a)
 	}
 }
 
+/* The same sums as decode_kernel in O(T (b + log2(T/b))) operations per sample instead of
+ * O(T^2), for matrices of the form Sylvester(n) (x) B (n = T/b a power of two; the host has
+ * checked the uploaded matrix entry for entry): a dense b x b transform inside every group of
+ * b consecutive transmits, then a fast Walsh-Hadamard transform across the groups, both in
+ * place on the LDS tile.  Every partial sum of Int16 RF is an integer below 2^24, exact in
+ * f32 whatever the order, so for the reference's usual raw data the result is bit-identical to
+ * the O(T^2) loop; for float RF the two differ by float rounding only.  f32 accumulation only
+ * (the per-operation f16 rounding of ACC16 pipelines depends on the order: those stay on
+ * decode_kernel).  Lanes are samples (row pitch T+1: conflict free); the butterflies of a
+ * stage are dealt to the four waves. */
+template <bool CPLX, uint32_t B>
+__global__ __launch_bounds__(256) void decode_fwht_kernel(const BfDecodeArgs a)
+{
+	typedef typename std::conditional<CPLX, f32x2, float>::type V;
+	extern __shared__ __attribute__((aligned(16))) float decode_lds[];
+	V *tile = reinterpret_cast<V *>(decode_lds);
+	const uint32_t T = a.transmit_count, C = a.channel_count;
+	const uint32_t channel = blockIdx.y;
+	const uint32_t s0      = blockIdx.x * 64;
+	const uint32_t pitch   = T + 1;
+
+	for (uint32_t e = threadIdx.x; e < 64 * T; e += 256) {
+		uint32_t sl = e / T, j = e - sl * T;
+		uint32_t sample = s0 + sl;
+		f32x2 v = {0.f, 0.f};
+		if (sample < a.sample_count)
+			v = load_element(a.in_kind, a.in, ((int64_t)sample * C + channel) * T + j);
+		if constexpr (CPLX) tile[sl * pitch + j] = v; else tile[sl * pitch + j] = v.x;
+	}
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	V *x = tile + (size_t)lane * pitch;
+
+	if constexpr (B > 1) {
+		/* y[g*B + i] = sum_j Bm[i][j] x[g*B + j] for every group g; B is 12 or 20, unrolled into
+		 * registers, the matrix through wave-uniform loads */
+		for (uint32_t g = wave; g < T / B; g += 4) {
+			V in[B];
+			#pragma unroll
+			for (uint32_t j = 0; j < B; j++) in[j] = x[g * B + j];
+			#pragma unroll
+			for (uint32_t i = 0; i < B; i++) {
+				V acc = in[0] * a.hadamard_base[i * B];
+				#pragma unroll
+				for (uint32_t j = 1; j < B; j++) acc += in[j] * a.hadamard_base[i * B + j];
+				x[g * B + i] = acc;
+			}
+		}
+		__syncthreads();
+	}
+	/* Sylvester butterflies across groups: element (g, i) pairs with (g ^ h, i) */
+	for (uint32_t h = 1; h < T / B; h <<= 1) {
+		for (uint32_t p = wave; p < T / 2; p += 4) {
+			uint32_t i  = p % B, q = p / B;                      /* q enumerates the T/(2B) group pairs */
+			uint32_t g  = ((q / h) * 2 * h) + (q % h);           /* group with bit h clear */
+			uint32_t lo = g * B + i, hi = (g + h) * B + i;
+			V u = x[lo], v = x[hi];
+			x[lo] = u + v; x[hi] = u - v;
+		}
+		__syncthreads();
+	}
+
+	const uint32_t sample = s0 + lane;
+	if (sample < a.sample_count) {
+		for (uint32_t i = wave; i < T; i += 4) {
+			V acc = x[i];
+			int64_t off = a.out_stride[1] * channel + a.out_stride[2] * i + a.out_stride[0] * sample;
+			f32x2 v;
+			if constexpr (CPLX) v = f32x2{acc.x / (float)T, acc.y / (float)T}; else v = f32x2{acc / (float)T, 0.f};
+			if (a.out_kind & 1) store_element(a.out_kind, a.out, off, v);
+			else                store_scalar(a.out_kind, a.out, off, v.x);
+		}
+	}
+}
+
 extern "C" hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s)
 {
 	if (!a->sample_count || !a->channel_count || !a->transmit_count) return hipSuccess;
@@ -233,6 +311,23 @@ extern "C" hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s)
 	dim3 grid((a->sample_count + 63) / 64, a->channel_count);
 	size_t lds = (size_t)64 * (a->transmit_count + 1) * (cplx ? 8 : 4);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	if (!acc16 && a->hadamard_base_order && a->hadamard_base && a->transmit_count >= 4) {
+		switch (a->hadamard_base_order) {
+		case 1:
+			if (cplx) hipLaunchKernelGGL((decode_fwht_kernel<true,  1>),  grid, dim3(256), lds, s, *a);
+			else      hipLaunchKernelGGL((decode_fwht_kernel<false, 1>),  grid, dim3(256), lds, s, *a);
+			return hipGetLastError();
+		case 12:
+			if (cplx) hipLaunchKernelGGL((decode_fwht_kernel<true,  12>), grid, dim3(256), lds, s, *a);
+			else      hipLaunchKernelGGL((decode_fwht_kernel<false, 12>), grid, dim3(256), lds, s, *a);
+			return hipGetLastError();
+		case 20:
+			if (cplx) hipLaunchKernelGGL((decode_fwht_kernel<true,  20>), grid, dim3(256), lds, s, *a);
+			else      hipLaunchKernelGGL((decode_fwht_kernel<false, 20>), grid, dim3(256), lds, s, *a);
+			return hipGetLastError();
+		default: break;       /* unknown base: dense kernel below */
+		}
+	}
 	if (cplx) {
 		if (acc16) hipLaunchKernelGGL((decode_kernel<true,  true>),  grid, dim3(256), lds, s, *a);
 		else       hipLaunchKernelGGL((decode_kernel<true,  false>), grid, dim3(256), lds, s, *a);

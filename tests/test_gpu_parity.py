@@ -147,6 +147,31 @@ def test_factored_kernel(name, split, bflib, oracle):
     compare(gpu, ref, acq)
 
 
+DECODING = sorted(n for n in cases.CASES
+                  if cases.make(n).bp.decode_mode and int(P.ShaderKind.Decode) in list(cases.make(n).bp.compute_stages[:cases.make(n).bp.compute_stages_count]))
+
+
+@pytest.mark.parametrize("name", DECODING)
+def test_decode_dense_kernel_and_fwht_agree(name, bflib, oracle):
+    """Decode runs as a fast Walsh-Hadamard transform wherever the matrix is Sylvester (x) base
+    (orders 2^k, 12*2^k, 20*2^k); 0x20 keeps the O(T^2) kernel.  Both match the oracle; on Int16
+    RF decoded first every partial sum is an exact integer, so the two frames are bit-identical."""
+    acq = cases.make(name)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    fast = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    compare(fast, ref, acq)
+    lib.beamformer_hip_set_das_path(0x20)
+    try:
+        dense = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(dense, ref, acq)
+    stages = list(acq.bp.compute_stages[: acq.bp.compute_stages_count])
+    if acq.bp.data_kind == int(P.DataKind.Int16) and stages[0] == int(P.ShaderKind.Decode):
+        assert np.array_equal(fast, dense, equal_nan=True)
+
+
 def test_pair_count_matches_oracle(bflib, oracle):
     """G of the roofline model: the geometry-only count kernel agrees with the oracle's tally
     of taken apodization branches (exactly, up to aperture-edge rounding)."""
