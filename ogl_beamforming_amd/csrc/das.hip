@@ -28,7 +28,7 @@
 /* das.glsl:54-61 with the angle in turns, reduced to [0,1) */
 __device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const BfDasArgs &p)
 {
-	float turns = hw_fract(p.demodulation_frequency * (index * p.inv_sampling_frequency));
+	float turns = hw_fract(index * p.turns_per_sample);
 	float c = hw_cos_turns(turns), s = hw_sin_turns(turns);
 	return f32x2{c * iq.x - s * iq.y, s * iq.x + c * iq.y};
 }
@@ -50,23 +50,27 @@ __device__ __forceinline__ sample_t<CPLX> sample_rf(const char *rf, int rf_offse
 			if constexpr (CPLX) result = rotate_iq(result, index, p);
 		}
 	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
-		if (index >= 0.f && index < S - 1.f) {
-			float tk = __builtin_floorf(index), t = index - tk;
-			uint32_t off = (uint32_t)(rf_offset + (int)tk) * ES;
+		/* 0 <= index < S-1  <=>  (unsigned)floor(index) < S-1: one convert and one compare */
+		uint32_t k = (uint32_t)cvt_floor_i32(index);
+		if (k < (uint32_t)(p.sample_count - 1)) {
+			float t = hw_fract(index);
+			uint32_t off = ((uint32_t)rf_offset + k) * ES;
 			if constexpr (CPLX) {
 				f32x4 v = gather<f32x4_a8>(rf, off);
 				f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-				result = (1.f - t) * a + t * b;
+				result = a + t * (b - a);
 				result = rotate_iq(result, index, p);
 			} else {
 				f32x2 v = gather<f32x2_a4>(rf, off);
-				result = (1.f - t) * v.x + t * v.y;
+				result = v.x + t * (v.y - v.x);
 			}
 		}
 	} else {
-		if (index >= 1.f && index < S - 2.f) {
-			float tk = __builtin_floorf(index), t = index - tk;
-			uint32_t off = (uint32_t)(rf_offset + (int)tk - 1) * ES;
+		/* 1 <= index < S-2  <=>  (unsigned)(floor(index) - 1) < S-3 */
+		uint32_t k = (uint32_t)(cvt_floor_i32(index) - 1);
+		if (k < (uint32_t)(p.sample_count - 3)) {
+			float t = hw_fract(index);
+			uint32_t off = ((uint32_t)rf_offset + k) * ES;
 			float t2 = t * t, t3 = t2 * t;
 			/* Hermite basis with tangents 0.5 (P2 - P0), 0.5 (P3 - P1) */
 			float b0 =  2.f * t3 - 3.f * t2 + 1.f;
@@ -180,7 +184,9 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 	const float f_number_over_z  = __builtin_fabsf(p.f_number * hw_rcp(xz));
 	const float apodization_test = 0.25f / (f_number_over_z * f_number_over_z);
 	const float fs_over_c        = p.sampling_frequency * p.inv_speed_of_sound;
-	const float first_weight     = hw_rsq((float)A);
+	/* the axis the decoded transmit elements run along, chosen once */
+	const float tx_lateral       = rx_cols ? xy : xx;
+	const float tx_pitch         = rx_cols ? p.pitch[1] : p.pitch[0];
 
 	for (int channel = ch0; channel < ch1; channel++) {
 		int rf_offset = channel * S * A + sparse * S;
@@ -190,14 +196,15 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 
 		for (int transmit = sparse; transmit < A; transmit++) {
 			float tx_channel = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
-			float tx_delta   = rx_cols ? xy - tx_channel * p.pitch[1] : xx - tx_channel * p.pitch[0];
-			float element_delta_squared = rx_cols ? rx_sq + tx_delta * tx_delta : tx_delta * tx_delta + rx_sq;
+			float tx_delta   = tx_lateral - tx_channel * tx_pitch;
+			float element_delta_squared = tx_delta * tx_delta + rx_sq;
 			bool pass = element_delta_squared < apodization_test;
 			if constexpr (COUNT) {
 				acc.pairs += pass;
 			} else if (pass) {
-				float apodization = (transmit == 0 ? first_weight : 1.0f)
-				                    * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
+				/* "tribal knowledge" weight of the first transmit (das.glsl:272-273): a scalar */
+				const float weight = transmit == 0 ? p.first_transmit_weight : 1.0f;
+				float apodization = weight * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
 				float index = transmit_index + hw_sqrt(z_delta_squared + element_delta_squared) * fs_over_c;
 				acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 			}
