@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				 * (r + min T >= 0 and r + max T < S - 1, the tile-wide extremes of T are in `range`),
 				 * the per-term range test and the zero-block select are dropped. */
 				const bool lane_safe = (r.x + range.x >= 0.f) && (r.x + range.y < (float)(S - 1));
-								const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
+				const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
 				auto batches = [&](auto checked) {
 					constexpr bool CHECK = decltype(checked)::value;
 					for (int a = 0; a < A; a += B, row += B * row_bytes) {
