@@ -253,6 +253,11 @@ def main():
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
                          "compulsory HBM traffic is ~1e4x smaller (BASELINE.md section 4)",
+                # what actually binds the kernel: every tap is a per-lane L1 gather and the
+                # texture-address path retires 64 B per clock per CU
+                "l1_gather": {"achieved": pairs_local * taps * sample_bytes / das_s / 1e9, "unit": "GB/s",
+                              "peak": 64 * 256 * 2.4e9 / 1e9, "peak_model": "64 B/clk/CU x 256 CUs x 2.4 GHz",
+                              "frac": pairs_local * taps * sample_bytes / das_s / (64 * 256 * 2.4e9)},
             },
         }
         if not args.no_cpu_baseline and world == 1:
