@@ -24,6 +24,7 @@
 #include <cerrno>
 #include <cstdarg>
 #include <csignal>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -305,7 +306,12 @@ int main(int argc, char **argv)
 	__atomic_store_n(&s.sm->version, (uint32_t)BEAMFORMER_SHARED_MEMORY_VERSION, __ATOMIC_SEQ_CST);   /* clients check this first */
 	say("ready name %s size %llu version %u", name, (unsigned long long)size, s.sm->version);
 
+	/* The reference's workers sleep on futexes the client posts (lib .c:192-198).  This loop
+	 * serves two signalling paths (the upload lock and the work queue) from one thread, so it
+	 * polls instead: busily for ~1 ms after the last request -- a streaming client sees
+	 * microsecond hand-offs -- then with 100 us sleeps so an idle server costs no CPU. */
 	long served = 0;
+	auto last_activity = std::chrono::steady_clock::now();
 	while (!g_stop && (once < 0 || served < once)) {
 		bool idle = true;
 		if (__atomic_load_n(&s.sm->locks[Lock_UploadRF], __ATOMIC_SEQ_CST)) {
@@ -323,7 +329,13 @@ int main(int argc, char **argv)
 			idle = false;
 			if (once >= 0 && served >= once) break;
 		}
-		if (idle) usleep(100);
+		if (!idle) {
+			last_activity = std::chrono::steady_clock::now();
+		} else if (std::chrono::steady_clock::now() - last_activity < std::chrono::milliseconds(1)) {
+			__builtin_ia32_pause();
+		} else {
+			usleep(100);
+		}
 	}
 
 	/* beamformer_terminate (beamformer.c:345-373): make blocked clients fail instead of hang */
