@@ -587,7 +587,8 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			uint32_t ext[3] = {a.size[0], a.size[1], zcount};
 			/* Small frames (real-time 2-D imaging) do not fill 256 CUs with one thread per voxel:
 			 * split the channel loop over K waves of a block (wave-level partial sums, combined
-			 * through LDS in split order) until the launch has ~16 waves per CU. */
+			 * through LDS in split order) until the launch has ~16 waves per CU (config 1, us per
+			 * frame by target wave count: 2048 -> 19.9, 4096 -> 15.2, 8192 -> 15.1, 16384 -> 17.1). */
 			uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
 			a.split_shift = 0;
 			while (!(c.das_path_mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
