@@ -102,6 +102,7 @@ typedef struct {
 typedef struct {
 	const void *in; void *out;
 	const float *coefficients;
+	const float *phasors;             /* demodulate: {cos, -sin} of the window-local phase for index 0..D*64+L-2, or null */
 	uint32_t filter_length, decimation, sample_count, batch_sample_count;
 	int32_t  complex_filter, demodulate;
 	float    sampling_frequency, demodulation_frequency;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 #include <cstdint>
 #include <string>
+#include <list>
 #include <vector>
 #include "planner.h"
 #include "bf_kernels.h"
@@ -61,7 +62,8 @@ struct PlanState {
 	Plan         plan;
 	bool         valid = false;
 	DeviceBuffer hadamard_t, hadamard_base, readi_hadamard, transmits, sparse, mapping;
-	std::vector<DeviceBuffer> taps;     /* per stage */
+	std::vector<DeviceBuffer> taps;     /* per stage: filter taps (+ demodulation phasors) */
+	std::list<std::vector<float>> tap_tables;   /* host copies the async uploads read from */
 	std::vector<BfTransmit>   transmit_table;
 	std::vector<uint16_t>     readi_bits;
 	std::string  error;

@@ -199,11 +199,26 @@ static PlanState *commit_block(uint32_t block)
 		ok &= upload(ps.readi_hadamard, ps.readi_bits.data(), sizeof(uint16_t) * ps.readi_bits.size(), s);
 
 	for (auto &t : ps.taps) t.release();
+	ps.tap_tables.clear();
 	ps.taps.assign(ps.plan.stages.size(), DeviceBuffer{});
 	for (size_t i = 0; i < ps.plan.stages.size(); i++) {
 		const Stage &st = ps.plan.stages[i];
-		if (st.kind == BeamformerShaderKind_Filter || st.kind == BeamformerShaderKind_Demodulate)
-			ok &= upload(ps.taps[i], st.filter.taps.data(), sizeof(float) * st.filter.taps.size(), s);
+		if (st.kind == BeamformerShaderKind_Filter || st.kind == BeamformerShaderKind_Demodulate) {
+			/* taps, then -- for Demodulate -- the window-local phasors {cos, -sin}(2 pi fd index / (fs/2))
+			 * of filter.glsl:99-107, in the kernel's own f32 expression */
+			ps.tap_tables.emplace_back(st.filter.taps);
+			std::vector<float> &table = ps.tap_tables.back();
+			if (st.kind == BeamformerShaderKind_Demodulate) {
+				const uint32_t window = ps.plan.decimation * 64 + (uint32_t)st.filter.length - 1;
+				const float fd = bp.demodulation_frequency, fs = bp.sampling_frequency / 2;
+				for (uint32_t index = 0; index < window; index++) {
+					float arg = 6.28318530717958647692f * fd * (float)index / fs;
+					table.push_back(cosf(arg));
+					table.push_back(-sinf(arg));
+				}
+			}
+			ok &= upload(ps.taps[i], table.data(), sizeof(float) * table.size(), s);
+		}
 	}
 	if (ps.plan.intermediate_bytes) {
 		ok &= c.scratch[0].ensure(ps.plan.intermediate_bytes + 64);
@@ -515,6 +530,7 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			BfFilterArgs a{};
 			a.in = cur; a.out = c.scratch[toggle].ptr;
 			a.coefficients   = (const float *)ps->taps[i].ptr;
+			a.phasors        = demod ? a.coefficients + st.filter.taps.size() : nullptr;
 			a.filter_length  = (uint32_t)st.filter.length;
 			a.complex_filter = st.filter.complex_taps;
 			a.demodulate     = demod;

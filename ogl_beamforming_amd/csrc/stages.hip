@@ -375,8 +375,15 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 			if (F16) { s.x = (float)(_Float16)s.x; s.y = (float)(_Float16)s.y; }
 			if (a.demodulate) {
 				/* s * (1,-1); rotate_iq (filter.glsl:57-64); * scale, all in SAMPLE_TYPE */
-				float arg = 6.28318530717958647692f * a.demodulation_frequency * (float)index / a.sampling_frequency;
-				float c = cosf(arg), sn = -sinf(arg);
+				/* the phase depends only on the position inside the window: the host tabulates it once
+				 * per plan with this very expression (libm sin/cos cost more than the whole FIR here) */
+				float c, sn;
+				if (a.phasors) {
+					c = a.phasors[2 * index]; sn = a.phasors[2 * index + 1];
+				} else {
+					float arg = 6.28318530717958647692f * a.demodulation_frequency * (float)index / a.sampling_frequency;
+					c = cosf(arg); sn = -sinf(arg);
+				}
 				f32x2 q = {s.x, -s.y};
 				f32x2 r = {c * q.x - sn * q.y, sn * q.x + c * q.y};
 				if (F16) {
