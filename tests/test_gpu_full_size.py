@@ -103,3 +103,44 @@ def test_full_size_linearity(bflib, config4):
     want = 0.5 * bx - 2.0 * by
     assert np.abs(want).max() > 0
     assert np.abs(bz - want).max() / np.abs(want).max() < 2e-4
+
+
+@pytest.mark.parametrize("n, path_name", [(2, "factored"), (3, "general"), (5, "general")])
+def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
+    """Configs 2, 3 and 5 at BASELINE sizes (config 5 on a 16-plane slab: 4.3 s per whole frame):
+    the scatterer (where the acquisition has one) peaks where it was placed, the automatic DAS path is the expected one, the
+    factored kernel agrees with the general kernel on the same frame (config 2), and the oracle
+    agrees on a few full-size rows around the scatterer."""
+    acq = cfg.config(n)
+    X, Y, Z = (max(1, v) for v in acq.bp.output_points[:3])
+    m = np.array(acq.bp.das_voxel_transform[:], np.float64).reshape(4, 4).T
+    want = None
+    if acq.scatterers:
+        sc = np.array(acq.scatterers[0], np.float64)
+        if Z == 1:                                       # (X, Y, 1) image: voxel y runs along world z
+            want = np.array([(sc[0] - m[0, 3]) / m[0, 0] * (X - 1), (sc[2] - m[2, 3]) / m[2, 1] * (Y - 1), 0.0])
+        else:
+            want = (sc - m[:3, 3]) / np.diag(m[:3, :3]) * (np.array([X, Y, Z]) - 1)
+    wz, wy = (int(round(want[2])), int(round(want[1]))) if want is not None else (Z // 2, Y // 2)
+    shard = None if n != 5 else (max(0, wz - 8), 16)
+    frame = run(bflib, acq, shard=shard)
+    t = P.HipFrameTimings()
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
+    assert int(t.das_path) == {"general": 0, "factored": 3}[path_name]
+    z0 = shard[0] if shard else 0
+    if want is not None:
+        mag = np.abs(np.nan_to_num(frame))
+        z, y, x = np.unravel_index(np.argmax(mag), mag.shape)
+        assert abs(x - want[0]) <= 2 and abs(y - want[1]) <= 2 and abs(z + z0 - want[2]) <= 2, ((x, y, z + z0), want)
+
+    rows = (max(0, wy - 1), 3)
+    ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters, z=(wz, 1), y=rows, threads=16)
+    got = frame[wz - z0: wz - z0 + 1, rows[0]: rows[0] + 3]
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    ok = ~np.isnan(ref)
+    from tests import cases
+    assert np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max() <= cases.tolerance(acq)
+
+    if n == 2:
+        general = run(bflib, acq, path=1)
+        assert np.abs(general - frame).max() / np.abs(frame).max() < 1e-4
