@@ -1,0 +1,51 @@
+"""bench.py's contract on a GPU box at a reduced scale: the JSON line and its roofline /
+cpu_baseline objects, and the multi-GPU schedule (pipelined RF broadcast, slab verification)
+rehearsed with two ranks on one GPU over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def last_json(text):
+    return json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.125", "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["unit"] == "voxels/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 64 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["kernel_ms"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "voxels/s" and cpu["sample"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--serial-broadcast"]])
+def test_two_ranks_rehearsed_on_one_gpu(extra):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.125", "--steps", "4",
+           "--warmup", "2", "--rehearse-on-one-gpu", "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["slab_verified"] is True
+    assert ("overlaps" in d["config"]["sharding"]) == (not extra)
+    assert d["roofline"]["pairs_total"] >= d["roofline"]["pairs_per_launch"] > 0
