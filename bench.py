@@ -239,6 +239,7 @@ def main():
                             f" -> {' -> '.join(P.ShaderKind(v).name for v in bp.compute_stages[:bp.compute_stages_count])}"
                             f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "
                             f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
+                **({"notes": acq.notes} if acq.notes else {}),
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": (f"{world} z-slab(s), RF broadcast via " + ("gloo through the host (one-GPU rehearsal)" if rehearse else "RCCL")
                              + (", broadcast of frame n+1 overlaps frame n" if pipelined else ", serial")) if distributed else "none",

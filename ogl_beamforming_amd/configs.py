@@ -321,6 +321,9 @@ def config(n, scale=1.0):
         acq = hercules("config3", C, A, S, (s(256, 8), s(256, 8), s(256, 8)), (-4.8e-3, -4.8e-3, z0),
                        (4.8e-3, 4.8e-3, z1), seed=3, focal=(0.0, focus), f_number=1.0)
         acq.bp.time_offset = focus / SPEED_OF_SOUND     # the wave leaves the array at t = 0
+        acq.notes = ("BASELINE's 32 x 32 matrix probe (1024 channels) exceeds the API's 256-channel limit; restated as a "
+                     "HERCULES aperture of 32 receive channels x 32 decoded transmit elements = 1024 element pairs, one "
+                     "diverging wave (virtual source 20 mm behind the array) -- SURVEY 8d config 3")
         return acq
     if n == 4:   # 3-D RCA, 256 ch x 75 plane waves, coherency weighting -> 512^3 (the headline metric)
         C, A, S = s(256, 16, 16), s(75, 3), s(4096, 512, 128)
@@ -334,9 +337,13 @@ def config(n, scale=1.0):
         C, A, S = s(256, 16, 16), s(128, 8), s(2048, 512, 128)
         A = 1 << int(math.log2(A))
         z0, z1 = depth_range(S, fraction=0.35)
-        return hercules("config5", C, A, S, (s(512, 8), s(512, 8), s(512, 8)),
-                        (-(C - 1) / 2 * 0.15e-3, -(A - 1) / 2 * 0.15e-3, z0),
-                        ((C - 1) / 2 * 0.15e-3, (A - 1) / 2 * 0.15e-3, z1), seed=5,
-                        data_kind=P.DataKind.Float16, pitch=0.15e-3, cw=True, f_number=0.5, interp=P.InterpolationMode.Linear,
-                        stages=(P.ShaderKind.Demodulate, P.ShaderKind.Decode, P.ShaderKind.DAS))
+        acq = hercules("config5", C, A, S, (s(512, 8), s(512, 8), s(512, 8)),
+                       (-(C - 1) / 2 * 0.15e-3, -(A - 1) / 2 * 0.15e-3, z0),
+                       ((C - 1) / 2 * 0.15e-3, (A - 1) / 2 * 0.15e-3, z1), seed=5,
+                       data_kind=P.DataKind.Float16, pitch=0.15e-3, cw=True, f_number=0.5, interp=P.InterpolationMode.Linear,
+                       stages=(P.ShaderKind.Demodulate, P.ShaderKind.Decode, P.ShaderKind.DAS))
+        acq.notes = ("the reference's canonical stage order {Demodulate, Decode, DAS} (tests/throughput.c:455-461) in place of "
+                     "BASELINE's {Decode, Filter, DAS}: coherency weighting is implicit after DAS, min/max is the library's "
+                     "beamformer_hip_frame_min_max -- SURVEY 8d config 5")
+        return acq
     raise ValueError(n)
