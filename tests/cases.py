@@ -71,6 +71,11 @@ def _cases():
         "hercules_chirp", 16, 4, 1024, (8, 8, 8), LO3, HI3, seed=25, decode=0, data_kind=D.Float32,
         stages=(S.Demodulate, S.DAS),
         filters=[cfg.matched_chirp_filter(12.5e6, 4e-6, -2e6, 2e6, complex_taps=True)])
+    # BASELINE config 5 in its literal stage order {Decode, Filter, DAS} on fp16 RF: Decode's output stays
+    # binary16 (accumulated with per-operation rounding), Filter stages through binary16, real-valued DAS + CW
+    c["config5_literal_order"] = lambda: cfg.hercules(
+        "config5_literal_order", 16, 16, 512, (10, 10, 12), LO3, HI3, seed=26, cw=True, data_kind=D.Float16,
+        stages=(S.Decode, S.Filter, S.DAS), filters=[cfg.kaiser_filter(25e6, 5e6, length=24, beta=5.0)])
     # FORCES family
     c["forces"] = lambda: cfg.forces("forces", 16, 16, 512, (20, 1, 20), LO3, HI3, seed=31)
     c["uforces_sparse"] = lambda: cfg.forces("uforces_sparse", 16, 8, 512, (16, 1, 16), LO3, HI3, seed=32,
