@@ -9,6 +9,12 @@
  *
  * Same conventions as ogl_beamformer_lib.h: returns 1 on success, 0 on failure with the
  * reason in beamformer_get_last_error().
+ *
+ * Threading: the library keeps one process-wide state (as the reference client keeps one
+ * process-wide connection, lib/ogl_beamformer_lib.c:29-34) and takes no locks; call it from one
+ * thread at a time.  Work it enqueues runs asynchronously on HIP streams; the data/compute
+ * calls return before the frame is finished and beamformer_get_last_frames /
+ * beamformer_hip_synchronize are the synchronisation points.
  */
 #ifndef OGL_BEAMFORMER_HIP_H
 #define OGL_BEAMFORMER_HIP_H
