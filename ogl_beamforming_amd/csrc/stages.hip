@@ -345,9 +345,10 @@ extern "C" hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s)
  * by the position inside that window, filter.glsl:99-107).  Four such groups share a
  * 256-thread block.  F16 selects the shader's SAMPLE_TYPE (filter.glsl:2-14): binary16 for
  * every 16-bit input kind, binary32 otherwise; products and sums are f32. */
-template <bool F16>
+template <int IN_KIND, bool DEMOD>
 __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 {
+	constexpr bool F16 = (IN_KIND >> 1) != 1;                       /* every 16-bit kind stages through binary16 */
 	extern __shared__ __attribute__((aligned(16))) float filter_lds[];
 	const uint32_t L = a.filter_length, D = a.decimation;
 	const uint32_t window = D * 64 + L - 1;
@@ -356,12 +357,12 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 	const uint32_t wg   = blockIdx.x * 4 + wave;                  /* the shader's gl_WorkGroupID.x */
 	const uint32_t channel = blockIdx.y, transmit = blockIdx.z;
 	float *w = filter_lds + (size_t)wave * window * 2;
-	const bool in_complex     = (a.in_kind & 1) != 0;
-	const bool complex_sample = in_complex || a.demodulate;          /* filter.glsl:16-19 */
+	constexpr bool in_complex     = (IN_KIND & 1) != 0;
+	constexpr bool complex_sample = in_complex || DEMOD;             /* filter.glsl:16-19 */
 
 	const bool offset_wraps = (D * wg * 64) < (L - 1);             /* filter.glsl:79 */
 	int64_t row_start = a.in_stride[1] * channel + a.in_stride[2] * transmit;
-	if (a.demodulate) row_start /= 2;                               /* filter.glsl:81-87 */
+	if (DEMOD) row_start /= 2;                                      /* filter.glsl:81-87 */
 	const int64_t window_start = row_start + (int64_t)D * wg * 64 - (int64_t)(L - 1);
 
 	float scale = a.complex_filter ? 1.0f : __builtin_sqrtf(2.0f);   /* filter.glsl:98 */
@@ -371,9 +372,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 		f32x2 s = {0.f, 0.f};
 		int64_t e = window_start + index;
 		if ((!offset_wraps || index >= L - 1) && e >= 0 && e < a.in_elements) {
-			s = load_element(a.in_kind, a.in, e);
+			s = load_element(IN_KIND, a.in, e);
 			if (F16) { s.x = (float)(_Float16)s.x; s.y = (float)(_Float16)s.y; }
-			if (a.demodulate) {
+			if (DEMOD) {
 				/* s * (1,-1); rotate_iq (filter.glsl:57-64); * scale, all in SAMPLE_TYPE */
 				/* the phase depends only on the position inside the window: the host tabulates it once
 				 * per plan with this very expression (libm sin/cos cost more than the whole FIR here) */
@@ -395,9 +396,13 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 				}
 			}
 		}
-		w[2 * index] = s.x; w[2 * index + 1] = s.y;
+		reinterpret_cast<f32x2 *>(w)[index] = s;
 	}
-	__syncthreads();
+	/* each wave reads back only the window it wrote: ordering inside the wave is enough, the
+	 * four groups of a block never wait for one another */
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
 	const uint32_t out_sample = wg * 64 + lane;
 	if (out_sample < a.sample_count / D) {                            /* filter.glsl:115 */
@@ -419,7 +424,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 			}
 		}
 		int64_t off = a.out_stride[1] * channel + a.out_stride[2] * transmit + a.out_stride[0] * out_sample;
-		if (a.batch_sample_count != 0) {                              /* filter.glsl:126-130 */
+		if (a.batch_sample_count == 0 && a.out_kind == 3) {           /* the common case: f32 complex, one 8-byte store */
+			reinterpret_cast<f32x2 *>(a.out)[off] = result;
+		} else if (a.batch_sample_count != 0) {                       /* filter.glsl:126-130 */
 			store_scalar(a.out_kind, a.out, off, result.x);
 			store_scalar(a.out_kind, a.out, off + a.batch_sample_count, result.y);
 		} else if (a.out_kind & 1) {
@@ -437,9 +444,14 @@ extern "C" hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s)
 	dim3 grid((groups + 3) / 4, a->channels, a->transmits);
 	size_t lds = (size_t)4 * (a->decimation * 64 + a->filter_length - 1) * 2 * sizeof(float);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
-	bool f16 = (a->in_kind >> 1) != 1;
-	if (f16) hipLaunchKernelGGL((filter_kernel<true>),  grid, dim3(256), lds, s, *a);
-	else     hipLaunchKernelGGL((filter_kernel<false>), grid, dim3(256), lds, s, *a);
+	#define BF_FILTER_CASE(kind) \
+		case kind: if (a->demodulate) hipLaunchKernelGGL((filter_kernel<kind, true>),  grid, dim3(256), lds, s, *a); \
+		           else               hipLaunchKernelGGL((filter_kernel<kind, false>), grid, dim3(256), lds, s, *a); break;
+	switch (a->in_kind) {
+	BF_FILTER_CASE(0) BF_FILTER_CASE(1) BF_FILTER_CASE(2) BF_FILTER_CASE(3) BF_FILTER_CASE(4) BF_FILTER_CASE(5)
+	default: return hipErrorInvalidValue;
+	}
+	#undef BF_FILTER_CASE
 	return hipGetLastError();
 }
 
