@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies, 5 LDS row-cache experiment")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="multi-GPU: broadcast and compute back to back on one stream instead of pipelined")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -270,8 +270,9 @@ def main():
         dist.destroy_process_group()
 
 
-PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel"]
-KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel"]
+PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
+              "factored kernel with LDS row cache"]
+KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel"]
 
 
 def measured_traffic(args, world, das_path):
