@@ -76,10 +76,12 @@ bool validate_pipeline(const int32_t *shaders, uint32_t shader_count, Beamformer
 		    !check(!bf_kind_complex[data_kind], BeamformerLibErrorKind_InvalidDemodulationDataKind))
 			return false;
 	}
-	/* the reference reads shaders[0] even when shader_count == 0; an empty pipeline cannot
-	 * start with Decode or Demodulate either way */
-	bool start_ok = shader_count > 0 && (shaders[0] == BeamformerShaderKind_Demodulate ||
-	                                     shaders[0] == BeamformerShaderKind_Decode);
+	/* the reference tests shaders[0] whatever shader_count is (lib .c:305-309): an empty pipeline
+	 * passes when the caller's array happens to start with Decode or Demodulate.  Kept as is --
+	 * callers pass the 16-entry array of BeamformerSimpleParameters -- and an empty plan is
+	 * legal here (no stage runs, the frame stays zero). */
+	bool start_ok = shaders && (shaders[0] == BeamformerShaderKind_Demodulate ||
+	                            shaders[0] == BeamformerShaderKind_Decode);
 	return check(start_ok, BeamformerLibErrorKind_InvalidStartShader);
 }
 

@@ -172,3 +172,91 @@ def test_reference_client_beamforms_through_the_server(name, server, oracle):
     assert lib_timings(C.byref(table), 20000), ref.beamformer_get_last_error_string()
     ids = [table.shader_ids[i] for i in range(table.shader_count)]
     assert int(P.ShaderKind.DAS) in ids
+
+
+def test_parameter_validation_agrees_with_the_compiled_reference_client(server, bflib):
+    """Differential test of the drop-in's validation: 400 random parameter sets -- many invalid:
+    counts past the limits, stage lists that start wrong, unknown stages and kinds, demodulation
+    of complex data -- pushed through the compiled reference client (talking to the server) and
+    through this library in process.  Same verdict and same error code every time
+    (validate_parameters / validate_pipeline order, lib/ogl_beamformer_lib.c:252-311)."""
+    ref = reference_client()
+    ours = bflib.library()
+    rng = np.random.default_rng(41)
+    base = cases.make("config1_small")
+    S, D = P.ShaderKind, P.DataKind
+    verdicts = {True: 0, False: 0}
+    for it in range(400):
+        bp = P.SimpleParameters.from_buffer_copy(bytes(base.bp))
+        n = int(rng.integers(0, 6))
+        pool = [int(S.Decode), int(S.Filter), int(S.Demodulate), int(S.DAS), int(S.Hilbert), int(S.Sum), 7, 11, -1]
+        weights = np.array([6, 4, 5, 6, 1, 1, 1, 1, 1], float)
+        stages = [int(rng.choice(pool, p=weights / weights.sum())) for _ in range(n)]
+        bp.compute_stages_count = int(rng.choice([n, n, n, 17, 0])) if rng.integers(0, 8) == 0 else n
+        for i, s in enumerate(stages[:16]):
+            bp.compute_stages[i] = s
+        bp.data_kind = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 9], p=[.2, .15, .15, .15, .15, .1, .05, .05]))
+        bp.channel_count = int(rng.choice([1, 16, 64, 256, 257, 0, 1000]))
+        bp.acquisition_count = int(rng.choice([1, 8, 128, 256, 257, 0]))
+        bp.sample_count = int(rng.choice([256, 4096, 0, 1]))
+        bp.decimation_rate = int(rng.integers(0, 5))
+        bp.raw_data_dimensions[0] = bp.sample_count * bp.acquisition_count
+        bp.raw_data_dimensions[1] = int(rng.choice([bp.channel_count, 256, 0]))
+        got_ref = bool(ref.beamformer_push_simple_parameters(C.byref(bp)))
+        err_ref = int(ref.beamformer_get_last_error())
+        got = bool(ours.beamformer_push_simple_parameters(C.byref(bp)))
+        err = int(ours.beamformer_get_last_error())
+        assert got == got_ref, (it, stages, bp.data_kind, bp.channel_count, bp.acquisition_count, bp.sample_count, err, err_ref)
+        if not got:
+            assert err == err_ref, (it, stages, bp.data_kind, P.LibError(err).name, P.LibError(err_ref).name)
+        verdicts[got] += 1
+    assert verdicts[True] >= 40 and verdicts[False] >= 40, verdicts       # both outcomes were exercised
+
+
+def test_array_pushes_and_data_size_checks_agree_with_the_reference_client(server, bflib):
+    """the remaining client-side checks (lib .c:438-464 array pushes, :410-429 filters, :503-511 data
+    sizes, :239-250 block reservation), same differential arrangement"""
+    ref = reference_client()
+    ours = bflib.library()
+    ref.beamformer_push_focal_vectors.argtypes = [C.POINTER(C.c_float), C.c_uint32]
+    rng = np.random.default_rng(43)
+
+    def both(name, *args):
+        a = bool(getattr(ref, name)(*args)); ea = int(ref.beamformer_get_last_error())
+        b = bool(getattr(ours, name)(*args)); eb = int(ours.beamformer_get_last_error())
+        assert a == b, (name, args[1:], a, b, P.LibError(ea).name, P.LibError(eb).name)
+        if not a:
+            assert ea == eb, (name, args[1:], P.LibError(ea).name, P.LibError(eb).name)
+        return a
+
+    i16 = (C.c_int16 * 512)(*range(512))
+    f32 = (C.c_float * 1024)()
+    u8 = (C.c_uint8 * 512)()
+    for count in (0, 1, 255, 256, 257, 512):
+        both("beamformer_push_channel_mapping", i16, count)
+        both("beamformer_push_sparse_elements", i16, count)
+        both("beamformer_push_focal_vectors", f32, count)
+        both("beamformer_push_transmit_receive_orientations", u8, count)
+    for kind in (0, 1, 2, 7, -1):
+        fp = P.FilterParameters()
+        fp.kind = kind
+        fp.sampling_frequency = 12.5e6
+        fp.kaiser.cutoff_frequency, fp.kaiser.beta, fp.kaiser.length = 2e6, 5.0, 16
+        both("beamformer_create_filter", C.byref(fp), 0, 0)
+    for stages, count, kind in (([0, 3], 2, 0), ([2, 3], 2, 1), ([3], 1, 0), ([0] * 17, 17, 0), ([2, 0, 3], 3, 4), ([0, 9], 2, 0), ([0, 3], 2, 6)):
+        arr = (C.c_int32 * 32)(*stages)
+        both("beamformer_push_pipeline", arr, count, kind)
+
+    # data size validation against the parameters in force (no compute needed to be rejected)
+    acq = cases.make("config1_small")
+    for lib in (ref, ours):
+        assert lib.beamformer_push_simple_parameters(C.byref(acq.bp))
+    rf = np.ascontiguousarray(acq.rf)
+    ptr = rf.ctypes.data_as(C.c_void_p)
+    for size, tag, slot in ((rf.nbytes - 2, 0, 0), (rf.nbytes + 2, 0, 0), (0, 0, 0), (rf.nbytes, 9, 0), (rf.nbytes, 0, 5)):
+        a = bool(ref.beamformer_push_data_with_compute(ptr, size, tag, slot)); ea = int(ref.beamformer_get_last_error())
+        b = bool(ours.beamformer_push_data_with_compute(ptr, size, tag, slot)); eb = int(ours.beamformer_get_last_error())
+        assert not a and not b, (size, tag, slot, a, b)
+        import torch
+        if torch.cuda.is_available() or eb != int(P.LibError.SharedMemory):     # without a device ours stops earlier: no backend
+            assert ea == eb, (size, tag, slot, P.LibError(ea).name, P.LibError(eb).name)
