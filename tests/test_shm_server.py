@@ -260,3 +260,20 @@ def test_array_pushes_and_data_size_checks_agree_with_the_reference_client(serve
         import torch
         if torch.cuda.is_available() or eb != int(P.LibError.SharedMemory):     # without a device ours stops earlier: no backend
             assert ea == eb, (size, tag, slot, P.LibError(ea).name, P.LibError(eb).name)
+
+
+@pytest.mark.gpu
+def test_reference_client_one_shot_call_through_the_server(server, oracle):
+    """beamformer_beamform_data of the reference client (lib .c:704-736): parameters, RF, compute and
+    the pulled image in one call, through shared memory"""
+    ref = reference_client()
+    ref.beamformer_beamform_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32]
+    acq = cases.make("config2_small")
+    assert ref.beamformer_create_filter(C.byref(acq.filters[0]), 0, 0), ref.beamformer_get_last_error_string()
+    want, _ = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    out = np.zeros(want.shape, np.complex64)
+    rf = np.ascontiguousarray(acq.rf)
+    ref.beamformer_set_global_timeout(20000)
+    assert ref.beamformer_beamform_data(C.byref(acq.bp), rf.ctypes.data_as(C.c_void_p), rf.nbytes,
+                                        out.ctypes.data_as(C.c_void_p), 20000), ref.beamformer_get_last_error_string()
+    assert np.abs(out - want).max() <= cases.tolerance(acq) * np.abs(want).max()
