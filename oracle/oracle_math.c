@@ -2,6 +2,7 @@
  * Restates math.c and beamformer_core.c:366-398 of the reference.  Pinned against the
  * compiled reference by tests/test_oracle_math.py using tests/golden/host_math.npz. */
 #include "oracle.h"
+#include "oracle_f16.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -286,4 +287,17 @@ void oracle_das_transform(const float *mn, const float *mx, int *points, float *
 	case 3: oracle_das_transform_3d(mn, mx, out);       break;
 	default: memset(out, 0, 16 * sizeof(float));        break;
 	}
+}
+
+
+/* the software binary16 of oracle_f16.h, exported so that tests can pin it against an independent
+ * IEEE implementation (numpy) */
+void oracle_f16_bits_from_f32(const float *in, uint16_t *out, uint64_t n)
+{
+	for (uint64_t i = 0; i < n; i++) out[i] = oracle_f32_to_f16_bits(in[i]);
+}
+
+void oracle_f16_roundtrip(const uint16_t *bits, float *out, uint64_t n)
+{
+	for (uint64_t i = 0; i < n; i++) out[i] = oracle_f16_bits_to_f32(bits[i]);
 }

@@ -173,3 +173,33 @@ def test_coherency_weighting_is_componentwise_and_nan_on_empty(oracle):
     # weighted = (re^2, im^2)/inc >= 0 componentwise wherever it is defined
     assert (frame.real[ok] >= 0).all() and (frame.imag[ok] >= 0).all()
     assert np.all(plain[~ok] == 0)
+
+
+def test_software_binary16_is_ieee(oracle):
+    """Every f16-staged tolerance rests on oracle_f16.h: all 65536 bit patterns widen exactly as
+    numpy's IEEE float16 does, and a million random floats (plus overflow, subnormal and tie
+    cases) narrow to the same bits (round to nearest even)."""
+    import ctypes as C
+    L = oracle.library()
+    L.oracle_f16_roundtrip.argtypes = [C.POINTER(C.c_uint16), C.POINTER(C.c_float), C.c_uint64]
+    L.oracle_f16_bits_from_f32.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint16), C.c_uint64]
+    bits = np.arange(65536, dtype=np.uint16)
+    wide = np.zeros(65536, np.float32)
+    L.oracle_f16_roundtrip(bits.ctypes.data_as(C.POINTER(C.c_uint16)), wide.ctypes.data_as(C.POINTER(C.c_float)), bits.size)
+    want = bits.view(np.float16).astype(np.float32)
+    assert np.array_equal(wide.view(np.uint32)[~np.isnan(want)], want.view(np.uint32)[~np.isnan(want)])
+    assert np.all(np.isnan(wide[np.isnan(want)]))
+    rng = np.random.default_rng(3)
+    with np.errstate(invalid="ignore", over="ignore"):
+      x = np.concatenate([
+        rng.standard_normal(400000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 400000).astype(np.float32),
+        rng.uniform(-70000, 70000, 300000).astype(np.float32),
+        (rng.integers(0, 65536, 200000).astype(np.uint16).view(np.float16).astype(np.float32)
+         * (1 + rng.choice([-2.0 ** -11, 0, 2.0 ** -11, 2.0 ** -12], 200000)).astype(np.float32)),     # around ties
+        np.array([0.0, -0.0, 65504, 65519.99, 65520, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, np.inf, -np.inf], np.float32)])
+    x = x[~np.isnan(x)]
+    got = np.zeros(x.size, np.uint16)
+    L.oracle_f16_bits_from_f32(x.ctypes.data_as(C.POINTER(C.c_float)), got.ctypes.data_as(C.POINTER(C.c_uint16)), x.size)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:5]
