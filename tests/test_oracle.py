@@ -203,3 +203,27 @@ def test_software_binary16_is_ieee(oracle):
     with np.errstate(over="ignore"):
         ref = x.astype(np.float16).view(np.uint16)
     assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:5]
+
+
+def test_oracle_output_is_frozen(oracle):
+    """The oracle is the yardstick of every GPU parity test: its output for twelve named
+    acquisitions is frozen in tests/golden/oracle_frames.npz (made by make_oracle_frames.py), so a
+    change to oracle/*.c that moves any result shows up here first."""
+    import os
+    from tests import cases
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_frames.npz"))
+    names = [k for k in golden.files if not k.endswith(".pairs")]
+    assert len(names) == 12
+    for name in names:
+        acq = cases.make(name)
+        frame, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+        want = golden[name]
+        if frame.shape[0] > 16:
+            frame = frame[::8]                                             # as stored
+        assert frame.shape == want.shape and frame.dtype == want.dtype
+        assert np.array_equal(np.isnan(frame), np.isnan(want)), name
+        ok = ~np.isnan(want)
+        # same C, same flags (-ffp-contract=off): equal to the last bit here; a libm of another
+        # vintage may move sin/cos by an ulp, hence the tiny allowance
+        assert np.abs(frame[ok] - want[ok]).max() <= 1e-6 * np.abs(want[ok]).max(), name
+        assert int(pairs) == int(golden[name + ".pairs"]), name
