@@ -107,6 +107,17 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_sum_last_frames(uint32_t count, vo
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold_db, float gamma, float db_cutoff,
                                                                 float *out, uint64_t out_floats);
 
+/* The Hilbert stage.  In the reference BeamformerShaderKind_Hilbert is served by an out-of-tree
+ * CUDA routine (cuda_hilbert, beamformer_internal.h:233-261) that the snapshot cannot load:
+ * capabilities.hilbert is 0 (beamformer.c:262-263) and a pipeline naming the stage is refused with
+ * InvalidComputeStage -- which is also what this library does by default.  Enabling this switch
+ * makes the stage available with the library's OWN definition (there is nothing to be identical
+ * to: parity unpinned): the analytic signal x + j H{x} along samples by a 63-tap type-III FIR
+ * Hilbert transformer (Hamming window), real part = the input delayed by 31 samples, the delay added
+ * to the DAS time offset; real input only; as in the reference's planner the stage is dropped when
+ * the pipeline also demodulates (beamformer_core.c:567) and makes the pipeline IQ (:589). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
+
 /* Select the DAS implementation: 0 = automatic (the separable-delay gather kernel when the
  * geometry allows, else the per-voxel factored kernel for RCA-family and FORCES frames with
  * three or more transmits, else the general kernel), 1 = always the general kernel, 4 = the

@@ -120,6 +120,7 @@ hipError_t bf_launch_ingest(const BfIngestArgs *a, hipStream_t s);
 hipError_t bf_launch_reshape(const BfReshapeArgs *a, hipStream_t s);
 hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s);
 hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s);
+hipError_t bf_launch_hilbert(const BfFilterArgs *a, hipStream_t s);
 hipError_t bf_launch_das(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);

@@ -84,6 +84,7 @@ struct Context {
 	uint64_t       frame_ring_bytes = 0;                       /* beamformed_frame_buffer_size */
 	uint32_t       das_path_mode = 0;
 	bool           count_pairs = false;
+	bool           hilbert_enabled = false;                    /* beamformer_hip_enable_hilbert */
 
 	/* device state */
 	int          requested_device = -1;

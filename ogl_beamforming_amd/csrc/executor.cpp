@@ -155,7 +155,7 @@ static PlanState *commit_block(uint32_t block)
 
 	std::string error;
 	Plan plan;
-	if (!build_plan(pb, plan, error)) { ps.valid = false; ps.error = error; return nullptr; }
+	if (!build_plan(pb, plan, error, c.hilbert_enabled)) { ps.valid = false; ps.error = error; return nullptr; }
 	ps.plan = std::move(plan);
 	const BeamformerParameters &bp = pb.parameters;
 	hipStream_t s = c.stream;
@@ -203,7 +203,8 @@ static PlanState *commit_block(uint32_t block)
 	ps.taps.assign(ps.plan.stages.size(), DeviceBuffer{});
 	for (size_t i = 0; i < ps.plan.stages.size(); i++) {
 		const Stage &st = ps.plan.stages[i];
-		if (st.kind == BeamformerShaderKind_Filter || st.kind == BeamformerShaderKind_Demodulate) {
+		if (st.kind == BeamformerShaderKind_Filter || st.kind == BeamformerShaderKind_Demodulate ||
+		    st.kind == BeamformerShaderKind_Hilbert) {
 			/* taps, then -- for Demodulate -- the window-local phasors {cos, -sin}(2 pi fd index / (fs/2))
 			 * of filter.glsl:99-107, in the kernel's own f32 expression */
 			ps.tap_tables.emplace_back(st.filter.taps);
@@ -522,6 +523,19 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			for (int k = 0; k < 3; k++) a.out_stride[k] = st.out_stride[k];
 			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
 			ok &= HIP_OK(bf_launch_decode(&a, s));
+			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+		}break;
+		case BeamformerShaderKind_Hilbert:{
+			BfFilterArgs a{};
+			a.in = cur; a.out = c.scratch[toggle].ptr;
+			a.coefficients  = (const float *)ps->taps[i].ptr;
+			a.filter_length = (uint32_t)st.filter.length;
+			a.sample_count  = Sd;
+			for (int k = 0; k < 3; k++) { a.in_stride[k] = st.in_stride[k]; a.out_stride[k] = st.out_stride[k]; }
+			a.in_elements = cur_elements_bytes / bf_kind_byte_size[st.in_kind];
+			a.channels = C; a.transmits = A;
+			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
+			ok &= HIP_OK(bf_launch_hilbert(&a, s));
 			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
 		}break;
 		case BeamformerShaderKind_Filter:

@@ -192,6 +192,23 @@ void m4_mul(const float *a, const float *b, float *out)
 	std::memcpy(out, r, sizeof(r));
 }
 
+/* The build-defined Hilbert stage (include/ogl_beamformer_hip.h, beamformer_hip_enable_hilbert):
+ * taps of the analytic-signal FIR  y[n] = sum_{j<63} h[j] x[n - 62 + j]:  h[31] = 1 and, for odd m,
+ * h[31 + m] = -j (2 / (pi m)) w[31 + m] with a Hamming window w -- a type-III Hilbert transformer
+ * next to a pure delay of 31 samples. */
+std::vector<float> hilbert_fir()
+{
+	const int L = kHilbertLength, M = (kHilbertLength - 1) / 2;
+	std::vector<float> taps(2 * L);
+	for (int j = 0; j < L; j++) {
+		int    m = j - M;
+		double w = 0.54 - 0.46 * std::cos(2.0 * 3.14159265358979323846 * (double)j / (double)(L - 1));
+		taps[2 * j]     = j == M ? 1.0f : 0.0f;
+		taps[2 * j + 1] = (m & 1) ? (float)(-(2.0 / (3.14159265358979323846 * (double)m)) * w) : 0.0f;
+	}
+	return taps;
+}
+
 /* das_transform (math.c:906-920) with das_output_dimension (:799-829): the grid keeps its
  * extents but is renumbered so that a line is (n,1,1) and a plane is (a,b,1); a plane is the
  * world x-z plane at y = 0 (das_transform_2d_xz :872-877 -> das_transform_2d_with_normal

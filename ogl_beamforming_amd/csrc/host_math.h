@@ -21,6 +21,8 @@ std::vector<float> rf_chirp(float fmin, float fmax, float fs, int length, bool r
 std::vector<float> baseband_chirp(float fmin, float fmax, float fs, int length, bool reverse, float scale);
 float              filter_first_moment(const std::vector<float> &h, bool complex_taps, float fs);
 bool               filter_create(const BeamformerFilterParameters &fp, Filter &out);
+constexpr int      kHilbertLength = 63;
+std::vector<float> hilbert_fir();                                     /* 2*63 floats (re, im), correlation order */
 void               m4_mul(const float *a, const float *b, float *out);
 void               das_transform(const float mn[3], const float mx[3], int32_t points[3], float out16[16]);
 

@@ -70,7 +70,8 @@ bool validate_pipeline(const int32_t *shaders, uint32_t shader_count, Beamformer
 	for (uint32_t i = 0; i < shader_count; i++) {
 		bool stage_ok = shaders[i] >= BeamformerShaderKind_ComputeFirst && shaders[i] <= BeamformerShaderKind_ComputeLast;
 		if (!check(stage_ok, BeamformerLibErrorKind_InvalidComputeStage)) return false;
-		if (shaders[i] == BeamformerShaderKind_Hilbert && !check(false, BeamformerLibErrorKind_InvalidComputeStage))
+		if (shaders[i] == BeamformerShaderKind_Hilbert &&
+		    !check(ctx().hilbert_enabled, BeamformerLibErrorKind_InvalidComputeStage))     /* capabilities.hilbert */
 			return false;
 		if (shaders[i] == BeamformerShaderKind_Demodulate &&
 		    !check(!bf_kind_complex[data_kind], BeamformerLibErrorKind_InvalidDemodulationDataKind))
@@ -437,6 +438,14 @@ uint32_t beamformer_hip_display_last_frame(float threshold_db, float gamma, floa
 	return display_last_frame(threshold_db, gamma, db_cutoff, out, out_floats);
 }
 
+uint32_t beamformer_hip_enable_hilbert(uint32_t enable)
+{
+	Context &c = ctx();
+	c.hilbert_enabled = enable != 0;
+	for (auto &b : c.blocks) b.dirty |= Dirty_ComputePipeline;
+	return 1;
+}
+
 uint32_t beamformer_hip_set_das_path(uint32_t mode) { ctx().das_path_mode = mode; return 1; }
 
 void beamformer_hip_host_das_transform(const float min_coordinate[3], const float max_coordinate[3],
@@ -469,7 +478,7 @@ uint32_t beamformer_hip_describe_plan(uint32_t parameter_slot, BeamformerHipPlan
 	if (!valid_parameter_block(parameter_slot)) return 0;
 	Plan plan;
 	std::string error;
-	if (!build_plan(ctx().blocks[parameter_slot], plan, error)) return check(false, BeamformerLibErrorKind_InvalidComputeStage);
+	if (!build_plan(ctx().blocks[parameter_slot], plan, error, ctx().hilbert_enabled)) return check(false, BeamformerLibErrorKind_InvalidComputeStage);
 	std::memset(out, 0, sizeof(*out));
 	out->stage_count = (uint32_t)plan.stages.size();
 	for (size_t i = 0; i < plan.stages.size() && i < BeamformerMaxComputeShaderStages; i++) {

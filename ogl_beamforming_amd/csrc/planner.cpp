@@ -39,7 +39,7 @@ void copy3(int64_t *d, const int64_t *s)     { d[0] = s[0]; d[1] = s[1]; d[2] = 
 
 } // namespace
 
-bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
+bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error, bool allow_hilbert)
 {
 	const BeamformerParameters &bp = pb.parameters;
 	plan = Plan{};
@@ -50,7 +50,7 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 		demodulate |= pb.shaders[i] == BeamformerShaderKind_Demodulate;
 	}
 	if (demodulate) hilbert = false;                                   /* :567 */
-	if (hilbert) { error = "Hilbert stage is not available (capabilities.hilbert = 0)"; return false; }
+	if (hilbert && !allow_hilbert) { error = "Hilbert stage is not available (capabilities.hilbert = 0)"; return false; }
 
 	const uint32_t S = bp.sample_count, A = bp.acquisition_count, C = bp.channel_count;
 	if (!S || !A || !C || C > BeamformerMaxChannelCount || A > BeamformerMaxEmissionsCount) {
@@ -69,7 +69,7 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 		samples /= 2 * D;
 		fs      /= (float)(2 * D);
 	}
-	plan.iq_pipeline = bf_kind_complex[in_kind] != 0;                  /* :589 (hilbert never runs) */
+	plan.iq_pipeline = bf_kind_complex[in_kind] != 0 || hilbert;       /* :589 */
 	const int das_kind = plan.iq_pipeline ? BeamformerDataKind_Float32Complex : BeamformerDataKind_Float32;
 	plan.pipeline_data_kind = in_kind;
 	plan.channels = C; plan.acquisitions = A; plan.raw_samples = S;
@@ -87,7 +87,7 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 
 	for (uint32_t it = 0; it < pb.shader_count; it++) {
 		int shader = pb.shaders[it];
-		if (shader == BeamformerShaderKind_Hilbert) continue;
+		if (shader == BeamformerShaderKind_Hilbert && !hilbert) continue;   /* :625 */
 		if (shader == BeamformerShaderKind_Decode && bp.decode_mode == BeamformerDecodeMode_None) continue;
 		if (shader == BeamformerShaderKind_Sum || shader == BeamformerShaderKind_MinMax) continue;
 
@@ -215,6 +215,15 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error)
 				return false;
 			}
 			time_offset += st.filter.time_delay;                         /* :835 */
+		}break;
+		case BeamformerShaderKind_Hilbert:{
+			/* build-defined stage (host_math.cpp hilbert_fir): real input only, 31 samples of delay */
+			if (bf_kind_complex[st.in_kind]) { error = "the Hilbert stage needs real input"; return false; }
+			st.filter.taps = hilbert_fir();
+			st.filter.length = kHilbertLength;
+			st.filter.complex_taps = true;
+			st.filter.time_delay = (float)((kHilbertLength - 1) / 2) / fs;
+			time_offset += st.filter.time_delay;
 		}break;
 		case BeamformerShaderKind_DAS:{
 			plan.das_index = (int)plan.stages.size();

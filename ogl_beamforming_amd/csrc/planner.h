@@ -68,7 +68,7 @@ struct Plan {
 /* Restates plan_compute_pipeline (beamformer_core.c:553-1013) for a backend that runs every
  * receive channel in one pass: the reference's 16-channel chunk becomes channel_count.
  * Returns false with `error` set when the pipeline cannot run. */
-bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error);
+bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error, bool allow_hilbert = false);
 
 } // namespace bf
 #endif

@@ -455,6 +455,59 @@ extern "C" hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s)
 	return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------ Hilbert (build-defined) */
+
+/* Analytic signal along samples: y[n] = sum_{j<L} h[j] x[n - (L-1) + j] with the complex taps of
+ * host_math.cpp hilbert_fir (real part = x delayed by 31 samples, imaginary part = its Hilbert
+ * transform).  The reference has no implementation to follow (include/ogl_beamformer_hip.h).
+ * Same shape as the filter kernel: a wave owns 64 outputs and an LDS window of 64 + L - 1 real
+ * samples; f32 products and sums; samples outside the row are zero. */
+__global__ __launch_bounds__(256) void hilbert_kernel(const BfFilterArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) float filter_lds[];
+	const uint32_t L = a.filter_length, window = 64 + L - 1;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t wg   = blockIdx.x * 4 + wave;
+	const uint32_t channel = blockIdx.y, transmit = blockIdx.z;
+	float *w = filter_lds + (size_t)wave * window;
+	const int64_t row = a.in_stride[1] * channel + a.in_stride[2] * transmit;
+	const int64_t first = (int64_t)wg * 64 - (int64_t)(L - 1);
+	for (uint32_t index = lane; index < window; index += 64) {
+		int64_t s = first + index;
+		float v = 0.f;
+		if (s >= 0 && s < (int64_t)a.sample_count) {
+			int64_t e = row + a.in_stride[0] * s;
+			if (e < a.in_elements) v = load_element(a.in_kind, a.in, e).x;
+		}
+		w[index] = v;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+	const uint32_t n = wg * 64 + lane;
+	if (n < a.sample_count) {
+		f32x2 y = {0.f, 0.f};
+		for (uint32_t j = 0; j < L; j++) {
+			float x = w[lane + j];
+			y.x += a.coefficients[2 * j] * x;
+			y.y += a.coefficients[2 * j + 1] * x;
+		}
+		store_element(a.out_kind, a.out, a.out_stride[1] * channel + a.out_stride[2] * transmit + a.out_stride[0] * n, y);
+	}
+}
+
+extern "C" hipError_t bf_launch_hilbert(const BfFilterArgs *a, hipStream_t s)
+{
+	if (!a->sample_count || !a->channels || !a->transmits) return hipSuccess;
+	uint32_t groups = (a->sample_count + 63) / 64;
+	dim3 grid((groups + 3) / 4, a->channels, a->transmits);
+	size_t lds = (size_t)4 * (64 + a->filter_length - 1) * sizeof(float);
+	hipLaunchKernelGGL(hilbert_kernel, dim3(grid), dim3(256), lds, s, *a);
+	return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------ sum */
 
 /* shaders/sum.glsl:7-12: out += prescale * in over every component of the frame.  The

@@ -105,6 +105,7 @@ def _load():
         "beamformer_hip_frame_min_max": (u32, [C.POINTER(C.c_float)]),
         "beamformer_hip_sum_last_frames": (u32, [u32, vp, u64]),
         "beamformer_hip_display_last_frame": (u32, [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), u64]),
+        "beamformer_hip_enable_hilbert": (u32, [u32]),
         "beamformer_hip_set_das_path": (u32, [u32]),
         "beamformer_hip_zbp_parameters": (u32, [vp, u64, C.POINTER(P.SimpleParameters), C.POINTER(P.HipZbpPayload)]),
         "beamformer_hip_zbp_load": (u32, [C.c_char_p, u32, C.POINTER(P.SimpleParameters), C.POINTER(vp), C.POINTER(u64)]),

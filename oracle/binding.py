@@ -85,6 +85,10 @@ def library():
         lib.oracle_das_transform.argtypes = [fp, fp, C.POINTER(C.c_int), fp]
         lib.oracle_das_transform_2d.argtypes = [C.c_int, fp, fp, C.c_float, fp]
         lib.oracle_das_transform_3d.argtypes = [fp, fp, fp]
+        lib.oracle_enable_hilbert.argtypes = [C.c_int]
+        lib.oracle_enable_hilbert.restype = None
+        lib.oracle_hilbert_fir.argtypes = [fp]
+        lib.oracle_hilbert_fir.restype = None
         lib.oracle_sum.argtypes = [fp, fp, C.c_float, C.c_uint64]
         lib.oracle_sum.restype = None
         lib.oracle_display.argtypes = [fp, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_float, fp]
@@ -185,3 +189,8 @@ def display(frame, threshold_db=55.0, gamma=1.0, db_cutoff=0.0):
     lib.oracle_display(frame.ctypes.data_as(fp), frame.size, int(np.iscomplexobj(frame)), threshold_db, gamma, db_cutoff,
                        out.ctypes.data_as(fp))
     return out
+
+
+def enable_hilbert(enable=True):
+    """the build-defined Hilbert stage (oracle.h); off by default, as capabilities.hilbert is 0"""
+    library().oracle_enable_hilbert(1 if enable else 0)

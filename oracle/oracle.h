@@ -109,6 +109,19 @@ void oracle_filter(const OracleFilter *f, const void *in, void *out, uint32_t ou
 void oracle_coherency_weighting(float *coherent, const float *incoherent, uint32_t voxels,
                                 int complex_data, float scale);
 
+/* BUILD-DEFINED Hilbert stage (PARITY UNPINNED).  The reference's Hilbert stage is an out-of-tree
+ * CUDA routine that its snapshot cannot load (capabilities.hilbert = 0, beamformer.c:262-263), so
+ * there is nothing to restate.  This build defines it as the analytic signal x + j H{x} along
+ * samples with a 63-tap type-III FIR Hilbert transformer, Hamming window:
+ *   y[n] = sum_{j<63} h[j] x[n - 62 + j],  h[31] = 1,  h[31 + m] = -j (2 / (pi m)) w[31 + m] for odd m,
+ * i.e. real part = the input delayed by 31 samples, imaginary part = its Hilbert transform with
+ * the same delay, which the planner adds to the DAS time offset (31 / fs).  Off unless
+ * oracle_enable_hilbert(1) (the product: beamformer_hip_enable_hilbert). */
+#define ORACLE_HILBERT_LENGTH 63
+void oracle_enable_hilbert(int enable);
+void oracle_hilbert_fir(float *taps_re_im /* 2 * ORACLE_HILBERT_LENGTH */);
+void oracle_hilbert(const OracleFilter *f, const void *in, void *out);
+
 /* sum.glsl:7-12, one pass: out += prescale * in over `floats` components */
 void oracle_sum(float *out, const float *in, float prescale, uint64_t floats);
 

@@ -301,3 +301,16 @@ void oracle_f16_roundtrip(const uint16_t *bits, float *out, uint64_t n)
 {
 	for (uint64_t i = 0; i < n; i++) out[i] = oracle_f16_bits_to_f32(bits[i]);
 }
+
+
+/* oracle.h: the build-defined Hilbert FIR, stored in the correlation order oracle_hilbert uses */
+void oracle_hilbert_fir(float *taps)
+{
+	const int L = ORACLE_HILBERT_LENGTH, M = (ORACLE_HILBERT_LENGTH - 1) / 2;
+	for (int j = 0; j < L; j++) {
+		int    m = j - M;
+		double w = 0.54 - 0.46 * cos(2.0 * 3.14159265358979323846 * (double)j / (double)(L - 1));
+		taps[2 * j]     = j == M ? 1.0f : 0.0f;
+		taps[2 * j + 1] = (m & 1) ? (float)(-(2.0 / (3.14159265358979323846 * (double)m)) * w) : 0.0f;
+	}
+}

@@ -30,6 +30,9 @@ typedef struct Node {
 static int stride_dont_care(const int *s) { return s[0] == 0 || s[1] == 0 || s[2] == 0; }
 static int stride_equal(const int *a, const int *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
 
+static int g_hilbert_enabled;
+void oracle_enable_hilbert(int enable) { g_hilbert_enabled = enable != 0; }
+
 int oracle_plan(const OracleParameterBlock *pb, OraclePlan *plan)
 {
 	const BeamformerParameters *bp = &pb->parameters;
@@ -41,6 +44,7 @@ int oracle_plan(const OracleParameterBlock *pb, OraclePlan *plan)
 		if (pb->shaders[i] == BeamformerShaderKind_Demodulate) demodulate  = 1;
 	}
 	if (demodulate) run_hilbert = 0;
+	if (run_hilbert && !g_hilbert_enabled) return 0;                       /* capabilities.hilbert = 0: the client refuses the stage */
 
 	float fs = bp->sampling_frequency;
 	int   input_sample_count = (int)bp->sample_count;
@@ -166,6 +170,10 @@ int oracle_plan(const OracleParameterBlock *pb, OraclePlan *plan)
 			if (oracle_filter_create(fp, coeffs, 8192, &delay) < 0) return 0;
 			time_offset += delay;
 		}break;
+		case BeamformerShaderKind_Hilbert:{                                /* build-defined, oracle.h */
+			if (kind_complex[st->in_kind]) return 0;                         /* needs real input */
+			time_offset += (float)((ORACLE_HILBERT_LENGTH - 1) / 2) / fs;
+		}break;
 		case BeamformerShaderKind_DAS:{                                    /* :882, :906-917 */
 			plan->first_image_stage = plan->stage_count - 1 + 1;
 			memcpy(plan->das_voxel_transform, bp->das_voxel_transform, sizeof(plan->das_voxel_transform));
@@ -256,6 +264,20 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		/* output_element_offset selects the slot inside the one bound buffer (:1338-1342) */
 		uint8_t *out = (slot + 1) == das_index ? pp_das : pp_out;
 		oracle_filter(&f, in, out, 0);
+		e->input_index = !e->input_index;
+	}break;
+	case BeamformerShaderKind_Hilbert:{
+		float taps[2 * ORACLE_HILBERT_LENGTH];
+		oracle_hilbert_fir(taps);
+		OracleFilter f = {0};
+		f.filter_length = ORACLE_HILBERT_LENGTH; f.complex_filter = 1; f.coefficients = taps;
+		f.sample_count = plan->input_sample_count;
+		memcpy(f.in_stride,  st->in_stride,  sizeof(f.in_stride));
+		memcpy(f.out_stride, st->out_stride, sizeof(f.out_stride));
+		f.in_kind = st->in_kind; f.out_kind = st->out_kind;
+		f.channels = Cn; f.transmits = A;
+		const void *in = slot == 0 ? (const void *)rf_pointer : (const void *)pp_in;
+		oracle_hilbert(&f, in, (slot + 1) == das_index ? pp_das : pp_out);
 		e->input_index = !e->input_index;
 	}break;
 	case BeamformerShaderKind_Reshape:{

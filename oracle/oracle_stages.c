@@ -254,6 +254,28 @@ void oracle_coherency_weighting(float *coherent, const float *incoherent, uint32
 		}
 }
 
+/* oracle.h: y[n] = sum_j h[j] x[n - (L-1) + j], real x (the real component of whatever kind
+ * arrives), complex f32-accumulated y stored in the output kind; samples outside the row are 0 */
+void oracle_hilbert(const OracleFilter *f, const void *in, void *out)
+{
+	const int L = f->filter_length;
+	for (int t = 0; t < f->transmits; t++)
+	for (int c = 0; c < f->channels; c++)
+	for (int n = 0; n < f->sample_count; n++) {
+		float re = 0.f, im = 0.f;
+		for (int j = 0; j < L; j++) {
+			int s = n - (L - 1) + j;
+			if (s < 0 || s >= f->sample_count) continue;
+			float x[2];
+			load_element(f->in_kind, in, (int64_t)f->in_stride[0] * s + (int64_t)f->in_stride[1] * c + (int64_t)f->in_stride[2] * t, x);
+			re += f->coefficients[2 * j]     * x[0];
+			im += f->coefficients[2 * j + 1] * x[0];
+		}
+		float y[2] = {re, im};
+		store_element(f->out_kind, out, (int64_t)f->out_stride[0] * n + (int64_t)f->out_stride[1] * c + (int64_t)f->out_stride[2] * t, y);
+	}
+}
+
 void oracle_sum(float *out, const float *in, float prescale, uint64_t floats)
 {
 	for (uint64_t i = 0; i < floats; i++) out[i] = out[i] + prescale * in[i];
