@@ -138,9 +138,13 @@ def main():
             landed[k].record(comm)
         state["issued"] += 1
 
+    min_max = (C.c_float * 2)()
+
     def push(buf):
         ok = L.beamformer_hip_push_device_data_with_compute(C.c_void_p(buf.data_ptr()), buf.numel(), 0, 0)
         assert ok, lib.last_error()
+        if args.config == 5:                       # BASELINE configs[4] ends in min_max: part of the step
+            assert L.beamformer_hip_frame_min_max(min_max), lib.last_error()
 
     def step():
         if pipelined:
