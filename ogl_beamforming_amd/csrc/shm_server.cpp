@@ -133,6 +133,9 @@ struct Server {
 	ShmHeader *sm = nullptr;
 	uint64_t   size = 0;
 	void      *rf_ring[BeamformerMaxRawDataFramesInFlight] = {};
+	hipStream_t stream = nullptr;                                /* the library runs on this stream */
+	hipEvent_t  read_done[BeamformerMaxRawDataFramesInFlight] = {};   /* the frame that read rf_ring[i] in place has finished */
+	bool        read_pending[BeamformerMaxRawDataFramesInFlight] = {};
 	uint64_t   rf_ring_bytes = 0, rf_active_size = 0;
 	uint64_t   insertion_index = 0, compute_index = 0;
 	uint32_t   rf_block = 0;
@@ -140,6 +143,14 @@ struct Server {
 	ShmBlock *block(uint32_t i) { return reinterpret_cast<ShmBlock *>(reinterpret_cast<uint8_t *>(sm + 1) + (size_t)i * sizeof(ShmBlock)); }
 	/* beamformer_shared_memory_data_pointer (beamformer_shared_memory.c:280-297): the client
 	 * re-creates an Arena header behind the last block and aligns the payload to 4 KiB */
+	uint64_t payload_offset() const
+	{
+		uint64_t off = sizeof(ShmHeader) + (uint64_t)sm->reserved_parameter_blocks * sizeof(ShmBlock) + kArenaHeaderBytes;
+		return (off + 4095) & ~4095ull;
+	}
+	/* bytes of the scratch arena a client may have filled / may be handed: every size that
+	 * arrives through the region is checked against this before it is used */
+	uint64_t payload_capacity() const { uint64_t off = payload_offset(); return off < size ? size - off : 0; }
 	uint8_t *payload()
 	{
 		uint64_t off = sizeof(ShmHeader) + (uint64_t)sm->reserved_parameter_blocks * sizeof(ShmBlock) + kArenaHeaderBytes;
@@ -200,14 +211,20 @@ void handle_upload(Server &s, uint64_t rf_block_rf_size)
 	uint32_t block = (uint32_t)(rf_block_rf_size >> 32);
 	uint64_t size  = rf_block_rf_size & 0xFFFFFFFFull;
 	take_lock(&sm->locks[Lock_ScratchSpace], -1);
-	bool ok = true;
+	bool ok = size <= s.payload_capacity() && sm->reserved_parameter_blocks <= BeamformerMaxParameterBlocks;
+	if (!ok) size = 0;
 	uint64_t need = (size + 63) & ~63ull;
 	if (need > s.rf_ring_bytes) {
+		beamformer_hip_synchronize();
+		for (auto &pending : s.read_pending) pending = false;
 		for (auto &p : s.rf_ring) { if (p) (void)hipFree(p); p = nullptr; }
 		for (auto &p : s.rf_ring) ok &= hipMalloc(&p, need + 64) == hipSuccess;
 		s.rf_ring_bytes = ok ? need : 0;
 	}
 	uint32_t slot = (uint32_t)(s.insertion_index % BeamformerMaxRawDataFramesInFlight);
+	/* the slot about to be overwritten was read in place by the frame three uploads ago, which the
+	 * library runs asynchronously: wait for exactly that frame */
+	if (s.read_pending[slot]) { (void)hipEventSynchronize(s.read_done[slot]); s.read_pending[slot] = false; }
 	if (ok) ok = hipMemcpy(s.rf_ring[slot], s.payload(), size, hipMemcpyHostToDevice) == hipSuccess;
 	s.rf_active_size = size;
 	s.rf_block = block;
@@ -241,18 +258,22 @@ void handle_work(Server &s, ShmWork *work)
 		/* :1588-1602: indirect work consumes the next uploaded slot, a re-queued Compute re-uses the last */
 		uint64_t frame = work->kind == WorkKind_ComputeIndirect ? s.compute_index : (s.compute_index ? s.compute_index - 1 : 0);
 		uint32_t slot  = (uint32_t)(frame % BeamformerMaxRawDataFramesInFlight);
-		if (ok && s.rf_ring[slot])
+		if (ok && s.rf_ring[slot]) {
 			ok = beamformer_hip_push_device_data_with_compute(s.rf_ring[slot], (uint32_t)s.rf_active_size, work->compute.view_plane, b) != 0;
-		else ok = false;
+			if (s.stream && s.read_done[slot]) s.read_pending[slot] = hipEventRecord(s.read_done[slot], s.stream) == hipSuccess;
+		} else ok = false;
 		if (work->kind == WorkKind_ComputeIndirect) s.compute_index++;
 		say("compute block %u %s%s", b, ok ? "ok" : "failed: ", ok ? "" : beamformer_get_last_error_string());
 	}break;
 	case WorkKind_ExportBuffer:{                                   /* beamformer_core.c:1468-1509 */
 		post_sync(sm, Lock_DispatchCompute);
+		if (work->lock >= Lock_Count + BeamformerMaxParameterBlocks) { say("export: lock index %u out of range", work->lock); break; }
 		take_lock(&sm->locks[work->lock], -1);
 		bool ok = false;
 		beamformer_set_global_timeout((uint32_t)-1);
-		if (work->export_.kind == Export_BeamformedData) {
+		if (work->export_.size > s.payload_capacity()) {
+			ok = false;
+		} else if (work->export_.kind == Export_BeamformedData) {
 			ok = beamformer_get_last_frames(s.payload(), work->export_.size, work->export_.count) != 0;
 		} else if (work->export_.kind == Export_Stats && work->export_.size >= sizeof(BeamformerComputeStatsTable)) {
 			ok = beamformer_compute_timings(reinterpret_cast<BeamformerComputeStatsTable *>(s.payload()), -1) != 0;
@@ -293,6 +314,14 @@ int main(int argc, char **argv)
 	Server s;
 	s.sm = static_cast<ShmHeader *>(region);
 	s.size = size;
+	/* run the library on a stream of ours so that per-slot completion events can be recorded behind
+	 * its frames (no device: the calls fail and every compute request is answered with an error) */
+	if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess) {
+		beamformer_hip_set_stream(s.stream);
+		for (auto &e : s.read_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+	} else {
+		s.stream = nullptr;
+	}
 	std::memset((void *)s.sm, 0, sizeof(ShmHeader));                /* beamformer.c:249 */
 	s.sm->reserved_parameter_blocks    = 1;
 	s.sm->beamformed_frame_buffer_size = 4ull << 30;               /* the library's frame ring */
