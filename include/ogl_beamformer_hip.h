@@ -78,7 +78,8 @@ typedef struct {
 	uint64_t das_voxels;
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
-	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel */
+	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel,
+	                              4 factored kernel with LDS row cache */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);

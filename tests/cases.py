@@ -71,6 +71,15 @@ def _cases():
         "hercules_chirp", 16, 4, 1024, (8, 8, 8), LO3, HI3, seed=25, decode=0, data_kind=D.Float32,
         stages=(S.Demodulate, S.DAS),
         filters=[cfg.matched_chirp_filter(12.5e6, 4e-6, -2e6, 2e6, complex_taps=True)])
+    # HERCULES volumes whose x-y extent fills whole 256-voxel tiles (the shape full-size frames run in)
+    c["hercules_table_cw"] = lambda: cfg.hercules(
+        "hercules_table_cw", 16, 16, 512, (16, 16, 3), LO3, HI3, seed=27, cw=True, f_number=0.7,
+        stages=(S.Demodulate, S.Decode, S.DAS))
+    c["hercules_table_real_cubic"] = lambda: cfg.hercules("hercules_table_real_cubic", 24, 8, 512, (32, 16, 2), LO3, HI3, seed=28,
+                                                          interp=I.Cubic, f_number=1.0, focal=(0.0, -12e-3))
+    c["uhercules_table_sparse"] = lambda: cfg.hercules("uhercules_table_sparse", 16, 8, 512, (16, 16, 2), LO3, HI3, seed=29,
+                                                       kind=K.UHERCULES, sparse=[0, 3, 5, 9, 12, 14, 15], decode=0,
+                                                       orientation=0x21, data_kind=D.Float32Complex, cw=True, f_number=0.5)
     # BASELINE config 5 in its literal stage order {Decode, Filter, DAS} on fp16 RF: Decode's output stays
     # binary16 (accumulated with per-operation rounding), Filter stages through binary16, real-valued DAS + CW
     c["config5_literal_order"] = lambda: cfg.hercules(
