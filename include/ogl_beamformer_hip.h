@@ -120,8 +120,9 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
 
 /* Select the DAS implementation: 0 = automatic (the separable-delay gather kernel when the
- * geometry allows, else the per-voxel factored kernel for RCA-family and FORCES frames with
- * three or more transmits, else the general kernel), 1 = always the general kernel, 4 = the
+ * geometry allows and the interpolation is linear, else the per-voxel factored kernel for
+ * RCA-family and FORCES frames with three or more transmits, else the gather kernel where the
+ * geometry allows, else the general kernel), 1 = always the general kernel, 4 = the
  * factored kernel wherever it applies (also ahead of the gather kernel), 5 = the LDS row-cache
  * variant of the factored kernel where it applies (experiment, measured slower), 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower

@@ -629,7 +629,14 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
 			} else {
 				BfSeparableArgs sep{};
-				if ((c.das_path_mode & 0xF) != 1 && (c.das_path_mode & 0xF) != 4 && (c.das_path_mode & 0xF) != 5 && plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+				/* The LDS-table kernel's hand-scheduled loop exists for linear interpolation; for cubic
+				 * and nearest its generic loop loses to the factored kernel (200 ch x 33 tx -> 129 x 333 x 21,
+				 * cubic: 7.6 ms against 4.8 ms; nearest 2.6 against 2.1), which then goes first. */
+				const uint32_t das_mode = c.das_path_mode & 0xF;
+				const bool tables_first = a.interpolation == 1 || das_mode == 3 ||
+				                          !factored_applies(a, ps->transmit_table, das_mode);
+				if (das_mode != 1 && das_mode != 4 && das_mode != 5 && tables_first &&
+				    plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
 					 * allocated with that much slack): the gather target of out-of-range lanes */
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);

@@ -62,7 +62,10 @@ def factored_applies(bp):
 
 
 def expected_path(name, bp):
-    if name in SEPARABLE:
+    # the LDS-table kernel goes first for linear interpolation; for cubic and nearest the
+    # factored kernel does where it applies (executor.cpp), the table kernel otherwise
+    if name in SEPARABLE and (bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp)
+                              or bp.acquisition_count < 3):
         return 1
     transmits = bp.acquisition_count - (1 if P.AcquisitionKind(bp.acquisition_kind) == P.AcquisitionKind.UFORCES else 0)
     return 3 if factored_applies(bp) and transmits >= 3 else 0
