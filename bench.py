@@ -292,8 +292,8 @@ def main():
 
 
 PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
-              "factored kernel with LDS row cache"]
-KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel"]
+              "factored kernel with LDS row cache", "HERCULES aligned-grid kernel"]
+KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel", "das_hercules_kernel"]
 
 
 def measured_traffic(args, world, das_path):

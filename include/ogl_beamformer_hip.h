@@ -79,7 +79,7 @@ typedef struct {
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
 	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel,
-	                              4 factored kernel with LDS row cache */
+	                              4 factored kernel with LDS row cache, 5 HERCULES aligned-grid kernel */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
@@ -127,6 +127,9 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
  * variant of the factored kernel where it applies (experiment, measured slower), 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower
  * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
+ * HERCULES-family frames whose grid is aligned with the array (one lateral transducer coordinate a
+ * function of the output row alone) and at least 32 voxels wide run the aligned-grid kernel
+ * (das_hercules.hip) in every mode but 1; 6 = that kernel also on narrow grids (idle lanes).
  * Adding 0x10 keeps the general kernel at one thread per voxel for frames it would otherwise
  * split over channels (frames under ~4096 waves of voxels: K waves share 64 voxels, each
  * sums C/K channels, partial sums meet in LDS); adding 0x20 keeps Decode on the O(T^2) kernel

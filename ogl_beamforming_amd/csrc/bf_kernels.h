@@ -73,6 +73,20 @@ typedef struct {
 	                             the DAS input: where out-of-range lanes gather from */
 } BfSeparableArgs;
 
+/* geometry of the HERCULES fast path (das_hercules.hip): lanes of a wave lie along the output's x
+ * axis; the array axis that moves with x is the OUTER loop, the other one (a function of the
+ * output row y alone) the INNER loop, served from a wave-uniform table */
+typedef struct {
+	float   *table;           /* [size[1]][table_pitch]: squared lateral distance row y <-> inner element n */
+	float   *extremes;        /* [size[1]][2]: min and max of each table row */
+	uint32_t table_pitch;     /* floats per row, >= inner_count + 8 (the kernel prefetches a batch ahead) */
+	uint32_t inner_count, outer_count;
+	uint32_t inner_coord;     /* transducer coordinate of the inner axis: 0 = x, 1 = y */
+	uint32_t inner_is_transmit;   /* inner loop walks decoded transmit elements (else receive channels) */
+	uint32_t tiles[3];        /* 64-voxel x segments, groups of 4 output rows, z planes of the shard */
+	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes behind the DAS input */
+} BfHerculesArgs;
+
 typedef struct {
 	const void *raw; void *out;
 	const int16_t *channel_mapping;   /* device, [channels] */
@@ -128,6 +142,7 @@ hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hi
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
  * 2*1024 floats */
 hipError_t bf_launch_das_factored(const BfDasArgs *a, hipStream_t s);
+hipError_t bf_launch_das_hercules(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s);
 hipError_t bf_launch_das_rowcache(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_sum(void *out, const void *in, float prescale, uint64_t bytes, hipStream_t s);
 hipError_t bf_launch_display(const void *frame, uint64_t voxels, int complex_data, float threshold_db,

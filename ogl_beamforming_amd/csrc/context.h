@@ -107,6 +107,7 @@ struct Context {
 	bool         have_sample = false;
 	uint64_t     replan_frame = 0;                             /* first frame of the current plan */
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
+	DeviceBuffer hercules_table;                               /* das_hercules.hip: per-row lateral table, rebuilt per launch */
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;
 };

@@ -1,0 +1,366 @@
+/* das_hercules.hip -- delay-and-sum fast path for the HERCULES family on gfx950 (MI355X).
+ *
+ * Same arithmetic contract as das.hip's das_hercules (shaders/das.glsl:233-286 of the
+ * reference): one transmit focus, a 2-D aperture of (receive channel c) x (decoded transmit
+ * element t), and for every element pair
+ *     e^2   = (lateral_rx - c pitch_rx)^2 + (lateral_tx - t pitch_tx)^2
+ *     index = T0(voxel) + sqrt(z^2 + e^2) fs / c          pass: e^2 < 0.25 / (F# / z)^2
+ *     out  += w_t cos^2(pi F#/z sqrt(e^2)) * rotate_iq(interpolate(rf[c][t], index), index).
+ *
+ * The general kernel is VALU bound at ~44 issue slots per pair (tools/microbench.hip: a wave64
+ * VALU instruction holds its SIMD for 4 clocks, a transcendental for twice that).  This kernel
+ * applies when the volume's lateral axes are aligned with the array's (exact-zero matrix
+ * coefficients, host check plan_hercules): the 64 lanes of a wave lie along the output's x axis and
+ * share y and z, so one of the two lateral terms of e^2 is per lane and constant over the inner
+ * loop, and the other is WAVE UNIFORM: it comes from a small global table D2[y][n] (built per
+ * launch by hercules_table_kernel) through scalar loads and enters the vector ALU as an SGPR
+ * operand.  Per pair that leaves
+ *     two packed adds for (e^2, z^2 + e^2) of two elements, v_sqrt, a packed fma for two indices;
+ *     cos^2(sqrt(w)), w = (pi F#/z)^2 e^2, as a degree-5 polynomial in w evaluated for two
+ *       elements per packed instruction (|error| < 7e-7) instead of v_sqrt + v_cos;
+ *     floor / fraction / address, ONE 16-byte gather, the interpolation as two packed ops;
+ *     v_fract + v_sin + v_cos of the demodulation phase, the phasor scaled by the apodization in
+ *       one packed multiply, two packed FMAs of rotate-accumulate;
+ *     |sample| for coherency weighting (packed square, add, v_sqrt, fma).
+ * The f-number test and the row range test are decided per wave and outer element from the
+ * table row's extremes: when every lane passes both for the whole inner loop (the common case)
+ * the loop runs without compares, selects or branches; otherwise a checked instantiation runs.
+ * Gathers of four pairs are in flight together.  No LDS, no MFMA: gather-accumulate.
+ *
+ * "outer"/"inner": the array axis that runs along the output's x axis is the outer loop (its
+ * per-lane term is computed once per element), the other one the inner loop.  Either may be the
+ * receive or the transmit axis; only the RF row strides and the first-transmit weight differ.
+ */
+#include "das_common.h"
+
+#define BF_HERC_BATCH 4
+
+/* cos^2(sqrt(w)) on [0, (pi/2)^2]: degree-5 fit at the Chebyshev nodes, |error| < 4.0e-7 (6.7e-7 as an
+ * f32 Horner chain) -- next to 1e-4 of parity tolerance and the ~1e-6 of the hardware's v_cos */
+#define BF_APOD_C0  0.9999996f
+#define BF_APOD_C1 -0.9999883f
+#define BF_APOD_C2  0.33327785f
+#define BF_APOD_C3 -0.044347722f
+#define BF_APOD_C4  0.0030977894f
+#define BF_APOD_C5 -0.000112471265f
+
+namespace {
+
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+
+__device__ __forceinline__ f32x2 apod_poly(f32x2 w)
+{
+	f32x2 r = splat(BF_APOD_C5);
+	r = r * w + splat(BF_APOD_C4);
+	r = r * w + splat(BF_APOD_C3);
+	r = r * w + splat(BF_APOD_C2);
+	r = r * w + splat(BF_APOD_C1);
+	r = r * w + splat(BF_APOD_C0);
+	return r;
+}
+
+/* das.glsl:187-202 with the per-transmit constants precomputed (same as das.hip) */
+__device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx, float wy, float wz)
+{
+	float result = 0.f;
+	if (!(t.flags & BF_TX_NONE)) {
+		float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+		if (t.flags & BF_TX_PLANE) {
+			result = px * t.sin_a + wz * t.cos_a;
+		} else {
+			float dx = px - t.focus_x, dz = wz - t.focus_z;
+			result = hw_sqrt(dx * dx + dz * dz);
+		}
+	}
+	return result;
+}
+
+/* transducer-space lateral coordinate `coord` (0 = x, 1 = y) of voxel (x, y, z) */
+__device__ __forceinline__ void voxel_to_xdc(const BfDasArgs &p, uint32_t x, uint32_t y, uint32_t z,
+                                             float &wx, float &wy, float &wz, float &xx, float &xy, float &xz)
+{
+	float px = (float)x / fmaxf(1.0f, (float)p.size[0] - 1.0f);       /* das.glsl:374-376 */
+	float py = (float)y / fmaxf(1.0f, (float)p.size[1] - 1.0f);
+	float pz = (float)z / fmaxf(1.0f, (float)p.size[2] - 1.0f);
+	m4_point(p.voxel_transform, px, py, pz, wx, wy, wz);
+	m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+}
+
+} /* namespace */
+
+/* D2[y * pitch + n] = (uniform lateral coordinate of output row y - position of inner element n)^2,
+ * n < inner_count; entries up to the row pitch repeat the last element (never used for sums);
+ * extremes[y] = {min, max} of the row.  One block per output row. */
+__global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, const BfHerculesArgs q)
+{
+	const uint32_t y = blockIdx.x;
+	float wx, wy, wz, xx, xy, xz;
+	voxel_to_xdc(p, 0, y, p.z_first, wx, wy, wz, xx, xy, xz);
+	const float lateral = q.inner_coord ? xy : xx;
+	const float pitch   = q.inner_coord ? p.pitch[1] : p.pitch[0];
+	float lo = __builtin_inff(), hi = -__builtin_inff();
+	for (uint32_t n = threadIdx.x; n < q.table_pitch; n += blockDim.x) {
+		uint32_t m = n < q.inner_count ? n : q.inner_count - 1;
+		float element = (q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
+		float delta = lateral - element * pitch;
+		float d2 = delta * delta;
+		q.table[(size_t)y * q.table_pitch + n] = d2;
+		lo = fminf(lo, d2); hi = fmaxf(hi, d2);
+	}
+	__shared__ float red[2][4];
+	for (int off = 32; off > 0; off >>= 1) {
+		lo = fminf(lo, __shfl_xor(lo, off, 64));
+		hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+	}
+	if ((threadIdx.x & 63u) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 4; w++) { lo = fminf(lo, red[0][w]); hi = fmaxf(hi, red[1][w]); }
+		q.extremes[2 * y] = lo; q.extremes[2 * y + 1] = hi;
+	}
+}
+
+/* Grid: q.tiles[0] * q.tiles[1] * q.tiles[2] blocks of 256 threads; a block is 4 waves = 4 output rows
+ * (y) x 64 voxels along x of one z plane. */
+template <int INTERP, bool CPLX, bool CW>
+__global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
+{
+	constexpr uint32_t ES = CPLX ? 8 : 4;
+	using VT = sample_t<CPLX>;
+
+	/* blockIdx -> tile with each XCD walking a contiguous run of tiles (das.hip) */
+	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
+	const uint32_t per   = (total + 7u) / 8u;
+	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+	if (tile >= total) return;
+	const uint32_t tx_ = tile % q.tiles[0];
+	const uint32_t ty_ = (tile / q.tiles[0]) % q.tiles[1];
+	const uint32_t zl  = tile / (q.tiles[0] * q.tiles[1]);
+	const uint32_t z   = p.z_first + zl;
+
+	const uint32_t lane = threadIdx.x & 63u;
+	/* the wave's output row: wave uniform, told to the compiler so that table reads become scalar loads */
+	const uint32_t y = __builtin_amdgcn_readfirstlane(ty_ * 4u + (threadIdx.x >> 6));
+	if (y >= p.size[1]) return;
+	const uint32_t x_real = tx_ * 64u + lane;
+	const bool     inside = x_real < p.size[0];
+	const uint32_t x = inside ? x_real : p.size[0] - 1u;           /* idle lanes repeat the last voxel, store nothing */
+
+	float wx, wy, wz, xx, xy, xz;
+	voxel_to_xdc(p, x, y, z, wx, wy, wz, xx, xy, xz);
+
+	const int S = p.sample_count, A = p.acquisition_count;
+	const BfTransmit t0 = p.transmits[0];
+	const float fs_over_c = p.sampling_frequency * p.inv_speed_of_sound;
+	const float T0  = (transmit_distance(t0, wx, wy, wz) * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+	const float z2  = xz * xz;
+	const float f_number_over_z  = __builtin_fabsf(p.f_number * hw_rcp(xz));
+	const float apodization_test = 0.25f / (f_number_over_z * f_number_over_z);
+	const float w_scale = (3.14159265358979f * f_number_over_z) * (3.14159265358979f * f_number_over_z);
+	const float turns_per_sample = p.turns_per_sample;
+
+	const float outer_lateral = q.inner_coord ? xx : xy;           /* the other coordinate */
+	const float outer_pitch   = q.inner_coord ? p.pitch[0] : p.pitch[1];
+	const float *__restrict__ row_d2 = q.table + (size_t)y * q.table_pitch;
+	const float d2_min = q.extremes[2 * y], d2_max = q.extremes[2 * y + 1];
+
+	const char *rf = (const char *)p.rf;
+	const uint32_t ulast = (uint32_t)(S - 1);
+	const int   n_inner = (int)q.inner_count, n_outer = (int)q.outer_count;
+	/* byte strides of the RF rows along the two loops: rf[c][t] rows of S samples */
+	const uint32_t row_bytes    = (uint32_t)S * ES;
+	const uint32_t inner_stride = q.inner_is_transmit ? row_bytes : row_bytes * (uint32_t)A;
+	const uint32_t outer_stride = q.inner_is_transmit ? row_bytes * (uint32_t)A : row_bytes;
+	const uint32_t sparse_rows  = p.sparse ? row_bytes : 0u;       /* UHERCULES: transmit rows start at 1 */
+
+	VT    coherent   = zero_sample<CPLX>();
+	float incoherent = 0.f;
+
+	for (int m = 0; m < n_outer; m++) {
+		float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
+		float od  = outer_lateral - outer_element * outer_pitch;
+		float od2 = od * od;
+		/* wave-level decisions for this outer element from the table row's extremes */
+		const bool  lane_none = !(od2 + d2_min < apodization_test);
+		if (__builtin_amdgcn_ballot_w64(!lane_none) == 0) continue;             /* nobody passes anything */
+		const bool  lane_all  = (od2 + d2_max < apodization_test);
+		const float i_lo = T0 + hw_sqrt(z2 + (od2 + d2_min)) * fs_over_c;
+		const float i_hi = T0 + hw_sqrt(z2 + (od2 + d2_max)) * fs_over_c;
+		bool lane_range;
+		if constexpr (INTERP == BF_INTERP_LINEAR)       lane_range = i_lo >= 0.5f && i_hi < (float)(S - 1) - 0.5f;
+		else if constexpr (INTERP == BF_INTERP_CUBIC)   lane_range = i_lo >= 1.5f && i_hi < (float)(S - 2) - 0.5f;
+		else                                            lane_range = i_lo >= 0.5f && i_hi < (float)S - 1.0f;
+		const bool wave_fast = __builtin_amdgcn_ballot_w64(!(lane_all && lane_range)) == 0;
+
+		const uint32_t row0 = (uint32_t)m * outer_stride + sparse_rows;
+		/* partial sums of this outer element; acc1/acc2 hold re*(cos,sin) and im*(cos,sin) */
+		f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+		float accr = 0.f, mag = 0.f;
+		const f32x2 od2p = splat(od2), z2p = splat(z2), T0p = splat(T0), kp = splat(fs_over_c),
+		            wsp = splat(w_scale), tpsp = splat(turns_per_sample),
+		            oz2p = splat(od2 + z2), wodp = splat(w_scale * od2);
+
+		/* B = 1 or BF_HERC_BATCH elements starting at inner element n; d2in = their table entries */
+		auto group = [&](auto checked_c, auto count_c, int n, const float *d2in, float first_weight) {
+			constexpr bool CHECK = decltype(checked_c)::value;
+			constexpr int  B     = decltype(count_c)::value;
+			constexpr int  P     = (B + 1) / 2;
+			float d2[2 * P];
+			#pragma unroll
+			for (int k = 0; k < 2 * P; k++) d2[k] = d2in[k < B ? k : B - 1];
+			f32x2 e2[P], dist[P], index[P], apod[P], turns[P];
+			#pragma unroll
+			for (int k = 0; k < P; k++) {
+				const f32x2 dn = f32x2{d2[2 * k], d2[2 * k + 1]};
+				f32x2 dd;
+				if constexpr (CHECK) {
+					e2[k] = od2p + dn;                       /* the reference's association: the f-number test reads it */
+					dd    = z2p + e2[k];
+					apod[k] = apod_poly(e2[k] * wsp);
+				} else {
+					dd      = oz2p + dn;                     /* (od2 + z2) + d2: one packed add */
+					apod[k] = apod_poly(dn * wsp + wodp);    /* w = ws e2 as one packed fma */
+				}
+				dist[k]  = f32x2{hw_sqrt(dd.x), hw_sqrt(dd.y)};
+				index[k] = dist[k] * kp + T0p;
+				if constexpr (CPLX) turns[k] = index[k] * tpsp;
+			}
+			/* floor and fraction of two indices with packed adds (unchecked linear path only: every index is
+			 * known to lie in [0.5, S - 1.5)): adding 2^23 - 0.5 rounds index - 0.5 to an integer in the low
+			 * mantissa bits, i.e. floor(index) -- or, for an exactly integral index, possibly index - 1 with
+			 * fraction 1, which interpolates to the same sample */
+			f32x2 magic[P], fracp[P];
+			if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
+				#pragma unroll
+				for (int k = 0; k < P; k++) {
+					magic[k] = index[k] + splat(8388607.5f);
+					fracp[k] = index[k] - (magic[k] - splat(8388608.0f));
+				}
+			}
+			float   frac[B], ap[B];
+			Tap<INTERP> tap[B];
+			uint32_t off[B];
+			#pragma unroll
+			for (int k = 0; k < B; k++) {
+				[[maybe_unused]] float idx = (k & 1) ? index[k >> 1].y : index[k >> 1].x;
+				float e   = 0.f;
+				if constexpr (CHECK) e = (k & 1) ? e2[k >> 1].y : e2[k >> 1].x;
+				ap[k]     = (k & 1) ? apod[k >> 1].y : apod[k >> 1].x;
+				if (k == 0) ap[k] *= first_weight;
+				uint32_t row = row0 + (uint32_t)(n + k) * inner_stride;
+				if constexpr (INTERP == BF_INTERP_LINEAR && !CHECK) {
+					frac[k] = (k & 1) ? fracp[k >> 1].y : fracp[k >> 1].x;
+					float mg = (k & 1) ? magic[k >> 1].y : magic[k >> 1].x;
+					/* bits(magic) = 0x4B000000 + floor(index); the constant leaves through the wave-uniform row offset */
+					off[k] = (__builtin_bit_cast(uint32_t, mg) * ES) + (row - 0x4B000000u * ES);
+				} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+					frac[k] = hw_fract(idx);
+					uint32_t ki = (uint32_t)cvt_floor_i32(idx);
+					off[k] = row + ki * ES;
+					bool ok = (ki < ulast) && (e < apodization_test);
+					off[k] = ok ? off[k] : q.zero_offset;
+					ap[k]  = ok ? ap[k] : 0.f;
+				} else {
+					tap[k] = tap_setup<INTERP, CPLX>(idx, (float)S, S - 1);
+					off[k] = row + tap[k].off;
+					if constexpr (CHECK) ap[k] = (e < apodization_test) ? ap[k] : 0.f;
+				}
+			}
+			TapData<INTERP, CPLX> d[B];
+			#pragma unroll
+			for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, off[k]);
+			#pragma unroll
+			for (int k = 0; k < B; k++) {
+				VT sv;
+				if constexpr (INTERP == BF_INTERP_LINEAR) {
+					if constexpr (CPLX) { f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * (s1 - s0); }
+					else                { sv = d[k].a.x + frac[k] * (d[k].a.y - d[k].a.x); }
+				} else {
+					sv = tap_finish<INTERP, CPLX>(tap[k], d[k]);
+				}
+				if constexpr (CPLX) {
+					float tr = hw_fract((k & 1) ? turns[k >> 1].y : turns[k >> 1].x);
+					f32x2 cs = f32x2{hw_cos_turns(tr), hw_sin_turns(tr)} * ap[k];
+					acc1 += sv.x * cs;
+					acc2 += sv.y * cs;
+					/* plain multiply + two FMAs: a packed square followed by scalar adds is slower here */
+					if constexpr (CW) mag = __builtin_fmaf(ap[k], hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x)), mag);
+				} else {
+					accr = __builtin_fmaf(ap[k], sv, accr);
+					if constexpr (CW) mag = __builtin_fmaf(ap[k], __builtin_fabsf(sv), mag);
+				}
+			}
+		};
+
+		auto inner = [&](auto checked_c) {
+			int n = 0;
+			/* the reference's weight of transmit 0 (das.glsl:272-273); UHERCULES never visits it */
+			if (q.inner_is_transmit && !p.sparse) {
+				float d2 = row_d2[0];
+				group(checked_c, std::integral_constant<int, 1>{}, 0, &d2, p.first_transmit_weight);
+				n = 1;
+			}
+			/* table entries of the next batch are fetched (scalar loads) while this one computes; the
+			 * row is padded so that reading one batch past the end stays inside it */
+			float cur[BF_HERC_BATCH];
+			#pragma unroll
+			for (int k = 0; k < BF_HERC_BATCH; k++) cur[k] = row_d2[n + k];
+			for (; n + BF_HERC_BATCH <= n_inner; n += BF_HERC_BATCH) {
+				float nxt[BF_HERC_BATCH];
+				#pragma unroll
+				for (int k = 0; k < BF_HERC_BATCH; k++) nxt[k] = row_d2[n + BF_HERC_BATCH + k];
+				group(checked_c, std::integral_constant<int, BF_HERC_BATCH>{}, n, cur, 1.0f);
+				#pragma unroll
+				for (int k = 0; k < BF_HERC_BATCH; k++) cur[k] = nxt[k];
+			}
+			for (; n < n_inner; n++) {
+				float d2 = row_d2[n];
+				group(checked_c, std::integral_constant<int, 1>{}, n, &d2, 1.0f);
+			}
+		};
+		if (wave_fast) inner(std::false_type{});
+		else           inner(std::true_type{});
+
+		/* fold this outer element (its weight when the outer loop is the transmit loop) */
+		const float outer_weight = (!q.inner_is_transmit && !p.sparse && m == 0) ? p.first_transmit_weight : 1.0f;
+		if constexpr (CPLX) {
+			coherent.x += outer_weight * (acc1.x - acc2.y);
+			coherent.y += outer_weight * (acc1.y + acc2.x);
+		} else {
+			coherent += outer_weight * accr;
+		}
+		if constexpr (CW) incoherent += outer_weight * mag;
+	}
+	if (!inside) return;
+
+	uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
+	if constexpr (CW) coherent = coherent * (coherent / incoherent);   /* coherency_weighting.glsl:36 */
+	reinterpret_cast<VT *>(p.out)[out_index] = coherent;
+}
+
+template <int INTERP, bool CPLX, bool CW>
+static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
+{
+	hipLaunchKernelGGL(hercules_table_kernel, dim3(a->size[1]), dim3(256), 0, s, *a, *q);
+	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
+	uint32_t grid  = ((total + 7u) / 8u) * 8u;
+	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW>), dim3(grid), dim3(256), 0, s, *a, *q);
+	return hipGetLastError();
+}
+
+template <int INTERP>
+static hipError_t launch_herc_kind(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
+{
+	if (a->complex_data) return a->coherency_weighting ? launch_herc<INTERP, true,  true>(a, q, s) : launch_herc<INTERP, true,  false>(a, q, s);
+	else                 return a->coherency_weighting ? launch_herc<INTERP, false, true>(a, q, s) : launch_herc<INTERP, false, false>(a, q, s);
+}
+
+extern "C" hipError_t bf_launch_das_hercules(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
+{
+	switch (a->interpolation) {
+	case BF_INTERP_NEAREST: return launch_herc_kind<BF_INTERP_NEAREST>(a, q, s);
+	case BF_INTERP_LINEAR:  return launch_herc_kind<BF_INTERP_LINEAR>(a, q, s);
+	case BF_INTERP_CUBIC:   return launch_herc_kind<BF_INTERP_CUBIC>(a, q, s);
+	}
+	return hipErrorInvalidValue;
+}

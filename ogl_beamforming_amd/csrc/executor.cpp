@@ -121,6 +121,7 @@ void shutdown_device()
 	for (auto &b : c.rf) b.release();
 	for (auto &b : c.scratch) b.release();
 	c.ring.release(); c.pair_counter.release(); c.minmax_scratch.release(); c.sum_scratch.release();
+	c.hercules_table.release();
 	for (auto &t : c.timing) {
 		if (t.created) for (auto &e : t.events) if (e) (void)hipEventDestroy(e);
 		t = TimingSlot{};
@@ -434,6 +435,48 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 	return true;
 }
 
+/* Can this HERCULES-family frame use the aligned fast path (das_hercules.hip)?  The kernel lays
+ * the 64 lanes of a wave along the output's x axis and reads the squared lateral distance along
+ * the OTHER array axis from a per-output-row table, so one transducer lateral coordinate has to
+ * be a function of the output row y alone: every product that would let voxel x or voxel z move
+ * it must be an exact zero (then the table entry is bit-identical to the per-voxel value).
+ * Everything else -- depth, the transmit distance, the coordinate along x -- stays per voxel. */
+static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
+                          uint32_t zcount, bool forced, BfHerculesArgs &q)
+{
+	if (a.family != BF_DAS_HERCULES || tx.empty()) return false;
+	if (!forced) {
+		if (a.size[0] < 32 || a.split_shift) return false;       /* thin or tiny frames: the general kernel's channel split */
+		if (((a.size[0] + 63u) & ~63u) > a.size[0] + a.size[0] / 3u) return false;   /* > 25 % idle lanes */
+	}
+	auto W = [&](int row, int col) { return vox[4 * col + row]; };
+	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
+	auto moves = [&](int row, int col) {      /* does transducer coordinate `row` move with voxel axis `col`? */
+		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return true;
+		return false;
+	};
+	int inner = -1;
+	for (int coord = 0; coord < 2 && inner < 0; coord++)
+		if (!moves(coord, 0) && !moves(coord, 2)) inner = coord;
+	/* prefer the coordinate that does move with y when both qualify (a degenerate grid) */
+	if (inner == 0 && !moves(1, 0) && !moves(1, 2) && !moves(0, 1) && moves(1, 1)) inner = 1;
+	if (inner < 0) return false;
+	const bool rx_cols = (tx[0].flags & BF_RX_COLUMNS) != 0;
+	const int  tx_coord = rx_cols ? 1 : 0;                        /* das.glsl:238-247: transmit elements run along the other axis */
+	const uint32_t A = (uint32_t)a.acquisition_count, C = (uint32_t)a.channel_count;
+	const uint32_t transmits = A - (a.sparse ? 1u : 0u);
+	if (!transmits || !C) return false;
+	q.inner_coord       = (uint32_t)inner;
+	q.inner_is_transmit = inner == tx_coord;
+	q.inner_count       = q.inner_is_transmit ? transmits : C;
+	q.outer_count       = q.inner_is_transmit ? C : transmits;
+	q.table_pitch       = (q.inner_count + 8u + 3u) & ~3u;      /* the kernel prefetches one batch of 4 past the end */
+	q.tiles[0] = (a.size[0] + 63u) / 64u;
+	q.tiles[1] = (a.size[1] + 3u) / 4u;
+	q.tiles[2] = zcount;
+	return true;
+}
+
 /* Can the per-voxel factored kernel (das_factored.hip) take this frame?  It needs the sample
  * index to be a receive term plus a transmit term: RCA-family frames whose transmits all share
  * one receive orientation, and FORCES/UFORCES.  With fewer than three transmits per channel
@@ -649,6 +692,16 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
 						das_path = 1;
 					}
+				} else if (BfHerculesArgs hq{}; das_mode != 1 &&
+				           plan_hercules(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, das_mode == 6, hq) &&
+				           c.hercules_table.ensure(((size_t)hq.table_pitch + 2) * a.size[1] * sizeof(float))) {
+					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
+					hq.zero_offset = (uint32_t)used;            /* as for the gather kernel above */
+					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
+					hq.table    = (float *)c.hercules_table.ptr;
+					hq.extremes = hq.table + (size_t)hq.table_pitch * a.size[1];
+					ok &= HIP_OK(bf_launch_das_hercules(&a, &hq, s));
+					das_path = 5;
 				} else if (factored_applies(a, ps->transmit_table, c.das_path_mode & 0xF)) {
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					a.zero_offset = (uint32_t)used;             /* as for the gather kernel above */

@@ -97,13 +97,19 @@ bool push_data_common(const void *data, uint32_t data_size, uint32_t image_plane
 	const ParameterBlock &pb = c.blocks[slot];
 	const BeamformerParameters &bp = pb.parameters;
 	uint64_t max_rf_size = frame_ring_bytes() / 3;                   /* capabilities.max_rf_data_size */
-	uint32_t bytes    = (uint32_t)bf_kind_byte_size[pb.data_kind];
-	uint32_t rf_size  = bp.acquisition_count * bp.sample_count * bp.channel_count * bytes;   /* u32 arithmetic as in the reference */
-	uint32_t raw_size = bp.raw_data_dimensions[0] * bp.raw_data_dimensions[1] * bytes;
+	/* The reference does this arithmetic in u32 (lib .c:503-511); a product that wraps there passes
+	 * its check and then reads far outside the caller's buffer.  Same checks and error codes, in u64:
+	 * sizes the reference accepts without wrapping are judged identically, wrapped ones are refused. */
+	uint64_t bytes    = (uint64_t)bf_kind_byte_size[pb.data_kind];
+	uint64_t rf_size  = (uint64_t)bp.acquisition_count * bp.sample_count * bp.channel_count * bytes;
+	uint64_t raw_size = (uint64_t)bp.raw_data_dimensions[0] * bp.raw_data_dimensions[1] * bytes;
 	if (!check(data != nullptr, BeamformerLibErrorKind_BufferOverflow)) return false;
-	if (!check(rf_size <= max_rf_size, BeamformerLibErrorKind_RFDataSizeOverflow)) return false;
-	if (!check(rf_size <= data_size && data_size == raw_size, BeamformerLibErrorKind_DataSizeMismatch)) return false;
+	if (!check(rf_size <= max_rf_size && rf_size <= UINT32_MAX, BeamformerLibErrorKind_RFDataSizeOverflow)) return false;
+	if (!check(rf_size <= data_size && (uint64_t)data_size == raw_size, BeamformerLibErrorKind_DataSizeMismatch)) return false;
 	if (!check(rf_size > 0, BeamformerLibErrorKind_DataSizeMismatch)) return false;
+	/* the ingest walks channel_mapping[0 .. channel_count): bound it before anything indexes with it */
+	if (!check(bp.channel_count <= BeamformerMaxChannelCount && bp.acquisition_count <= BeamformerMaxEmissionsCount,
+	           BeamformerLibErrorKind_DataSizeMismatch)) return false;
 	return push_rf_and_compute(slot, data, data_size, on_device);
 }
 

@@ -69,6 +69,21 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error, bool a
 		samples /= 2 * D;
 		fs      /= (float)(2 * D);
 	}
+	/* The DAS kernels test sample indices with unsigned compares against S-1 / S-3 and clamp tap
+	 * addresses into the row: a row shorter than the interpolation's support (1 sample nearest,
+	 * 2 linear, 4 cubic -- sample_rf, das.glsl:99-124) has no valid index at all and would make those
+	 * bounds wrap.  The reference would produce an all-zero frame; refuse the plan instead of
+	 * launching it (decimation can take `samples` to 0 or 1). */
+	{
+		bool has_das = false;
+		for (uint32_t i = 0; i < pb.shader_count; i++) has_das |= pb.shaders[i] == BeamformerShaderKind_DAS;
+		const uint32_t support = bp.interpolation_mode == BeamformerInterpolationMode_Cubic ? 4u
+		                       : bp.interpolation_mode == BeamformerInterpolationMode_Linear ? 2u : 1u;
+		if (samples == 0 || (has_das && samples < support)) {
+			error = "too few samples per row for the DAS interpolation after demodulation/decimation";
+			return false;
+		}
+	}
 	plan.iq_pipeline = bf_kind_complex[in_kind] != 0 || hilbert;       /* :589 */
 	const int das_kind = plan.iq_pipeline ? BeamformerDataKind_Float32Complex : BeamformerDataKind_Float32;
 	plan.pipeline_data_kind = in_kind;

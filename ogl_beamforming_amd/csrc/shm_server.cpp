@@ -246,7 +246,11 @@ void handle_work(Server &s, ShmWork *work)
 	case WorkKind_Compute:
 	case WorkKind_ComputeIndirect:{                                /* beamformer_core.c:1519-1677 */
 		uint32_t b = work->compute.parameter_block;
-		bool ok = b < sm->reserved_parameter_blocks && commit_block(s, b);
+		/* both values live in client-writable memory: bound the block index by the protocol's maximum as
+		 * well as by the (client-written) reserved count before it indexes the lock and block arrays */
+		uint32_t reserved = sm->reserved_parameter_blocks;
+		if (reserved > BeamformerMaxParameterBlocks) reserved = BeamformerMaxParameterBlocks;
+		bool ok = b < reserved && commit_block(s, b);
 		post_sync(sm, Lock_DispatchCompute);                         /* :1533 */
 		if (work->kind == WorkKind_ComputeIndirect) {
 			/* :1591-1602: the RF of this frame must have been uploaded */
@@ -267,7 +271,11 @@ void handle_work(Server &s, ShmWork *work)
 	}break;
 	case WorkKind_ExportBuffer:{                                   /* beamformer_core.c:1468-1509 */
 		post_sync(sm, Lock_DispatchCompute);
-		if (work->lock >= Lock_Count + BeamformerMaxParameterBlocks) { say("export: lock index %u out of range", work->lock); break; }
+		if (work->lock < 0 || work->lock >= Lock_Count + BeamformerMaxParameterBlocks) {
+			say("export: lock index %d out of range", work->lock);
+			post_sync(sm, Lock_ExportSync);                            /* answer the client instead of leaving it blocked */
+			break;
+		}
 		take_lock(&sm->locks[work->lock], -1);
 		bool ok = false;
 		beamformer_set_global_timeout((uint32_t)-1);

@@ -80,6 +80,23 @@ def _cases():
     c["uhercules_table_sparse"] = lambda: cfg.hercules("uhercules_table_sparse", 16, 8, 512, (16, 16, 2), LO3, HI3, seed=29,
                                                        kind=K.UHERCULES, sparse=[0, 3, 5, 9, 12, 14, 15], decode=0,
                                                        orientation=0x21, data_kind=D.Float32Complex, cw=True, f_number=0.5)
+    # HERCULES grids wide enough (>= 32 voxels along x, <= 25 % idle lanes) for the aligned-grid kernel
+    # (das_hercules.hip) to be picked automatically: both orientations (inner loop = transmits / = channels),
+    # ragged x edge, transmit count not a multiple of the batch, f-number culling that is partial per wave.
+    # (Frames this small normally get the general kernel's channel split; fewer than 8 channels rules that out,
+    # so the first two exercise the automatic selection.)
+    c["hercules_wide_cw"] = lambda: cfg.hercules(
+        "hercules_wide_cw", 7, 16, 512, (64, 6, 3), LO3, HI3, seed=51, cw=True, f_number=0.7,
+        stages=(S.Demodulate, S.Decode, S.DAS))
+    c["hercules_wide_real_swapped"] = lambda: cfg.hercules(
+        "hercules_wide_real_swapped", 6, 8, 512, (56, 5, 2), (-4e-3, -2e-3, 3e-3), (4e-3, 2e-3, 9e-3), seed=52,
+        orientation=0x21, f_number=1.2, focal=(0.0, -12e-3))
+    c["uhercules_wide_sparse_cubic"] = lambda: cfg.hercules(
+        "uhercules_wide_sparse_cubic", 16, 8, 512, (48, 4, 2), LO3, HI3, seed=53, kind=K.UHERCULES,
+        sparse=[0, 3, 5, 9, 12, 14, 15], decode=0, data_kind=D.Float32Complex, cw=True, f_number=0.9, interp=I.Cubic)
+    c["hercules_wide_nearest"] = lambda: cfg.hercules(
+        "hercules_wide_nearest", 8, 7, 512, (40, 3, 3), LO3, HI3, seed=54, decode=0, interp=I.Nearest,
+        data_kind=D.Float32Complex, f_number=0.6)
     # BASELINE config 5 in its literal stage order {Decode, Filter, DAS} on fp16 RF: Decode's output stays
     # binary16 (accumulated with per-operation rounding), Filter stages through binary16, real-valued DAS + CW
     c["config5_literal_order"] = lambda: cfg.hercules(

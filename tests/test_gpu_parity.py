@@ -61,7 +61,24 @@ def factored_applies(bp):
     return False
 
 
+def hercules_family(bp):
+    return P.AcquisitionKind(bp.acquisition_kind) in (P.AcquisitionKind.HERCULES, P.AcquisitionKind.UHERCULES,
+                                                      P.AcquisitionKind.HERO_PA)
+
+
+def hercules_fast_auto(bp):
+    """host rule of executor.cpp plan_hercules for the axis-aligned grids of tests/cases.py: >= 32 voxels
+    along x, no channel split (>= 4096 waves of voxels or few channels), <= 25 % idle lanes"""
+    X, Y, Z = (max(1, v) for v in bp.output_points[:3])
+    waves, split, C = (X * Y * Z + 63) // 64, 0, bp.channel_count
+    while split < 4 and (waves << split) < 4096 and (C >> (split + 1)) >= 4:
+        split += 1
+    return hercules_family(bp) and X >= 32 and split == 0 and ((X + 63) & ~63) <= X + X // 3
+
+
 def expected_path(name, bp):
+    if hercules_fast_auto(bp):
+        return 5
     # the LDS-table kernel goes first for linear interpolation; for cubic and nearest the
     # factored kernel does where it applies (executor.cpp), the table kernel otherwise
     if name in SEPARABLE and (bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp)
@@ -124,6 +141,26 @@ def test_general_kernel_without_channel_split(name, bflib, oracle):
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert last_das_path(bflib) == 0
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq)
+
+
+HERCULES = sorted(n for n in cases.CASES if hercules_family(cases.make(n).bp))
+
+
+@pytest.mark.parametrize("name", HERCULES)
+def test_hercules_aligned_kernel(name, bflib, oracle):
+    """das_hercules.hip on every HERCULES-family case (mode 6 also takes the grids too narrow for the
+    automatic rule): both loop orders, sparse transmits, every interpolation, real and IQ data, with and
+    without coherency weighting, checked and unchecked inner loops"""
+    acq = cases.make(name)
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    lib.beamformer_hip_set_das_path(6)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == 5
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq)

@@ -246,3 +246,35 @@ def test_pipeline_without_das_is_planned(L, bflib):
     assert L.beamformer_push_parameters(C.byref(bp))
     assert L.beamformer_hip_describe_plan(0, C.byref(plan))
     assert [plan.stages[i].kind for i in range(plan.stage_count)] in ([], [S.Reshape])
+
+
+@pytest.mark.parametrize("demodulate", [False, True])
+def test_planner_refuses_rows_shorter_than_the_interpolation_support(demodulate, L):
+    """A DAS input row shorter than the taps of its interpolation (1 nearest, 2 linear, 4 cubic;
+    sample_rf, das.glsl:99-124) has no valid sample index, and the kernels' unsigned range tests
+    against S-1 / S-3 would wrap: the plan is refused instead of launched."""
+    I = P.InterpolationMode
+    for interp, support in ((I.Nearest, 1), (I.Linear, 2), (I.Cubic, 4)):
+        for das_samples in (1, 2, 3, 4):
+            raw = das_samples * 2 if demodulate else das_samples
+            acq = cfg.rca("short", 16, 2, 256, (8, 8, 1), (-1e-3, 0, 5e-3), (1e-3, 0, 9e-3), seed=1,
+                          demodulate=demodulate, interp=interp)
+            bp = acq.bp
+            bp.sample_count = raw
+            bp.raw_data_dimensions[0] = raw * bp.acquisition_count
+            for slot, fp in enumerate(acq.filters):
+                assert L.beamformer_create_filter(C.byref(fp), slot, 0)
+            assert L.beamformer_push_simple_parameters(C.byref(bp))
+            plan = P.HipPlan()
+            ok = bool(L.beamformer_hip_describe_plan(0, C.byref(plan)))
+            assert ok == (das_samples >= support), (interp, das_samples, demodulate)
+            if ok:
+                assert plan.das_samples == das_samples
+    # decimation that leaves no sample at all
+    acq = cfg.rca("short", 16, 2, 256, (8, 8, 1), (-1e-3, 0, 5e-3), (1e-3, 0, 9e-3), seed=1, interp=I.Nearest)
+    acq.bp.sample_count = 4
+    acq.bp.decimation_rate = 4
+    acq.bp.raw_data_dimensions[0] = 4 * acq.bp.acquisition_count
+    assert L.beamformer_create_filter(C.byref(acq.filters[0]), 0, 0)
+    assert L.beamformer_push_simple_parameters(C.byref(acq.bp))
+    assert not L.beamformer_hip_describe_plan(0, C.byref(P.HipPlan()))

@@ -1,0 +1,345 @@
+/* microbench.hip -- the per-CU ceilings DESIGN.md prices the DAS kernels against, measured.
+ *
+ * One standalone program (hipcc --offload-arch=gfx950 tools/microbench.hip -o tools/bin/microbench),
+ * prints one JSON object.  Every probe is a loop of inline-asm instructions timed INSIDE the
+ * kernel with s_memtime (shader clock) next to s_memrealtime (100 MHz), so rates come out per
+ * clock per CU at the clock the part actually sustains, and the sustained clock itself is
+ * reported.  Probes (each at several waves per SIMD):
+ *   valu      v_fma_f32, v_pk_fma_f32, v_sqrt_f32, v_sin_f32, v_rcp_f32, v_cvt_flr_i32_f32,
+ *             v_fract_f32: wave-instructions per clock per SIMD
+ *   gather    per-lane global_load_dword / dwordx2 / dwordx4 with 4 loads in flight per wave,
+ *             from a window resident in the CU's L1 (8 KB per block), in the XCD's L2 (2 MB
+ *             shared) -- address patterns: contiguous (coalesced), DAS-like (8-byte aligned,
+ *             neighbouring lanes 0..8 B apart: the interpolation taps of neighbouring voxels),
+ *             random inside the window: bytes per clock per CU
+ *   lds       ds_read_b64, ds_read_b128 (16-B aligned), ds_read2_b64 (16 B at 8-B alignment) with
+ *             the same three patterns: bytes per clock per CU
+ * Nothing here is on the product path; it is the evidence behind roofline.binding in bench.py.
+ */
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Stamp { uint64_t cycles, realtime; };   /* per wave: shader-clock ticks and 100 MHz ticks over the timed loop */
+
+__device__ __forceinline__ uint64_t memtime()     { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ uint64_t memrealtime() { return __builtin_amdgcn_s_memrealtime(); }
+
+/* ------------------------------------------------------------------ VALU issue */
+enum { OP_FMA, OP_PK_FMA, OP_SQRT, OP_SIN, OP_RCP, OP_CVT_FLR, OP_FRACT, OP_MUL, OP_COUNT };
+static const char *op_name[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_sqrt_f32", "v_sin_f32", "v_rcp_f32",
+                                        "v_cvt_flr_i32_f32", "v_fract_f32", "v_mul_f32"};
+
+template <int OP>
+__global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, int iters)
+{
+	/* 8 independent chains per lane, 4 rounds per iteration = 32 instructions per iteration */
+	float a[8]; f32x2 p[8];
+	for (int k = 0; k < 8; k++) { a[k] = 1.0f + 0.001f * (float)(threadIdx.x + k); p[k] = f32x2{a[k], a[k] + 0.5f}; }
+	float b = 0.999f, c = 0.0001f;
+	f32x2 pb = {0.999f, 0.998f}, pc = {0.0001f, 0.0002f};
+	__syncthreads();
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				if constexpr (OP == OP_FMA)     asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+				if constexpr (OP == OP_MUL)     asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+				if constexpr (OP == OP_PK_FMA)  asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pb), "v"(pc));
+				if constexpr (OP == OP_SQRT)    asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
+				if constexpr (OP == OP_SIN)     asm volatile("v_sin_f32 %0, %0" : "+v"(a[k]));
+				if constexpr (OP == OP_RCP)     asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k]));
+				if constexpr (OP == OP_CVT_FLR) asm volatile("v_cvt_flr_i32_f32 %0, %0" : "+v"(a[k]));
+				if constexpr (OP == OP_FRACT)   asm volatile("v_fract_f32 %0, %0" : "+v"(a[k]));
+			}
+		}
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	float s = 0.f;
+	for (int k = 0; k < 8; k++) s += a[k] + p[k].x + p[k].y;
+	if (s == 12345.678f) sink[0] = s;
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		stamps[wave] = Stamp{t1 - t0, r1 - r0};
+	}
+}
+
+/* ------------------------------------------------------------------ per-lane gathers from global memory */
+enum { PAT_COALESCED, PAT_DAS, PAT_RANDOM, PAT_COUNT };
+static const char *pat_name[PAT_COUNT] = {"contiguous", "das_like", "random"};
+
+/* byte offset of lane `lane`'s access number `n` inside a window of `mask + 1` bytes, aligned to `align` */
+template <int PAT>
+__device__ __forceinline__ uint32_t pattern(uint32_t lane, uint32_t n, uint32_t width, uint32_t mask, uint32_t align)
+{
+	uint32_t off;
+	if constexpr (PAT == PAT_COALESCED) off = lane * width + n * 64u * width;
+	else if constexpr (PAT == PAT_DAS)  off = ((lane * 5u) >> 3) * 8u + n * 1000u;      /* 0..8 B between neighbours, 8-B aligned */
+	else { uint32_t h = (lane * 2654435761u) ^ (n * 40503u + 0x9E3779B9u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; off = h; }
+	return (off & mask) & ~(align - 1u);
+}
+
+template <int WIDTH, int PAT>
+__global__ __launch_bounds__(1024) void gather_probe(const char *base, uint32_t window_bytes, uint32_t per_block_window,
+                                                     Stamp *stamps, float *sink, int iters)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	const char *win = base + (per_block_window ? (size_t)blockIdx.x * window_bytes : 0);
+	const uint32_t mask = window_bytes / 2u - 1u;       /* offsets fall in the first half of the (power-of-two) window: the footprint */
+	const uint32_t align = PAT == PAT_COALESCED ? (uint32_t)WIDTH : (WIDTH >= 8 ? 8u : 4u);
+	/* warm the window into the cache */
+	float warm = 0.f;
+	for (uint32_t o = threadIdx.x * 16u; o < window_bytes; o += blockDim.x * 16u) warm += *(const float *)(win + o);
+	__syncthreads();
+	f32x4 acc = {warm, 0.f, 0.f, 0.f};
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		uint32_t off[4];
+		#pragma unroll
+		for (int k = 0; k < 4; k++) off[k] = pattern<PAT>(lane + wave * 7u, (uint32_t)(i * 4 + k), WIDTH, mask, align);
+		if constexpr (WIDTH == 16) {
+			f32x4 d0, d1, d2, d3;
+			asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\t"
+			             "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+			             : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(win) : "memory");
+			acc += d0 + d1 + d2 + d3;
+		} else if constexpr (WIDTH == 8) {
+			f32x2 d0, d1, d2, d3;
+			asm volatile("global_load_dwordx2 %0, %4, %8\n\tglobal_load_dwordx2 %1, %5, %8\n\t"
+			             "global_load_dwordx2 %2, %6, %8\n\tglobal_load_dwordx2 %3, %7, %8\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+			             : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(win) : "memory");
+			acc.x += d0.x + d1.x + d2.x + d3.x; acc.y += d0.y + d1.y + d2.y + d3.y;
+		} else {
+			float d0, d1, d2, d3;
+			asm volatile("global_load_dword %0, %4, %8\n\tglobal_load_dword %1, %5, %8\n\t"
+			             "global_load_dword %2, %6, %8\n\tglobal_load_dword %3, %7, %8\n\ts_waitcnt vmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+			             : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(win) : "memory");
+			acc.x += d0 + d1 + d2 + d3;
+		}
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+	if (lane == 0) stamps[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = Stamp{t1 - t0, r1 - r0};
+}
+
+/* ------------------------------------------------------------------ LDS reads */
+enum { LDS_B64, LDS_B128, LDS_READ2_B64, LDS_B32, LDS_COUNT };
+static const char *lds_name[LDS_COUNT] = {"ds_read_b64", "ds_read_b128", "ds_read2_b64(16B@8)", "ds_read_b32"};
+
+template <int KIND, int PAT>
+__global__ __launch_bounds__(1024) void lds_probe(Stamp *stamps, float *sink, int iters, uint32_t window_bytes)
+{
+	extern __shared__ __attribute__((aligned(16))) char lds[];
+	for (uint32_t o = threadIdx.x * 4u; o < window_bytes; o += blockDim.x * 4u) *(float *)(lds + o) = (float)o;
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t mask = window_bytes / 2u - 1u;
+	constexpr uint32_t WIDTH = KIND == LDS_B64 ? 8 : (KIND == LDS_B32 ? 4 : 16);
+	const uint32_t align = KIND == LDS_B128 ? 16u : (KIND == LDS_B32 ? 4u : 8u);
+	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		uint32_t off[4];
+		#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			uint32_t o = pattern<PAT>(lane + wave * 7u, (uint32_t)(i * 4 + k), WIDTH, mask, align);
+			if (PAT == PAT_COALESCED) o &= ~(WIDTH - 1u);
+			off[k] = o;
+		}
+		if constexpr (KIND == LDS_B128) {
+			f32x4 d0, d1, d2, d3;
+			asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]) : "memory");
+			acc += d0 + d1 + d2 + d3;
+		} else if constexpr (KIND == LDS_READ2_B64) {
+			f32x4 d0, d1, d2, d3;
+			asm volatile("ds_read2_b64 %0, %4 offset1:1\n\tds_read2_b64 %1, %5 offset1:1\n\tds_read2_b64 %2, %6 offset1:1\n\t"
+			             "ds_read2_b64 %3, %7 offset1:1\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]) : "memory");
+			acc += d0 + d1 + d2 + d3;
+		} else if constexpr (KIND == LDS_B64) {
+			f32x2 d0, d1, d2, d3;
+			asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]) : "memory");
+			acc.x += d0.x + d1.x + d2.x + d3.x; acc.y += d0.y + d1.y + d2.y + d3.y;
+		} else {
+			float d0, d1, d2, d3;
+			asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]) : "memory");
+			acc.x += d0 + d1 + d2 + d3;
+		}
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+	if (lane == 0) stamps[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = Stamp{t1 - t0, r1 - r0};
+}
+
+/* ------------------------------------------------------------------ host side */
+struct Result { double cycles_per_wave, clock_ghz, wall_ms; };
+
+static Stamp *d_stamps; static float *d_sink; static std::vector<Stamp> h_stamps;
+static int n_cu = 256;
+
+template <typename F>
+static Result run(F launch, int waves_total)
+{
+	hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+	launch();                                         /* warm up (code load, clocks) */
+	CHECK(hipDeviceSynchronize());
+	CHECK(hipEventRecord(e0));
+	launch();
+	CHECK(hipEventRecord(e1));
+	CHECK(hipEventSynchronize(e1));
+	float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+	h_stamps.resize(waves_total);
+	CHECK(hipMemcpy(h_stamps.data(), d_stamps, sizeof(Stamp) * waves_total, hipMemcpyDeviceToHost));
+	std::vector<double> cyc(waves_total), clk(waves_total);
+	for (int i = 0; i < waves_total; i++) {
+		cyc[i] = (double)h_stamps[i].cycles;
+		clk[i] = h_stamps[i].realtime ? (double)h_stamps[i].cycles / ((double)h_stamps[i].realtime * 10e-9) * 1e-9 : 0.0;
+	}
+	std::nth_element(cyc.begin(), cyc.begin() + waves_total / 2, cyc.end());
+	std::nth_element(clk.begin(), clk.begin() + waves_total / 2, clk.end());
+	CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+	return Result{cyc[waves_total / 2], clk[waves_total / 2], ms};
+}
+
+static std::string json;
+static void emit(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+#include <cstdarg>
+static void emit(const char *fmt, ...) { char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); json += buf; }
+
+template <int OP> static void valu_case(bool first)
+{
+	const int iters = 16000;                           /* 512k instructions per wave */
+	for (int wps : {1, 2, 4, 8}) {
+		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
+		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
+		Result r = run([&] { hipLaunchKernelGGL((valu_probe<OP>), dim3(blocks), dim3(64 * waves_per_block), 0, 0, d_stamps, d_sink, iters); }, waves);
+		double inst = 32.0 * iters;
+		double per_simd = wps * inst / r.cycles_per_wave;          /* wave-instructions per clock per SIMD */
+		emit("%s{\"op\":\"%s\",\"waves_per_simd\":%d,\"wave_inst_per_clk_per_simd\":%.4f,\"cycles_per_wave_inst\":%.3f,"
+		     "\"lanes_per_clk_per_cu\":%.1f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", (first && wps == 1) ? "" : ",\n  ",
+		     op_name[OP], wps, per_simd, 1.0 / per_simd, per_simd * 64 * 4, r.clock_ghz, r.wall_ms);
+	}
+}
+
+static char *d_window;
+
+template <int WIDTH, int PAT> static void gather_case(const char *level, uint32_t window, bool per_block, bool &first)
+{
+	const int iters = 2000;
+	for (int wps : {2, 4, 8}) {
+		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
+		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
+		Result r = run([&] { hipLaunchKernelGGL((gather_probe<WIDTH, PAT>), dim3(blocks), dim3(64 * waves_per_block), 0, 0,
+		                                        d_window, window, per_block ? 1u : 0u, d_stamps, d_sink, iters); }, waves);
+		double bytes_per_wave = 4.0 * iters * 64 * WIDTH;
+		double b_clk_cu = 4.0 * wps * bytes_per_wave / r.cycles_per_wave;
+		emit("%s{\"inst\":\"global_load_%s\",\"level\":\"%s\",\"window_bytes\":%u,\"pattern\":\"%s\",\"waves_per_simd\":%d,"
+		     "\"bytes_per_clk_per_cu\":%.2f,\"clk_per_wave_inst_per_cu\":%.2f,\"clock_ghz\":%.3f,\"chip_TBps\":%.2f,\"wall_ms\":%.3f}",
+		     first ? "" : ",\n  ", WIDTH == 16 ? "dwordx4" : (WIDTH == 8 ? "dwordx2" : "dword"), level, window, pat_name[PAT], wps,
+		     b_clk_cu, 64.0 * WIDTH / b_clk_cu, r.clock_ghz, b_clk_cu * n_cu * r.clock_ghz * 1e9 / 1e12, r.wall_ms);
+		first = false;
+	}
+}
+
+template <int KIND, int PAT> static void lds_case(bool &first)
+{
+	const int iters = 4000;
+	const uint32_t window = 32768;
+	constexpr int WIDTH = KIND == LDS_B64 ? 8 : (KIND == LDS_B32 ? 4 : 16);
+	for (int wps : {1, 2, 4, 8}) {
+		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
+		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
+		Result r = run([&] { hipLaunchKernelGGL((lds_probe<KIND, PAT>), dim3(blocks), dim3(64 * waves_per_block), window, 0,
+		                                        d_stamps, d_sink, iters, window); }, waves);
+		double bytes_per_wave = 4.0 * iters * 64 * WIDTH;
+		double b_clk_cu = 4.0 * wps * bytes_per_wave / r.cycles_per_wave;
+		emit("%s{\"inst\":\"%s\",\"pattern\":\"%s\",\"waves_per_simd\":%d,\"bytes_per_clk_per_cu\":%.2f,"
+		     "\"clk_per_wave_inst_per_cu\":%.2f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
+		     first ? "" : ",\n  ", lds_name[KIND], pat_name[PAT], wps, b_clk_cu, 64.0 * WIDTH / b_clk_cu, r.clock_ghz, r.wall_ms);
+		first = false;
+	}
+}
+
+int main(int argc, char **argv)
+{
+	CHECK(hipSetDevice(0));
+	hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+	n_cu = prop.multiProcessorCount;
+	CHECK(hipMalloc(&d_stamps, sizeof(Stamp) * 16384));
+	CHECK(hipMalloc(&d_sink, 64));
+	CHECK(hipMalloc(&d_window, 512u << 20));
+	CHECK(hipMemset(d_window, 0, 512u << 20));
+	bool quick = argc > 1 && !strcmp(argv[1], "--quick");
+
+	emit("{\"device\":\"%s\",\"arch\":\"%s\",\"compute_units\":%d,\"clock_rate_khz\":%d,\n", prop.name, prop.gcnArchName, n_cu, prop.clockRate);
+	emit(" \"method\":\"in-kernel s_memtime (shader clock) and s_memrealtime (100 MHz) around a loop of inline-asm instructions; median over waves; "
+	     "every CU busy with the stated waves per SIMD\",\n");
+
+	emit(" \"valu\":[\n  ");
+	valu_case<OP_FMA>(true);
+	valu_case<OP_MUL>(false);
+	valu_case<OP_PK_FMA>(false);
+	valu_case<OP_SQRT>(false);
+	valu_case<OP_SIN>(false);
+	valu_case<OP_RCP>(false);
+	valu_case<OP_CVT_FLR>(false);
+	valu_case<OP_FRACT>(false);
+	emit("],\n");
+
+	bool first = true;
+	emit(" \"gather\":[\n  ");
+	/* L1: each block owns an 8 KB window (<= 2 blocks per CU: 16 KB of the 32 KB L1) */
+	gather_case<16, PAT_COALESCED>("L1", 8192, true, first);
+	gather_case<16, PAT_DAS>("L1", 8192, true, first);
+	gather_case<16, PAT_RANDOM>("L1", 8192, true, first);
+	gather_case<8, PAT_COALESCED>("L1", 8192, true, first);
+	gather_case<8, PAT_DAS>("L1", 8192, true, first);
+	gather_case<8, PAT_RANDOM>("L1", 8192, true, first);
+	gather_case<4, PAT_COALESCED>("L1", 8192, true, first);
+	gather_case<4, PAT_DAS>("L1", 8192, true, first);
+	gather_case<4, PAT_RANDOM>("L1", 8192, true, first);
+	if (!quick) {
+		/* L2: all blocks share one 2 MB window (fits each XCD's 4 MB L2, not the 32 KB L1) */
+		gather_case<16, PAT_COALESCED>("L2", 2u << 20, false, first);
+		gather_case<16, PAT_RANDOM>("L2", 2u << 20, false, first);
+		gather_case<8, PAT_RANDOM>("L2", 2u << 20, false, first);
+		/* Infinity Cache: 128 MB shared window */
+		gather_case<16, PAT_RANDOM>("MALL", 128u << 20, false, first);
+	}
+	emit("],\n");
+
+	first = true;
+	emit(" \"lds\":[\n  ");
+	lds_case<LDS_B128, PAT_COALESCED>(first);
+	lds_case<LDS_B128, PAT_RANDOM>(first);
+	lds_case<LDS_READ2_B64, PAT_COALESCED>(first);
+	lds_case<LDS_READ2_B64, PAT_DAS>(first);
+	lds_case<LDS_READ2_B64, PAT_RANDOM>(first);
+	lds_case<LDS_B64, PAT_COALESCED>(first);
+	lds_case<LDS_B64, PAT_DAS>(first);
+	lds_case<LDS_B64, PAT_RANDOM>(first);
+	lds_case<LDS_B32, PAT_DAS>(first);
+	lds_case<LDS_B32, PAT_RANDOM>(first);
+	emit("]}\n");
+	fputs(json.c_str(), stdout);
+	return 0;
+}
