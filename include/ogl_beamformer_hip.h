@@ -31,6 +31,27 @@ extern "C" {
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_device(int32_t device_index);
 BEAMFORMER_LIB_EXPORT int32_t  beamformer_hip_get_device(void);
 
+/* Several devices behind the same push-RF / pull-image calls (the voxel grid shards,
+ * the RF does not).  ONE process, `count` devices (1..8; HIP ordinals; the same ordinal may be listed more
+ * than once, which is how a one-GPU box tests the path).  Must precede the first call that touches a
+ * device; afterwards it only succeeds for the set already in use (beamformer_hip_shutdown releases it).
+ *   - device_indices[0] is the ingest device: beamformer_push_data_with_compute /
+ *     beamformer_hip_push_device_data_with_compute land the RF there exactly as with one device;
+ *   - the channel-mapped RF is then copied to every other device (hipMemcpyPeerAsync over xGMI, one copy
+ *     stream per destination, three RF slots deep so the copies of frame n+1 run beside the kernels of
+ *     frame n) and each device runs the whole stage list on its own contiguous z-slab of the block's
+ *     grid (of its output shard, if one is set): slab sizes differ by at most one plane, earlier devices
+ *     take the larger ones.  No reduction collective -- voxels are independent (das.glsl:368-407);
+ *   - beamformer_get_last_frames returns whole frames: the slabs stitched in z order, each frame rounded
+ *     to 64 bytes exactly as one device exports it (lib/ogl_beamformer_lib.c:656-702 semantics);
+ *     a slab is bit-identical to the same planes of a one-device frame;
+ *   - beamformer_hip_frame_min_max combines the per-slab extremes on the host; the Sum and display
+ *     reductions run per slab and are stitched the same way; beamformer_compute_timings reports, per
+ *     stage, the slowest device; beamformer_hip_get_last_frame_info describes the ingest device's slab;
+ *     beamformer_hip_set_stream is refused (a stream belongs to one device). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_devices(const int32_t *device_indices, uint32_t count);
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_device_count(void);
+
 /* Run all work on the caller's stream (a hipStream_t; 0 restores the library's own
  * stream).  Lets a host framework order its own device work (an RCCL broadcast of the RF
  * frame, a consumer of the image) against the beamformer without host synchronisation. */
@@ -83,6 +104,11 @@ typedef struct {
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
+
+/* The newest frame as ONE of the devices of beamformer_hip_set_devices saw it: its slab's voxels and
+ * pairs, its own event times.  (beamformer_hip_get_last_frame_timings reports the ingest device's stage
+ * times with the voxel and pair counts of the whole frame and the slowest device's frame time.) */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out);
 
 /* When enabled, every frame also runs a geometry-only kernel that counts the triples that
  * pass the apodization test (G in BASELINE.md section 4).  Off by default. */

@@ -73,23 +73,13 @@ constexpr uint32_t kTimingSlots = 32;    /* beamformer_compute_stats.c: 32-frame
 constexpr uint32_t kStageIngest    = 0xFFFF;
 constexpr uint32_t kStagePairCount = 0xFFFE;
 
-struct Context {
-	/* library-level state that needs no device */
-	BeamformerLibErrorKind last_error = BeamformerLibErrorKind_None;
-	int32_t        timeout_ms = 0;
-	ParameterBlock blocks[BeamformerMaxParameterBlocks];
-	uint32_t       reserved_parameter_blocks = 1;              /* beamformer.c:249-263 */
-	BeamformerLiveImagingParameters live{};
-	uint32_t       live_dirty_flags = 0;
-	uint64_t       frame_ring_bytes = 0;                       /* beamformed_frame_buffer_size */
-	uint32_t       das_path_mode = 0;
-	bool           count_pairs = false;
-	bool           hilbert_enabled = false;                    /* beamformer_hip_enable_hilbert */
+constexpr uint32_t kMaxDevices = 8;      /* one node of MI355X */
 
-	/* device state */
-	int          requested_device = -1;
-	int          device = -1;
-	bool         device_ready = false;
+/* Everything that lives on one HIP device.  A process normally owns one (devices[0]); after
+ * beamformer_hip_set_devices it owns several, each beamforming one z-slab of every frame. */
+struct Device {
+	int          device = -1;                                  /* HIP ordinal */
+	uint32_t     index = 0;                                    /* position in Context::devices */
 	hipStream_t  own_stream = nullptr, stream = nullptr;
 	PlanState    plans[BeamformerMaxParameterBlocks];
 	DeviceBuffer raw_staging[BeamformerMaxRawDataFramesInFlight];
@@ -108,6 +98,34 @@ struct Context {
 	uint64_t     replan_frame = 0;                             /* first frame of the current plan */
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
 	DeviceBuffer hercules_table;                               /* das_hercules.hip: per-row lateral table, rebuilt per launch */
+	/* multi-device frames (executor.cpp push_multi): the RF of slot k landed on this device / the frame
+	 * that read slot k has finished */
+	hipStream_t  peer_stream = nullptr;                        /* carries the copies INTO this device */
+	hipEvent_t   rf_landed[BeamformerMaxRawDataFramesInFlight]{}, rf_consumed[BeamformerMaxRawDataFramesInFlight]{};
+	bool         consumed_pending[BeamformerMaxRawDataFramesInFlight]{};
+	uint32_t     slab_first = 0, slab_count = 0;               /* planes of the current multi-device frame */
+};
+
+struct Context {
+	/* library-level state that needs no device */
+	BeamformerLibErrorKind last_error = BeamformerLibErrorKind_None;
+	int32_t        timeout_ms = 0;
+	ParameterBlock blocks[BeamformerMaxParameterBlocks];
+	uint32_t       reserved_parameter_blocks = 1;              /* beamformer.c:249-263 */
+	BeamformerLiveImagingParameters live{};
+	uint32_t       live_dirty_flags = 0;
+	uint64_t       frame_ring_bytes = 0;                       /* beamformed_frame_buffer_size */
+	uint32_t       das_path_mode = 0;
+	bool           count_pairs = false;
+	bool           hilbert_enabled = false;                    /* beamformer_hip_enable_hilbert */
+
+	/* device state */
+	int          requested_devices[kMaxDevices]{-1, -1, -1, -1, -1, -1, -1, -1};
+	uint32_t     requested_count = 0;                          /* 0: one device, chosen from the environment */
+	bool         device_ready = false;
+	Device       devices[kMaxDevices];
+	uint32_t     device_count = 1;
+	Device      *cur = &devices[0];                            /* the device the executor functions act on */
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;
 };
@@ -122,6 +140,7 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 bool wait_for_frames(int32_t timeout_ms);
 bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms);
 bool last_frame_timings(BeamformerHipFrameTimings *out);
+bool device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out);
 bool fill_stats_table(BeamformerComputeStatsTable *out);
 bool frame_min_max(float out[2]);
 bool sum_last_frames(uint32_t count, void *out, uint64_t out_size);

@@ -67,72 +67,123 @@ uint64_t default_frame_ring_bytes()
 	return 4ull << 30;
 }
 
+static bool init_one_device(Context &c, Device &d, int ordinal, uint32_t index)
+{
+	if (!HIP_OK(hipSetDevice(ordinal))) return false;
+	if (!HIP_OK(hipStreamCreateWithFlags(&d.own_stream, hipStreamNonBlocking))) return false;
+	if (!d.stream) d.stream = d.own_stream;
+	if (!HIP_OK(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking))) return false;
+	if (!HIP_OK(hipStreamCreateWithFlags(&d.peer_stream, hipStreamNonBlocking))) return false;
+	for (uint32_t k = 0; k < BeamformerMaxRawDataFramesInFlight; k++) {
+		if (!HIP_OK(hipEventCreateWithFlags(&d.rf_landed[k], hipEventDisableTiming))) return false;
+		if (!HIP_OK(hipEventCreateWithFlags(&d.rf_consumed[k], hipEventDisableTiming))) return false;
+		d.consumed_pending[k] = false;
+	}
+	if (!d.ring.ensure(c.frame_ring_bytes)) return false;
+	d.frames.assign(BeamformerMaxBacklogFrames, FrameRecord{});
+	d.device = ordinal; d.index = index;
+	return true;
+}
+
+/* Makes `dev` the device the executor functions act on. */
+static bool select_device(uint32_t dev)
+{
+	Context &c = g_context;
+	c.cur = &c.devices[dev];
+	return HIP_OK(hipSetDevice(c.cur->device));
+}
+
 bool ensure_device()
 {
 	Context &c = g_context;
 	if (c.device_ready) {
-		if (!HIP_OK(hipSetDevice(c.device))) return set_error(BeamformerLibErrorKind_SharedMemory);
+		c.cur = &c.devices[0];
+		if (!HIP_OK(hipSetDevice(c.cur->device))) return set_error(BeamformerLibErrorKind_SharedMemory);
 		return true;
 	}
 	int count = 0;
 	if (!HIP_OK(hipGetDeviceCount(&count)) || count <= 0) return set_error(BeamformerLibErrorKind_SharedMemory);
-	int device = c.requested_device;
-	if (device < 0) {
+	int      ordinals[kMaxDevices];
+	uint32_t n = c.requested_count;
+	if (n == 0) {
 		const char *e = std::getenv("BEAMFORMER_HIP_DEVICE");
 		if (!e) e = std::getenv("LOCAL_RANK");
-		device = e ? std::atoi(e) : 0;
+		ordinals[0] = e ? std::atoi(e) : 0;
+		n = 1;
+	} else {
+		for (uint32_t i = 0; i < n; i++) ordinals[i] = c.requested_devices[i];
 	}
-	if (device < 0 || device >= count) return set_error(BeamformerLibErrorKind_SharedMemory);
-	if (!HIP_OK(hipSetDevice(device))) return set_error(BeamformerLibErrorKind_SharedMemory);
-	if (!HIP_OK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking)))
-		return set_error(BeamformerLibErrorKind_SharedMemory);
-	if (!c.stream) c.stream = c.own_stream;
-	if (!HIP_OK(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking)))
-		return set_error(BeamformerLibErrorKind_SharedMemory);
+	for (uint32_t i = 0; i < n; i++)
+		if (ordinals[i] < 0 || ordinals[i] >= count) return set_error(BeamformerLibErrorKind_SharedMemory);
 	if (!c.frame_ring_bytes) c.frame_ring_bytes = default_frame_ring_bytes();
-	if (!c.ring.ensure(c.frame_ring_bytes)) return set_error(BeamformerLibErrorKind_SharedMemory);
-	c.frames.assign(BeamformerMaxBacklogFrames, FrameRecord{});
-	c.device = device;
-	c.device_ready = true;
+	bool ok = true;
+	for (uint32_t i = 0; i < n && ok; i++) ok = init_one_device(c, c.devices[i], ordinals[i], i);
+	/* peers copy RF slabs from the ingest device: let every device reach it directly over xGMI
+	 * (errors here only mean "already enabled" or "same device": the copies work either way) */
+	for (uint32_t i = 1; i < n && ok; i++) {
+		if (c.devices[i].device == c.devices[0].device) continue;
+		(void)hipSetDevice(c.devices[i].device);
+		(void)hipDeviceEnablePeerAccess(c.devices[0].device, 0);
+		(void)hipSetDevice(c.devices[0].device);
+		(void)hipDeviceEnablePeerAccess(c.devices[i].device, 0);
+		(void)hipGetLastError();
+	}
+	c.device_count = n;
+	c.cur = &c.devices[0];
+	c.device_ready = true;                      /* so that shutdown_device releases a partial set-up */
+	if (!ok || !HIP_OK(hipSetDevice(c.devices[0].device))) { shutdown_device(); return set_error(BeamformerLibErrorKind_SharedMemory); }
 	return true;
+}
+
+static void release_one_device(Device &d)
+{
+	if (d.device < 0) return;
+	(void)hipSetDevice(d.device);
+	(void)hipDeviceSynchronize();
+	for (auto &p : d.plans) {
+		p.hadamard_t.release(); p.hadamard_base.release(); p.readi_hadamard.release(); p.transmits.release();
+		p.sparse.release(); p.mapping.release();
+		for (auto &t : p.taps) t.release();
+		p.taps.clear(); p.valid = false;
+	}
+	for (auto &b : d.raw_staging) b.release();
+	for (auto &u : d.upload) {
+		if (u.pinned) (void)hipHostFree(u.pinned);
+		if (u.copied) (void)hipEventDestroy(u.copied);
+		if (u.consumed) (void)hipEventDestroy(u.consumed);
+		u = UploadSlot{};
+	}
+	if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
+	if (d.peer_stream) (void)hipStreamDestroy(d.peer_stream);
+	d.copy_stream = d.peer_stream = nullptr;
+	for (uint32_t k = 0; k < BeamformerMaxRawDataFramesInFlight; k++) {
+		if (d.rf_landed[k])   (void)hipEventDestroy(d.rf_landed[k]);
+		if (d.rf_consumed[k]) (void)hipEventDestroy(d.rf_consumed[k]);
+		d.rf_landed[k] = d.rf_consumed[k] = nullptr; d.consumed_pending[k] = false;
+	}
+	for (auto &b : d.rf) b.release();
+	for (auto &b : d.scratch) b.release();
+	d.ring.release(); d.pair_counter.release(); d.minmax_scratch.release(); d.sum_scratch.release();
+	d.hercules_table.release();
+	for (auto &t : d.timing) {
+		if (t.created) for (auto &e : t.events) if (e) (void)hipEventDestroy(e);
+		t = TimingSlot{};
+	}
+	if (d.own_stream) (void)hipStreamDestroy(d.own_stream);
+	if (d.stream == d.own_stream || d.index != 0) d.stream = nullptr;   /* a caller's stream on the first device stays selected */
+	d.own_stream = nullptr;
+	d.frames.clear();
+	d.ring_next_offset = 0; d.frame_counter = 0; d.rf_index = 0;
+	d.have_sample = false; d.last_sampled_frame = 0; d.last_sampled_block = 0; d.replan_frame = 0;
+	d.device = -1;
 }
 
 void shutdown_device()
 {
 	Context &c = g_context;
 	if (!c.device_ready) return;
-	(void)hipSetDevice(c.device);
-	(void)hipDeviceSynchronize();
-	for (auto &p : c.plans) {
-		p.hadamard_t.release(); p.hadamard_base.release(); p.readi_hadamard.release(); p.transmits.release();
-		p.sparse.release(); p.mapping.release();
-		for (auto &t : p.taps) t.release();
-		p.taps.clear(); p.valid = false;
-	}
-	for (auto &b : c.raw_staging) b.release();
-	for (auto &u : c.upload) {
-		if (u.pinned) (void)hipHostFree(u.pinned);
-		if (u.copied) (void)hipEventDestroy(u.copied);
-		if (u.consumed) (void)hipEventDestroy(u.consumed);
-		u = UploadSlot{};
-	}
-	if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
-	c.copy_stream = nullptr;
-	for (auto &b : c.rf) b.release();
-	for (auto &b : c.scratch) b.release();
-	c.ring.release(); c.pair_counter.release(); c.minmax_scratch.release(); c.sum_scratch.release();
-	c.hercules_table.release();
-	for (auto &t : c.timing) {
-		if (t.created) for (auto &e : t.events) if (e) (void)hipEventDestroy(e);
-		t = TimingSlot{};
-	}
-	if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
-	if (c.stream == c.own_stream) c.stream = nullptr;
-	c.own_stream = nullptr;
-	c.frames.clear();
-	c.ring_next_offset = 0; c.frame_counter = 0; c.rf_index = 0;
-	c.have_sample = false; c.last_sampled_frame = 0; c.last_sampled_block = 0; c.replan_frame = 0;
-	c.device_ready = false; c.device = -1;
+	for (uint32_t i = 0; i < kMaxDevices; i++) release_one_device(c.devices[i]);
+	c.device_ready = false; c.device_count = 1; c.cur = &c.devices[0];
 	for (auto &b : c.blocks) b.dirty |= Dirty_Parameters;   /* plans are rebuilt on next use */
 }
 
@@ -150,16 +201,20 @@ static uint16_t half_bits_pm1(float v) { return v < 0 ? 0xBC00 : 0x3C00; }   /* 
 static PlanState *commit_block(uint32_t block)
 {
 	Context &c = g_context;
+	Device  &d = *c.cur;
 	ParameterBlock &pb = c.blocks[block];
-	PlanState &ps = c.plans[block];
+	PlanState &ps = d.plans[block];
 	if (ps.valid && !pb.dirty) return &ps;
+	/* with several devices every one of them replans: the change reaches them through push_multi,
+	 * which commits the ingest device LAST -- only that commit clears the dirty bits */
+	const bool clears_dirty = c.device_count == 1 || d.index == 0;
 
 	std::string error;
 	Plan plan;
 	if (!build_plan(pb, plan, error, c.hilbert_enabled)) { ps.valid = false; ps.error = error; return nullptr; }
 	ps.plan = std::move(plan);
 	const BeamformerParameters &bp = pb.parameters;
-	hipStream_t s = c.stream;
+	hipStream_t s = d.stream;
 
 	/* a table a kernel of an earlier frame may still be reading must not be overwritten
 	 * under it: replanning is rare, so simply drain the stream first */
@@ -223,13 +278,13 @@ static PlanState *commit_block(uint32_t block)
 		}
 	}
 	if (ps.plan.intermediate_bytes) {
-		ok &= c.scratch[0].ensure(ps.plan.intermediate_bytes + 64);
-		ok &= c.scratch[1].ensure(ps.plan.intermediate_bytes + 64);
+		ok &= d.scratch[0].ensure(ps.plan.intermediate_bytes + 64);
+		ok &= d.scratch[1].ensure(ps.plan.intermediate_bytes + 64);
 	}
 	/* host vectors above must outlive the async copies out of pageable memory */
 	ok &= HIP_OK(hipStreamSynchronize(s));
 	if (!ok) { ps.valid = false; ps.error = "device allocation or upload failed"; return nullptr; }
-	pb.dirty = 0;
+	if (clears_dirty) pb.dirty = 0;
 	ps.valid = true;
 	return &ps;
 }
@@ -238,19 +293,20 @@ static PlanState *commit_block(uint32_t block)
 static FrameRecord *next_frame(const uint32_t points[3], bool complex_frame, uint32_t block)
 {
 	Context &c = g_context;
+	Device  &d = *c.cur;
 	int kind = complex_frame ? BeamformerDataKind_Float32Complex : BeamformerDataKind_Float32;
 	uint64_t bytes = round_up((uint64_t)points[0] * points[1] * points[2] * (uint64_t)bf_kind_byte_size[kind], 64);
-	if (bytes > c.ring.size) return nullptr;
-	if (c.ring_next_offset > c.ring.size - bytes) c.ring_next_offset = 0;
-	uint64_t id = c.frame_counter++;
-	FrameRecord *f = &c.frames[id % c.frames.size()];
+	if (bytes > d.ring.size) return nullptr;
+	if (d.ring_next_offset > d.ring.size - bytes) d.ring_next_offset = 0;
+	uint64_t id = d.frame_counter++;
+	FrameRecord *f = &d.frames[id % d.frames.size()];
 	/* records whose storage this frame reuses stop being exportable */
-	for (FrameRecord &old : c.frames)
-		if (old.bytes && old.offset < c.ring_next_offset + bytes && c.ring_next_offset < old.offset + old.bytes) old.bytes = 0;
-	f->offset = c.ring_next_offset; f->bytes = bytes;
+	for (FrameRecord &old : d.frames)
+		if (old.bytes && old.offset < d.ring_next_offset + bytes && d.ring_next_offset < old.offset + old.bytes) old.bytes = 0;
+	f->offset = d.ring_next_offset; f->bytes = bytes;
 	f->points[0] = points[0]; f->points[1] = points[1]; f->points[2] = points[2];
 	f->data_kind = kind; f->id = (uint32_t)id; f->block = block;
-	c.ring_next_offset += bytes;
+	d.ring_next_offset += bytes;
 	return f;
 }
 
@@ -510,14 +566,15 @@ static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
 static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ingest_timed)
 {
 	Context &c = g_context;
+	Device  &d = *c.cur;
 	PlanState *ps = commit_block(block);
 	if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
 	const Plan &plan = ps->plan;
 	const ParameterBlock &pb = c.blocks[block];
 	const BeamformerParameters &bp = pb.parameters;
-	hipStream_t s = c.stream;
+	hipStream_t s = d.stream;
 
-	TimingSlot &t = c.timing[c.frame_counter % kTimingSlots];
+	TimingSlot &t = d.timing[d.frame_counter % kTimingSlots];
 	if (!t.created) {
 		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
 		t.created = true;
@@ -552,13 +609,13 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			a.interleave = !bf_kind_complex[st.in_kind] && bf_kind_complex[st.out_kind];
 			a.left  = cur;
 			a.right = (const char *)cur + (size_t)Sd * C * A * (size_t)bf_kind_byte_size[st.in_kind];   /* :1384-1385 */
-			a.out = c.scratch[toggle].ptr;
+			a.out = d.scratch[toggle].ptr;
 			ok &= HIP_OK(bf_launch_reshape(&a, s));
-			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+			cur = a.out; cur_elements_bytes = (int64_t)d.scratch[toggle].size; toggle ^= 1;
 		}break;
 		case BeamformerShaderKind_Decode:{
 			BfDecodeArgs a{};
-			a.in = cur; a.out = c.scratch[toggle].ptr;
+			a.in = cur; a.out = d.scratch[toggle].ptr;
 			a.hadamard_t = (const float *)ps->hadamard_t.ptr;
 			a.hadamard_base_order = (c.das_path_mode & 0x20) ? 0 : plan.hadamard_base_order;
 			a.hadamard_base = a.hadamard_base_order ? (const float *)ps->hadamard_base.ptr : nullptr;
@@ -566,11 +623,11 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			for (int k = 0; k < 3; k++) a.out_stride[k] = st.out_stride[k];
 			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
 			ok &= HIP_OK(bf_launch_decode(&a, s));
-			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+			cur = a.out; cur_elements_bytes = (int64_t)d.scratch[toggle].size; toggle ^= 1;
 		}break;
 		case BeamformerShaderKind_Hilbert:{
 			BfFilterArgs a{};
-			a.in = cur; a.out = c.scratch[toggle].ptr;
+			a.in = cur; a.out = d.scratch[toggle].ptr;
 			a.coefficients  = (const float *)ps->taps[i].ptr;
 			a.filter_length = (uint32_t)st.filter.length;
 			a.sample_count  = Sd;
@@ -579,13 +636,13 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			a.channels = C; a.transmits = A;
 			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
 			ok &= HIP_OK(bf_launch_hilbert(&a, s));
-			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+			cur = a.out; cur_elements_bytes = (int64_t)d.scratch[toggle].size; toggle ^= 1;
 		}break;
 		case BeamformerShaderKind_Filter:
 		case BeamformerShaderKind_Demodulate:{
 			bool demod = st.kind == BeamformerShaderKind_Demodulate;
 			BfFilterArgs a{};
-			a.in = cur; a.out = c.scratch[toggle].ptr;
+			a.in = cur; a.out = d.scratch[toggle].ptr;
 			a.coefficients   = (const float *)ps->taps[i].ptr;
 			a.phasors        = demod ? a.coefficients + st.filter.taps.size() : nullptr;
 			a.filter_length  = (uint32_t)st.filter.length;
@@ -604,22 +661,27 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			a.channels = C; a.transmits = A;
 			a.in_kind = st.in_kind; a.out_kind = st.out_kind;
 			ok &= HIP_OK(bf_launch_filter(&a, s));
-			cur = a.out; cur_elements_bytes = (int64_t)c.scratch[toggle].size; toggle ^= 1;
+			cur = a.out; cur_elements_bytes = (int64_t)d.scratch[toggle].size; toggle ^= 1;
 		}break;
 		case BeamformerShaderKind_DAS:{
 			uint32_t zfirst = 0, zcount = plan.output_points[2];
 			if (pb.shard_z_count) { zfirst = pb.shard_z_first; zcount = pb.shard_z_count; }
+			if (c.device_count > 1) { zfirst = d.slab_first; zcount = d.slab_count; }   /* this device's z-slab (push_multi) */
 			uint32_t points[3] = {plan.output_points[0], plan.output_points[1], zcount};
 			FrameRecord *f = next_frame(points, plan.iq_pipeline, block);
 			if (!f) return set_error(BeamformerLibErrorKind_FrameSizeOverflow);
 			f->timing_slot = (int)(f->id % kTimingSlots);
+			if (zcount == 0) {           /* more devices than planes: this device holds an empty slab of the frame */
+				t.das_voxels = 0; t.das_taps = 0; t.das_sample_bytes = 0; t.das_path = 0; t.frame_id = f->id;
+				break;
+			}
 
 			BfDasArgs a{};
 			std::memcpy(a.xdc_transform,   bp.xdc_transform,         sizeof(a.xdc_transform));
 			std::memcpy(a.voxel_transform, plan.das_voxel_transform, sizeof(a.voxel_transform));
 			a.pitch[0] = bp.xdc_element_pitch[0]; a.pitch[1] = bp.xdc_element_pitch[1];
 			a.rf  = cur;
-			a.out = (char *)c.ring.ptr + f->offset;
+			a.out = (char *)d.ring.ptr + f->offset;
 			a.transmits       = (const BfTransmit *)ps->transmits.ptr;
 			a.sparse_elements = (const int16_t *)ps->sparse.ptr;
 			a.readi_hadamard  = (const uint16_t *)ps->readi_hadamard.ptr;
@@ -694,11 +756,11 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 					}
 				} else if (BfHerculesArgs hq{}; das_mode != 1 &&
 				           plan_hercules(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, das_mode == 6, hq) &&
-				           c.hercules_table.ensure(((size_t)hq.table_pitch + 2) * a.size[1] * sizeof(float))) {
+				           d.hercules_table.ensure(((size_t)hq.table_pitch + 2) * a.size[1] * sizeof(float))) {
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					hq.zero_offset = (uint32_t)used;            /* as for the gather kernel above */
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					hq.table    = (float *)c.hercules_table.ptr;
+					hq.table    = (float *)d.hercules_table.ptr;
 					hq.extremes = hq.table + (size_t)hq.table_pitch * a.size[1];
 					ok &= HIP_OK(bf_launch_das_hercules(&a, &hq, s));
 					das_path = 5;
@@ -725,8 +787,8 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 				if (c.count_pairs) {
 					/* geometry-only recount of the apodization test; its own segment so that it
 					 * stays out of the DAS time */
-					ok &= c.pair_counter.ensure(sizeof(unsigned long long) * kTimingSlots);
-					a.pair_counter = (unsigned long long *)c.pair_counter.ptr + (f->id % kTimingSlots);
+					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * kTimingSlots);
+					a.pair_counter = (unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots);
 					ok &= HIP_OK(hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned long long), s));
 					segment((uint32_t)st.kind);
 					ok &= HIP_OK(bf_launch_das_count(&a, s));
@@ -755,20 +817,69 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 		FrameRecord *f = next_frame(points, plan.iq_pipeline, block);
 		if (!f) return set_error(BeamformerLibErrorKind_FrameSizeOverflow);
 		f->timing_slot = (int)(f->id % kTimingSlots);
-		ok &= HIP_OK(hipMemsetAsync((char *)c.ring.ptr + f->offset, 0, f->bytes, s));
+		ok &= HIP_OK(hipMemsetAsync((char *)d.ring.ptr + f->offset, 0, f->bytes, s));
 		t.das_voxels = 0; t.das_taps = 0; t.das_sample_bytes = 0; t.das_path = 0; t.frame_id = f->id;
 	}
 	if (!ok) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	return true;
 }
 
+/* z-slab of device `i` of `n` over `planes` planes starting at `first`: contiguous, sizes differing by
+ * at most one, earlier devices take the larger slabs (ogl_beamforming_amd/sharding.py uses the same rule) */
+static void device_slab(uint32_t i, uint32_t n, uint32_t first, uint32_t planes, uint32_t &z_first, uint32_t &z_count)
+{
+	uint32_t base = planes / n, extra = planes % n;
+	z_count = base + (i < extra ? 1u : 0u);
+	z_first = first + i * base + (i < extra ? i : extra);
+}
+
+/* Several devices, one frame: the channel-mapped RF that the ingest device (devices[0])
+ * holds at `src` is copied to every peer's RF slot -- hipMemcpyPeerAsync, one stream per destination, so
+ * the copies run side by side on their xGMI links and, three RF slots deep, beside the kernels of the
+ * previous frame -- and every peer beamforms its own z-slab of the block's grid.  No reduction
+ * collective: voxels are independent.  Called with devices[0] current and its ingest already
+ * enqueued on its stream; returns with devices[0] current again. */
+static bool run_peers(uint32_t block, const void *src, uint64_t rf_size, uint32_t slot)
+{
+	Context &c = g_context;
+	Device  &d0 = c.devices[0];
+	const ParameterBlock &pb = c.blocks[block];
+	const uint32_t n = c.device_count;
+	const uint32_t planes_total = (uint32_t)(pb.parameters.output_points[2] > 1 ? pb.parameters.output_points[2] : 1);
+	const uint32_t first  = pb.shard_z_count ? pb.shard_z_first : 0u;
+	const uint32_t planes = pb.shard_z_count ? pb.shard_z_count : planes_total;
+	for (uint32_t i = 0; i < n; i++) device_slab(i, n, first, planes, c.devices[i].slab_first, c.devices[i].slab_count);
+
+	/* "the mapped RF of this frame is complete on the ingest device" */
+	bool ok = HIP_OK(hipEventRecord(d0.rf_landed[slot], d0.stream));
+	for (uint32_t i = 1; i < n && ok; i++) {
+		Device &p = c.devices[i];
+		if (!select_device(i)) { ok = false; break; }
+		ok &= p.rf[slot].ensure(round_up(rf_size, 64) + 64);
+		ok &= HIP_OK(hipStreamWaitEvent(p.peer_stream, d0.rf_landed[slot], 0));
+		/* the frame that read this slot three pushes ago must be done with it */
+		if (p.consumed_pending[slot]) ok &= HIP_OK(hipStreamWaitEvent(p.peer_stream, p.rf_consumed[slot], 0));
+		if (!ok) break;
+		ok &= HIP_OK(hipMemcpyPeerAsync(p.rf[slot].ptr, p.device, src, d0.device, rf_size, p.peer_stream));
+		ok &= HIP_OK(hipEventRecord(p.rf_landed[slot], p.peer_stream));
+		ok &= HIP_OK(hipStreamWaitEvent(p.stream, p.rf_landed[slot], 0));
+		TimingSlot &t = p.timing[p.frame_counter % kTimingSlots];
+		t.sampled = true; t.events_slot = (uint32_t)(p.frame_counter % kTimingSlots);
+		ok = ok && run_frame(block, p.rf[slot].ptr, (int64_t)p.rf[slot].size, false);
+		p.consumed_pending[slot] = ok && HIP_OK(hipEventRecord(p.rf_consumed[slot], p.stream));
+	}
+	if (!select_device(0)) ok = false;
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+}
+
 /* lib .c:491-570 (client copy) + beamformer_core.c:1756-1805 (upload worker) */
 bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool data_on_device)
 {
 	Context &c = g_context;
+	Device  &d = *c.cur;
 	ParameterBlock &pb = c.blocks[block];
 	const BeamformerParameters &bp = pb.parameters;
-	hipStream_t s = c.stream;
+	hipStream_t s = d.stream;
 
 	const uint64_t bytes   = (uint64_t)bf_kind_byte_size[pb.data_kind];
 	const uint64_t out_row = bytes * bp.sample_count * bp.acquisition_count;
@@ -785,10 +896,24 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	bool a1s2 = bp.contrast_mode == BeamformerContrastMode_A1S2;
 
-	uint32_t slot = (uint32_t)(c.rf_index++ % BeamformerMaxRawDataFramesInFlight);
-	if (!c.rf[slot].ensure(round_up(rf_size, 64) + 64)) return set_error(BeamformerLibErrorKind_RFDataSizeOverflow);
+	uint32_t slot = (uint32_t)(d.rf_index++ % BeamformerMaxRawDataFramesInFlight);
+	if (!d.rf[slot].ensure(round_up(rf_size, 64) + 64)) return set_error(BeamformerLibErrorKind_RFDataSizeOverflow);
+	const bool multi = c.device_count > 1;
+	if (multi) {
+		/* every peer replans before the ingest device does (its commit clears the dirty bits) */
+		for (uint32_t i = 1; i < c.device_count; i++) {
+			if (!select_device(i) || !commit_block(block)) { select_device(0); return set_error(BeamformerLibErrorKind_InvalidComputeStage); }
+		}
+		if (!select_device(0)) return set_error(BeamformerLibErrorKind_SharedMemory);
+		/* this RF slot was the source of the peer copies three pushes ago: they must have landed before
+		 * anything overwrites it (long done by now; waiting on a never-recorded event is a no-op) */
+		for (uint32_t i = 1; i < c.device_count; i++) {
+			(void)hipStreamWaitEvent(s, c.devices[i].rf_landed[slot], 0);
+			(void)hipStreamWaitEvent(d.copy_stream, c.devices[i].rf_landed[slot], 0);
+		}
+	}
 
-	TimingSlot &t = c.timing[c.frame_counter % kTimingSlots];
+	TimingSlot &t = d.timing[d.frame_counter % kTimingSlots];
 	if (!t.created) {
 		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
 		t.created = true;
@@ -798,19 +923,19 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	const bool small = rf_size < kSmallFrameBytes &&
 	                   (uint64_t)bp.output_points[0] * (uint64_t)(bp.output_points[1] > 1 ? bp.output_points[1] : 1) *
 	                   (uint64_t)(bp.output_points[2] > 1 ? bp.output_points[2] : 1) < (4ull << 20);
-	if (!c.have_sample || pb.dirty != 0 || block != c.last_sampled_block) c.replan_frame = c.frame_counter;
+	if (!d.have_sample || pb.dirty != 0 || block != d.last_sampled_block) d.replan_frame = d.frame_counter;
 	/* the first frames of a plan are all sampled: the very first carries one-off launch costs */
-	t.sampled = !small || c.count_pairs || c.frame_counter - c.replan_frame < 3 ||
-	            c.frame_counter - c.last_sampled_frame >= kTimingSamplePeriod;
+	t.sampled = !small || c.count_pairs || d.frame_counter - d.replan_frame < 3 ||
+	            d.frame_counter - d.last_sampled_frame >= kTimingSamplePeriod;
 	if (t.sampled) {
-		c.have_sample = true; c.last_sampled_frame = c.frame_counter; c.last_sampled_block = block;
-		t.events_slot = (uint32_t)(c.frame_counter % kTimingSlots);
+		d.have_sample = true; d.last_sampled_frame = d.frame_counter; d.last_sampled_block = block;
+		t.events_slot = (uint32_t)(d.frame_counter % kTimingSlots);
 		(void)hipEventRecord(t.events[0], s);
 	} else {
-		t.events_slot = (uint32_t)(c.last_sampled_frame % kTimingSlots);
+		t.events_slot = (uint32_t)(d.last_sampled_frame % kTimingSlots);
 	}
 
-	UploadSlot &u = c.upload[slot];
+	UploadSlot &u = d.upload[slot];
 	if (!u.copied && (!HIP_OK(hipEventCreateWithFlags(&u.copied, hipEventDisableTiming)) ||
 	                  !HIP_OK(hipEventCreateWithFlags(&u.consumed, hipEventDisableTiming))))
 		return set_error(BeamformerLibErrorKind_SharedMemory);
@@ -858,18 +983,18 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 			std::memcpy(u.pinned, data, size);
 		}
 		if (overlap) {
-			void *dst = c.rf[slot].ptr;
+			void *dst = d.rf[slot].ptr;
 			if (!direct) {
-				if (!c.raw_staging[slot].ensure(round_up(size, 64) + 64)) return set_error(BeamformerLibErrorKind_BufferOverflow);
-				dst = c.raw_staging[slot].ptr;
+				if (!d.raw_staging[slot].ensure(round_up(size, 64) + 64)) return set_error(BeamformerLibErrorKind_BufferOverflow);
+				dst = d.raw_staging[slot].ptr;
 			}
 			/* the device buffers of this slot were last read by the frame three pushes ago; if that
 			 * frame recorded no `consumed` event (small or device-resident pushes do not), fence
 			 * against everything enqueued so far instead */
 			if (u.unfenced_reader) { u.consume_pending = HIP_OK(hipEventRecord(u.consumed, s)); u.unfenced_reader = false; }
-			if (u.consume_pending) ok &= HIP_OK(hipStreamWaitEvent(c.copy_stream, u.consumed, 0));
-			ok &= HIP_OK(hipMemcpyAsync(dst, u.pinned, direct ? rf_size : (uint64_t)size, hipMemcpyHostToDevice, c.copy_stream));
-			ok &= HIP_OK(hipEventRecord(u.copied, c.copy_stream));
+			if (u.consume_pending) ok &= HIP_OK(hipStreamWaitEvent(d.copy_stream, u.consumed, 0));
+			ok &= HIP_OK(hipMemcpyAsync(dst, u.pinned, direct ? rf_size : (uint64_t)size, hipMemcpyHostToDevice, d.copy_stream));
+			ok &= HIP_OK(hipEventRecord(u.copied, d.copy_stream));
 			u.copy_pending = true;
 			ok &= HIP_OK(hipStreamWaitEvent(s, u.copied, 0));
 			raw = dst;
@@ -892,12 +1017,12 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	if (direct && !zero_copy) {
 		/* the mapped layout is the raw layout: one copy straight into the RF slot */
-		if (data_on_device && !borrowed) ok &= HIP_OK(hipMemcpyAsync(c.rf[slot].ptr, data, rf_size, hipMemcpyDeviceToDevice, s));
+		if (data_on_device && !borrowed) ok &= HIP_OK(hipMemcpyAsync(d.rf[slot].ptr, data, rf_size, hipMemcpyDeviceToDevice, s));
 	} else {
 		PlanState *ps = commit_block(block);
 		if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
 		BfIngestArgs a{};
-		a.raw = raw; a.out = c.rf[slot].ptr;
+		a.raw = raw; a.out = d.rf[slot].ptr;
 		a.channel_mapping = (const int16_t *)ps->mapping.ptr;
 		a.in_row_bytes = in_row; a.out_row_bytes = out_row; a.channels = bp.channel_count;
 		a.a1s2 = a1s2; a.base = bf_kind_base[pb.data_kind];
@@ -917,10 +1042,15 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	c.last_push_time = now;
 
+	if (multi && !run_peers(block, borrowed ? data : d.rf[slot].ptr, rf_size, slot)) return false;
 	bool done = borrowed ? run_frame(block, data, (int64_t)rf_size, true)
-	                     : run_frame(block, c.rf[slot].ptr, (int64_t)c.rf[slot].size, true);
+	                     : run_frame(block, d.rf[slot].ptr, (int64_t)d.rf[slot].size, true);
 	if (overlap) { u.consume_pending = HIP_OK(hipEventRecord(u.consumed, s)); u.unfenced_reader = false; }
 	else         { u.consume_pending = false; u.unfenced_reader = true; }
+	/* a caller's device buffer read in place: the contract lets the caller overwrite it from work enqueued
+	 * later on the library's stream, so that stream also waits for the peer copies out of it */
+	if (multi && borrowed)
+		for (uint32_t i = 1; i < c.device_count; i++) (void)hipStreamWaitEvent(s, c.devices[i].rf_landed[slot], 0);
 	return done;
 }
 
@@ -930,48 +1060,91 @@ bool wait_for_frames(int32_t timeout_ms)
 {
 	Context &c = g_context;
 	if (!c.device_ready) return true;
-	if (timeout_ms < 0) return HIP_OK(hipStreamSynchronize(c.stream)) || set_error(BeamformerLibErrorKind_InvalidAccess);
-	auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
-	for (;;) {
-		hipError_t e = hipStreamQuery(c.stream);
-		if (e == hipSuccess) return true;
-		if (e != hipErrorNotReady) return set_error(BeamformerLibErrorKind_InvalidAccess);
-		if (std::chrono::steady_clock::now() >= deadline) return set_error(BeamformerLibErrorKind_SyncVariable);
-		std::this_thread::sleep_for(std::chrono::microseconds(50));
+	auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+	bool ok = true;
+	for (uint32_t i = 0; i < c.device_count && ok; i++) {
+		Device &d = c.devices[i];
+		if (!HIP_OK(hipSetDevice(d.device))) { ok = set_error(BeamformerLibErrorKind_InvalidAccess); break; }
+		if (timeout_ms < 0) { ok = HIP_OK(hipStreamSynchronize(d.stream)) || set_error(BeamformerLibErrorKind_InvalidAccess); continue; }
+		for (;;) {
+			hipError_t e = hipStreamQuery(d.stream);
+			if (e == hipSuccess) break;
+			if (e != hipErrorNotReady) { ok = set_error(BeamformerLibErrorKind_InvalidAccess); break; }
+			if (std::chrono::steady_clock::now() >= deadline) { ok = set_error(BeamformerLibErrorKind_SyncVariable); break; }
+			std::this_thread::sleep_for(std::chrono::microseconds(50));
+		}
 	}
+	(void)hipSetDevice(c.devices[0].device);
+	c.cur = &c.devices[0];
+	return ok;
 }
 
 /* BeamformerExportKind_BeamformedData (beamformer_core.c:1474-1494) */
 bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms)
 {
 	Context &c = g_context;
+	Device  &d = c.devices[0];
 	if (!wait_for_frames(timeout_ms)) return false;
-	if (c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (d.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	uint64_t req = count < 1 ? 1 : count;
-	if (req > c.frame_counter) req = c.frame_counter;
-	if (req > c.frames.size()) req = c.frames.size();
-	uint64_t index = c.frame_counter - req, exported = 0;
+	if (req > d.frame_counter) req = d.frame_counter;
+	if (req > d.frames.size()) req = d.frames.size();
+	uint64_t index = d.frame_counter - req, exported = 0;
 	bool ok = true;
-	for (uint64_t n = 0; n < req; n++, index++) {
-		const FrameRecord &f = c.frames[index % c.frames.size()];
-		if (f.bytes && exported + f.bytes <= out_size) {
-			ok &= HIP_OK(hipMemcpyAsync((char *)out + exported, (const char *)c.ring.ptr + f.offset, f.bytes,
-			                            hipMemcpyDeviceToHost, c.stream));
-			exported += f.bytes;
+	if (c.device_count == 1) {
+		for (uint64_t n = 0; n < req; n++, index++) {
+			const FrameRecord &f = d.frames[index % d.frames.size()];
+			if (f.bytes && exported + f.bytes <= out_size) {
+				ok &= HIP_OK(hipMemcpyAsync((char *)out + exported, (const char *)d.ring.ptr + f.offset, f.bytes,
+				                            hipMemcpyDeviceToHost, d.stream));
+				exported += f.bytes;
+			}
 		}
+		ok &= HIP_OK(hipStreamSynchronize(d.stream));
+		return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 	}
-	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	/* several devices: every frame id exists on each of them as one z-slab (devices run in lockstep);
+	 * the caller sees whole frames, slabs stitched in z order, each frame rounded to 64 bytes exactly
+	 * as a single device would have exported it */
+	for (uint64_t n = 0; n < req; n++, index++) {
+		uint64_t voxels = 0, elem = 0; bool valid = true;
+		for (uint32_t i = 0; i < c.device_count; i++) {
+			const FrameRecord &f = c.devices[i].frames[index % c.devices[i].frames.size()];
+			if (f.id != (uint32_t)index) { valid = false; break; }
+			uint64_t v = (uint64_t)f.points[0] * f.points[1] * f.points[2];
+			if (v && !f.bytes) { valid = false; break; }              /* storage reused by a newer frame */
+			voxels += v; if (v) elem = (uint64_t)bf_kind_byte_size[f.data_kind];
+		}
+		uint64_t whole = round_up(voxels * elem, 64);
+		if (!valid || !whole || exported + whole > out_size) continue;
+		uint64_t at = exported;
+		for (uint32_t i = 0; i < c.device_count; i++) {
+			Device &p = c.devices[i];
+			const FrameRecord &f = p.frames[index % p.frames.size()];
+			uint64_t bytes = (uint64_t)f.points[0] * f.points[1] * f.points[2] * elem;
+			if (!bytes) continue;
+			ok &= HIP_OK(hipSetDevice(p.device));
+			ok &= HIP_OK(hipMemcpyAsync((char *)out + at, (const char *)p.ring.ptr + f.offset, bytes, hipMemcpyDeviceToHost, p.stream));
+			at += bytes;
+		}
+		if (at < exported + whole) std::memset((char *)out + at, 0, exported + whole - at);   /* the rounding tail */
+		exported += whole;
+	}
+	for (uint32_t i = 0; i < c.device_count; i++) {
+		ok &= HIP_OK(hipSetDevice(c.devices[i].device));
+		ok &= HIP_OK(hipStreamSynchronize(c.devices[i].stream));
+	}
+	(void)hipSetDevice(d.device);
 	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 }
 
-bool last_frame_timings(BeamformerHipFrameTimings *out)
+static bool timings_of(Device &d, BeamformerHipFrameTimings *out)
 {
-	Context &c = g_context;
 	std::memset(out, 0, sizeof(*out));
-	if (!c.device_ready || c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	if (!HIP_OK(hipStreamSynchronize(c.stream))) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	TimingSlot &t = c.timing[(c.frame_counter - 1) % kTimingSlots];
-	TimingSlot &e = c.timing[t.events_slot];       /* t itself, or the newest sampled frame of the same plan */
+	if (d.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (!HIP_OK(hipSetDevice(d.device)) || !HIP_OK(hipStreamSynchronize(d.stream))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	TimingSlot &t = d.timing[(d.frame_counter - 1) % kTimingSlots];
+	TimingSlot &e = d.timing[t.events_slot];       /* t itself, or the newest sampled frame of the same plan */
 	out->stage_count = t.count;
 	for (uint32_t i = 0; i < t.count; i++) {
 		out->stage_kind[i] = t.kinds[i];
@@ -982,86 +1155,174 @@ bool last_frame_timings(BeamformerHipFrameTimings *out)
 	if (t.count && HIP_OK(hipEventElapsedTime(&total, e.events[0], e.events[t.count]))) out->frame_ms = total;
 	out->das_voxels = t.das_voxels; out->das_taps = t.das_taps;
 	out->das_sample_bytes = t.das_sample_bytes; out->das_path = t.das_path;
-	if (t.counted && c.pair_counter.ptr) {
+	if (t.counted && d.pair_counter.ptr) {
 		unsigned long long n = 0;
-		(void)hipMemcpy(&n, (unsigned long long *)c.pair_counter.ptr + ((c.frame_counter - 1) % kTimingSlots),
+		(void)hipMemcpy(&n, (unsigned long long *)d.pair_counter.ptr + ((d.frame_counter - 1) % kTimingSlots),
 		                sizeof(n), hipMemcpyDeviceToHost);
 		out->das_pairs = n;
 	}
 	return true;
 }
 
+/* the newest frame as one device saw it (its slab, its events) */
+bool device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out)
+{
+	Context &c = g_context;
+	std::memset(out, 0, sizeof(*out));
+	if (!c.device_ready || device_index >= c.device_count) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	bool ok = timings_of(c.devices[device_index], out);
+	(void)hipSetDevice(c.devices[0].device);
+	return ok;
+}
+
+/* the newest frame: stage times of the ingest device; with several devices the voxel and pair counts
+ * are those of the whole frame and the frame time is the slowest device's */
+bool last_frame_timings(BeamformerHipFrameTimings *out)
+{
+	Context &c = g_context;
+	std::memset(out, 0, sizeof(*out));
+	if (!c.device_ready) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (!timings_of(c.devices[0], out)) return false;
+	for (uint32_t i = 1; i < c.device_count; i++) {
+		BeamformerHipFrameTimings peer;
+		if (!timings_of(c.devices[i], &peer)) { (void)hipSetDevice(c.devices[0].device); return false; }
+		out->das_voxels += peer.das_voxels; out->das_pairs += peer.das_pairs;
+		if (peer.frame_ms > out->frame_ms) out->frame_ms = peer.frame_ms;
+	}
+	(void)hipSetDevice(c.devices[0].device);
+	return true;
+}
+
 /* BeamformerComputeStatsTable (beamformer_compute_stats.c:3-10) as coalesce_timing_table
- * (beamformer_core.c:1683-1747) fills it: seconds per planned stage for the last 32 frames */
+ * (beamformer_core.c:1683-1747) fills it: seconds per planned stage for the last 32 frames; with
+ * several devices each entry is the slowest device's (they run side by side) */
 bool fill_stats_table(BeamformerComputeStatsTable *out)
 {
 	Context &c = g_context;
 	std::memset(out, 0, sizeof(*out));
-	if (!c.device_ready || c.frame_counter == 0) return true;
-	if (!HIP_OK(hipStreamSynchronize(c.stream))) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	uint64_t frames = c.frame_counter < kTimingSlots ? c.frame_counter : kTimingSlots;
-	for (uint64_t n = 0; n < frames; n++) {
-		uint64_t id = c.frame_counter - frames + n;
-		TimingSlot &t = c.timing[id % kTimingSlots];
-		TimingSlot &e = c.timing[t.events_slot];
-		uint32_t col = 0;
-		for (uint32_t i = 0; i < t.count; i++) {
-			if (t.kinds[i] == kStageIngest || t.kinds[i] == kStagePairCount) continue;
-			if (col >= BeamformerMaxComputeShaderStages) break;
-			float ms = 0;
-			(void)hipEventElapsedTime(&ms, e.events[i], e.events[i + 1]);
-			out->times[id % 32][col] = ms * 1e-3f;
-			if (n == frames - 1) out->shader_ids[col] = t.kinds[i];
-			col++;
+	if (!c.device_ready || c.devices[0].frame_counter == 0) return true;
+	for (uint32_t dev = 0; dev < c.device_count; dev++) {
+		Device &d = c.devices[dev];
+		if (!HIP_OK(hipSetDevice(d.device)) || !HIP_OK(hipStreamSynchronize(d.stream))) {
+			(void)hipSetDevice(c.devices[0].device);
+			return set_error(BeamformerLibErrorKind_InvalidAccess);
 		}
-		if (n == frames - 1) out->shader_count = col;
+		uint64_t frames = d.frame_counter < kTimingSlots ? d.frame_counter : kTimingSlots;
+		for (uint64_t n = 0; n < frames; n++) {
+			uint64_t id = d.frame_counter - frames + n;
+			TimingSlot &t = d.timing[id % kTimingSlots];
+			TimingSlot &e = d.timing[t.events_slot];
+			uint32_t col = 0;
+			for (uint32_t i = 0; i < t.count; i++) {
+				if (t.kinds[i] == kStageIngest || t.kinds[i] == kStagePairCount) continue;
+				if (col >= BeamformerMaxComputeShaderStages) break;
+				float ms = 0;
+				(void)hipEventElapsedTime(&ms, e.events[i], e.events[i + 1]);
+				float &cell = out->times[id % 32][col];
+				if (ms * 1e-3f > cell) cell = ms * 1e-3f;
+				if (dev == 0 && n == frames - 1) out->shader_ids[col] = t.kinds[i];
+				col++;
+			}
+			if (dev == 0 && n == frames - 1) out->shader_count = col;
+		}
 	}
+	(void)hipSetDevice(c.devices[0].device);
 	for (size_t i = 0; i < c.rf_time_deltas.size() && i < 32; i++) out->rf_time_deltas[i] = c.rf_time_deltas[i];
+	return true;
+}
+
+/* byte offset of device `dev`'s slab inside the stitched newest frame, and the frame's total bytes */
+static bool newest_layout(Context &c, uint64_t offsets[kMaxDevices], uint64_t per_voxel, uint64_t &total)
+{
+	total = 0;
+	for (uint32_t i = 0; i < c.device_count; i++) {
+		Device &p = c.devices[i];
+		if (p.frame_counter == 0) return false;
+		const FrameRecord &f = p.frames[(p.frame_counter - 1) % p.frames.size()];
+		offsets[i] = total;
+		total += (uint64_t)f.points[0] * f.points[1] * f.points[2] * per_voxel;
+	}
 	return true;
 }
 
 bool frame_min_max(float out[2])
 {
 	Context &c = g_context;
-	if (!c.device_ready || c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	const FrameRecord &f = c.frames[(c.frame_counter - 1) % c.frames.size()];
-	if (!c.minmax_scratch.ensure(sizeof(float) * (2 * 1024 + 2))) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	float *scratch = (float *)c.minmax_scratch.ptr;
-	uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
-	bool ok = HIP_OK(bf_launch_min_max((const char *)c.ring.ptr + f.offset, voxels,
-	                                   f.data_kind == BeamformerDataKind_Float32Complex, scratch + 2, scratch, c.stream));
-	ok &= HIP_OK(hipMemcpyAsync(out, scratch, 2 * sizeof(float), hipMemcpyDeviceToHost, c.stream));
-	ok &= HIP_OK(hipStreamSynchronize(c.stream));
-	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (!c.device_ready || c.devices[0].frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	bool ok = true, any = false;
+	float lo = 0.f, hi = 0.f;
+	for (uint32_t i = 0; i < c.device_count && ok; i++) {
+		Device &d = c.devices[i];
+		const FrameRecord &f = d.frames[(d.frame_counter - 1) % d.frames.size()];
+		uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
+		if (!voxels) continue;
+		ok &= HIP_OK(hipSetDevice(d.device));
+		if (!ok || !d.minmax_scratch.ensure(sizeof(float) * (2 * 1024 + 2))) { ok = false; break; }
+		float *scratch = (float *)d.minmax_scratch.ptr;
+		float part[2];
+		ok &= HIP_OK(bf_launch_min_max((const char *)d.ring.ptr + f.offset, voxels,
+		                               f.data_kind == BeamformerDataKind_Float32Complex, scratch + 2, scratch, d.stream));
+		ok &= HIP_OK(hipMemcpyAsync(part, scratch, 2 * sizeof(float), hipMemcpyDeviceToHost, d.stream));
+		ok &= HIP_OK(hipStreamSynchronize(d.stream));
+		/* the two-float combine across slabs; NaN voxels propagate as in the one-device reduction */
+		if (!any) { lo = part[0]; hi = part[1]; any = true; }
+		else {
+			lo = (part[0] < lo || part[0] != part[0]) ? part[0] : lo;
+			hi = (part[1] > hi || part[1] != part[1]) ? part[1] : hi;
+		}
+	}
+	(void)hipSetDevice(c.devices[0].device);
+	out[0] = lo; out[1] = hi;
+	return (ok && any) || set_error(BeamformerLibErrorKind_InvalidAccess);
 }
 
 /* Rolling average of the `count` newest frames as the reference's Sum stage specifies it
  * (beamformer_core.c:1417-1448 + shaders/sum.glsl): cleared output, then one
  * out += (1/count) * frame pass per frame, oldest first.  The reference's planner drops
  * Sum from every pipeline (beamformer_core.c:632-637), so this is reachable only through
- * the extension and never changes what get_last_frames returns. */
+ * the extension and never changes what get_last_frames returns.  With several devices each
+ * averages its own slab and the slabs are stitched in the caller's buffer. */
 bool sum_last_frames(uint32_t count, void *out, uint64_t out_size)
 {
 	Context &c = g_context;
-	if (!c.device_ready || c.frame_counter == 0 || count == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	if (count > c.frame_counter || count > c.frames.size()) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	const FrameRecord &newest = c.frames[(c.frame_counter - 1) % c.frames.size()];
-	for (uint64_t id = c.frame_counter - count; id < c.frame_counter; id++) {
-		const FrameRecord &f = c.frames[id % c.frames.size()];
-		if (!f.bytes || f.bytes != newest.bytes || f.data_kind != newest.data_kind ||
-		    f.points[0] != newest.points[0] || f.points[1] != newest.points[1] || f.points[2] != newest.points[2])
-			return set_error(BeamformerLibErrorKind_DataSizeMismatch);
+	if (!c.device_ready || c.devices[0].frame_counter == 0 || count == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	uint64_t offsets[kMaxDevices], total = 0;
+	{
+		const Device &d0 = c.devices[0];
+		const FrameRecord &f0 = d0.frames[(d0.frame_counter - 1) % d0.frames.size()];
+		if (!newest_layout(c, offsets, (uint64_t)bf_kind_byte_size[f0.data_kind], total)) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	}
-	if (out_size < newest.bytes) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
-	if (!c.sum_scratch.ensure(newest.bytes)) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	bool ok = HIP_OK(hipMemsetAsync(c.sum_scratch.ptr, 0, newest.bytes, c.stream));
-	float prescale = 1.0f / (float)count;
-	for (uint64_t id = c.frame_counter - count; ok && id < c.frame_counter; id++) {
-		const FrameRecord &f = c.frames[id % c.frames.size()];
-		ok &= HIP_OK(bf_launch_sum(c.sum_scratch.ptr, (const char *)c.ring.ptr + f.offset, prescale, f.bytes, c.stream));
+	if (out_size < round_up(total, 64)) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
+	bool ok = true;
+	for (uint32_t i = 0; i < c.device_count && ok; i++) {
+		Device &d = c.devices[i];
+		if (count > d.frame_counter || count > d.frames.size()) return set_error(BeamformerLibErrorKind_InvalidAccess);
+		const FrameRecord &newest = d.frames[(d.frame_counter - 1) % d.frames.size()];
+		uint64_t slab_bytes = (uint64_t)newest.points[0] * newest.points[1] * newest.points[2] * (uint64_t)bf_kind_byte_size[newest.data_kind];
+		if (!slab_bytes) continue;
+		for (uint64_t id = d.frame_counter - count; id < d.frame_counter; id++) {
+			const FrameRecord &f = d.frames[id % d.frames.size()];
+			if (!f.bytes || f.bytes != newest.bytes || f.data_kind != newest.data_kind ||
+			    f.points[0] != newest.points[0] || f.points[1] != newest.points[1] || f.points[2] != newest.points[2])
+				return set_error(BeamformerLibErrorKind_DataSizeMismatch);
+		}
+		ok &= HIP_OK(hipSetDevice(d.device));
+		if (!ok || !d.sum_scratch.ensure(newest.bytes)) { ok = false; break; }
+		ok &= HIP_OK(hipMemsetAsync(d.sum_scratch.ptr, 0, newest.bytes, d.stream));
+		float prescale = 1.0f / (float)count;
+		for (uint64_t id = d.frame_counter - count; ok && id < d.frame_counter; id++) {
+			const FrameRecord &f = d.frames[id % d.frames.size()];
+			ok &= HIP_OK(bf_launch_sum(d.sum_scratch.ptr, (const char *)d.ring.ptr + f.offset, prescale, f.bytes, d.stream));
+		}
+		/* one device: the whole 64-byte-rounded frame, as before; several: the slab's own bytes */
+		uint64_t copy = c.device_count == 1 ? newest.bytes : slab_bytes;
+		ok &= HIP_OK(hipMemcpyAsync((char *)out + offsets[i], d.sum_scratch.ptr, copy, hipMemcpyDeviceToHost, d.stream));
 	}
-	ok &= HIP_OK(hipMemcpyAsync(out, c.sum_scratch.ptr, newest.bytes, hipMemcpyDeviceToHost, c.stream));
-	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	for (uint32_t i = 0; i < c.device_count; i++) {
+		ok &= HIP_OK(hipSetDevice(c.devices[i].device));
+		ok &= HIP_OK(hipStreamSynchronize(c.devices[i].stream));
+	}
+	(void)hipSetDevice(c.devices[0].device);
 	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 }
 
@@ -1069,15 +1330,27 @@ bool sum_last_frames(uint32_t count, void *out, uint64_t out_size)
 bool display_last_frame(float threshold_db, float gamma, float db_cutoff, float *out, uint64_t out_floats)
 {
 	Context &c = g_context;
-	if (!c.device_ready || c.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	const FrameRecord &f = c.frames[(c.frame_counter - 1) % c.frames.size()];
-	uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
-	if (out_floats < voxels) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
-	if (!c.sum_scratch.ensure(voxels * sizeof(float))) return set_error(BeamformerLibErrorKind_InvalidAccess);
-	bool ok = HIP_OK(bf_launch_display((const char *)c.ring.ptr + f.offset, voxels, f.data_kind == BeamformerDataKind_Float32Complex,
-	                                   threshold_db, gamma, db_cutoff, (float *)c.sum_scratch.ptr, c.stream));
-	ok &= HIP_OK(hipMemcpyAsync(out, c.sum_scratch.ptr, voxels * sizeof(float), hipMemcpyDeviceToHost, c.stream));
-	ok &= HIP_OK(hipStreamSynchronize(c.stream));
+	if (!c.device_ready || c.devices[0].frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	uint64_t offsets[kMaxDevices], total = 0;
+	if (!newest_layout(c, offsets, 1, total)) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	if (out_floats < total) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
+	bool ok = true;
+	for (uint32_t i = 0; i < c.device_count && ok; i++) {
+		Device &d = c.devices[i];
+		const FrameRecord &f = d.frames[(d.frame_counter - 1) % d.frames.size()];
+		uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
+		if (!voxels) continue;
+		ok &= HIP_OK(hipSetDevice(d.device));
+		if (!ok || !d.sum_scratch.ensure(voxels * sizeof(float))) { ok = false; break; }
+		ok &= HIP_OK(bf_launch_display((const char *)d.ring.ptr + f.offset, voxels, f.data_kind == BeamformerDataKind_Float32Complex,
+		                               threshold_db, gamma, db_cutoff, (float *)d.sum_scratch.ptr, d.stream));
+		ok &= HIP_OK(hipMemcpyAsync(out + offsets[i], d.sum_scratch.ptr, voxels * sizeof(float), hipMemcpyDeviceToHost, d.stream));
+	}
+	for (uint32_t i = 0; i < c.device_count; i++) {
+		ok &= HIP_OK(hipSetDevice(c.devices[i].device));
+		ok &= HIP_OK(hipStreamSynchronize(c.devices[i].stream));
+	}
+	(void)hipSetDevice(c.devices[0].device);
 	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 }
 

@@ -364,18 +364,56 @@ uint32_t beamformer_set_live_parameters(BeamformerLiveImagingParameters *params)
 uint32_t beamformer_hip_set_device(int32_t device_index)
 {
 	Context &c = ctx();
-	if (c.device_ready) return check(c.device == device_index, BeamformerLibErrorKind_InvalidAccess);
-	c.requested_device = device_index;
+	if (c.device_ready) return check(c.device_count == 1 && c.devices[0].device == device_index, BeamformerLibErrorKind_InvalidAccess);
+	c.requested_devices[0] = device_index;
+	c.requested_count = 1;
 	return 1;
 }
 
-int32_t beamformer_hip_get_device(void) { return ctx().device_ready ? ctx().device : ctx().requested_device; }
+int32_t beamformer_hip_get_device(void)
+{
+	Context &c = ctx();
+	return c.device_ready ? c.devices[0].device : (c.requested_count ? c.requested_devices[0] : -1);
+}
+
+uint32_t beamformer_hip_set_devices(const int32_t *device_indices, uint32_t count)
+{
+	Context &c = ctx();
+	if (!check(device_indices != nullptr && count >= 1 && count <= kMaxDevices, BeamformerLibErrorKind_InvalidAccess)) return 0;
+	if (c.device_ready) {
+		/* like beamformer_hip_set_device: afterwards only the set already in use is accepted */
+		bool same = c.device_count == count;
+		for (uint32_t i = 0; same && i < count; i++) same = c.devices[i].device == device_indices[i];
+		return check(same, BeamformerLibErrorKind_InvalidAccess);
+	}
+	for (uint32_t i = 0; i < count; i++) {
+		if (!check(device_indices[i] >= 0, BeamformerLibErrorKind_InvalidAccess)) return 0;
+		c.requested_devices[i] = device_indices[i];
+	}
+	c.requested_count = count;
+	return 1;
+}
+
+uint32_t beamformer_hip_get_device_count(void)
+{
+	Context &c = ctx();
+	return c.device_ready ? c.device_count : (c.requested_count ? c.requested_count : 1u);
+}
+
+uint32_t beamformer_hip_get_device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out)
+{
+	if (!ensure_device()) return 0;
+	return device_frame_timings(device_index, out);
+}
 
 uint32_t beamformer_hip_set_stream(void *hip_stream)
 {
 	Context &c = ctx();
-	if (c.device_ready && c.stream) (void)hipStreamSynchronize(c.stream);   /* keep frames ordered across the switch */
-	c.stream = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
+	/* a stream belongs to one device: with several devices the library keeps to its own streams */
+	if (!check(beamformer_hip_get_device_count() == 1 || hip_stream == nullptr, BeamformerLibErrorKind_InvalidAccess)) return 0;
+	Device &d = c.devices[0];
+	if (c.device_ready && d.stream) (void)hipStreamSynchronize(d.stream);   /* keep frames ordered across the switch */
+	d.stream = hip_stream ? (hipStream_t)hip_stream : d.own_stream;
 	return 1;
 }
 
@@ -406,9 +444,10 @@ uint32_t beamformer_hip_synchronize(void)
 uint32_t beamformer_hip_get_last_frame_info(BeamformerHipFrameInfo *out)
 {
 	Context &c = ctx();
-	if (!check(c.device_ready && c.frame_counter > 0, BeamformerLibErrorKind_InvalidAccess)) return 0;
-	const FrameRecord &f = c.frames[(c.frame_counter - 1) % c.frames.size()];
-	out->device_pointer = (char *)c.ring.ptr + f.offset;
+	const Device &d = c.devices[0];      /* with several devices: the ingest device's slab */
+	if (!check(c.device_ready && d.frame_counter > 0, BeamformerLibErrorKind_InvalidAccess)) return 0;
+	const FrameRecord &f = d.frames[(d.frame_counter - 1) % d.frames.size()];
+	out->device_pointer = (char *)d.ring.ptr + f.offset;
 	out->size_bytes = f.bytes;
 	out->points[0] = f.points[0]; out->points[1] = f.points[1]; out->points[2] = f.points[2];
 	out->data_kind = (uint32_t)f.data_kind;

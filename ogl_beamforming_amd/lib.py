@@ -95,6 +95,9 @@ def _load():
         # MI355X extensions (include/ogl_beamformer_hip.h)
         "beamformer_hip_set_device": (u32, [i32]),
         "beamformer_hip_get_device": (i32, []),
+        "beamformer_hip_set_devices": (u32, [C.POINTER(i32), u32]),
+        "beamformer_hip_get_device_count": (u32, []),
+        "beamformer_hip_get_device_frame_timings": (u32, [u32, C.POINTER(P.HipFrameTimings)]),
         "beamformer_hip_set_stream": (u32, [vp]),
         "beamformer_hip_set_output_shard": (u32, [u32, u32, u32]),
         "beamformer_hip_push_device_data_with_compute": (u32, [vp, u32, u32, u32]),
@@ -188,7 +191,9 @@ def get_last_frame(bp, shard_planes=None):
     _check(lib.beamformer_hip_get_last_frame_info(C.byref(info)))
     complex_out = info.data_kind == int(P.DataKind.Float32Complex)
     voxels = int(np.prod(shape))
-    raw = np.empty((int(info.size_bytes) + 3) // 4, dtype=np.float32)
+    # with several devices the info describes the ingest device's slab; the export is the whole frame
+    whole = (voxels * (8 if complex_out else 4) + 63) // 64 * 64
+    raw = np.empty((max(int(info.size_bytes), whole) + 3) // 4, dtype=np.float32)
     _check(lib.beamformer_get_last_frames(raw.ctypes.data_as(C.c_void_p), raw.nbytes, 1))
     if complex_out:
         return raw[: 2 * voxels].view(np.complex64).reshape(shape)

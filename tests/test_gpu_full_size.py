@@ -105,12 +105,12 @@ def test_full_size_linearity(bflib, config4):
     assert np.abs(bz - want).max() / np.abs(want).max() < 2e-4
 
 
-@pytest.mark.parametrize("n, path_name", [(2, "factored"), (3, "general"), (5, "general")])
+@pytest.mark.parametrize("n, path_name", [(2, "factored"), (3, "hercules"), (5, "hercules")])
 def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     """Configs 2, 3 and 5 at BASELINE sizes (config 5 on a 16-plane slab: 4.3 s per whole frame):
-    the scatterer (where the acquisition has one) peaks where it was placed, the automatic DAS path is the expected one, the
-    factored kernel agrees with the general kernel on the same frame (config 2), and the oracle
-    agrees on a few full-size rows around the scatterer."""
+    the scatterer (where the acquisition has one) peaks where it was placed, the automatic DAS path is the expected one
+    (factored kernel for config 2, HERCULES aligned-grid kernel for configs 3 and 5), it agrees with the general kernel on the
+    same frame, and the oracle agrees on a few full-size rows around the scatterer."""
     acq = cfg.config(n)
     X, Y, Z = (max(1, v) for v in acq.bp.output_points[:3])
     m = np.array(acq.bp.das_voxel_transform[:], np.float64).reshape(4, 4).T
@@ -126,7 +126,7 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     frame = run(bflib, acq, shard=shard)
     t = P.HipFrameTimings()
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
-    assert int(t.das_path) == {"general": 0, "factored": 3}[path_name]
+    assert int(t.das_path) == {"general": 0, "factored": 3, "hercules": 5}[path_name]
     z0 = shard[0] if shard else 0
     if want is not None:
         mag = np.abs(np.nan_to_num(frame))
@@ -141,9 +141,12 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     from tests import cases
     assert np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max() <= cases.tolerance(acq)
 
-    if n == 2:
-        general = run(bflib, acq, path=1)
-        assert np.abs(general - frame).max() / np.abs(frame).max() < 1e-4
+    # the specialised kernel against the general kernel over the whole frame (config 5: the slab)
+    general = run(bflib, acq, path=1, shard=shard)
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 0
+    assert np.array_equal(np.isnan(general), np.isnan(frame))
+    both = ~np.isnan(frame)
+    assert np.abs(general[both] - frame[both]).max() / np.abs(frame[both]).max() < 1e-4
 
 
 @pytest.mark.parametrize("interp, cw, points", [(P.InterpolationMode.Linear, True, (300, 201, 37)),

@@ -1,0 +1,143 @@
+"""Several devices behind the unchanged push-RF / pull-image calls (beamformer_hip_set_devices,
+SURVEY section 8e; the reference's export semantics lib/ogl_beamformer_lib.c:656-702).  A one-GPU box
+lists the same ordinal several times: each entry is a separate device context of the library (own
+streams, RF ring, plan tables, frame ring) fed by hipMemcpyPeerAsync, so the orchestration is the real
+one; only the link the copies travel over differs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ogl_beamforming_amd import params as P
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def use_devices(lib, ordinals):
+    lib.beamformer_hip_shutdown()
+    arr = (C.c_int32 * len(ordinals))(*ordinals)
+    assert lib.beamformer_hip_set_devices(arr, len(ordinals))
+    assert lib.beamformer_hip_get_device_count() == len(ordinals)
+
+
+@pytest.fixture()
+def devices(bflib):
+    lib = bflib.library()
+    yield lambda ordinals: use_devices(lib, ordinals)
+    use_devices(lib, [0])                      # leave the process-wide library as the other tests expect it
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name, count", [("config4_small", 2), ("config4_small", 3), ("config5_small", 4),
+                                         ("rca_vls_cw", 5), ("config2_small", 3), ("hercules_wide_cw", 2),
+                                         ("forces", 2)])
+def test_slabs_stitch_to_the_one_device_frame(name, count, bflib, devices):
+    """N device contexts, plain beamformer_beamform_data-style calls: the pulled frame is bit-identical
+    to the one-device frame (also when planes do not divide evenly, and for 2-D images, where all but
+    the first device hold an empty slab)."""
+    acq = cases.make(name)
+    devices([0])
+    one = bflib.beamform(acq.bp, acq.rf, acq.filters).copy()
+    lib = bflib.library()
+    mm_one = (C.c_float * 2)()
+    assert lib.beamformer_hip_frame_min_max(mm_one)
+    devices([0] * count)
+    many = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    assert same_bits(one, many)
+    # per-device slabs: contiguous, sizes differing by at most one, larger ones first
+    Z = one.shape[0]
+    planes = []
+    for i in range(count):
+        t = P.HipFrameTimings()
+        assert lib.beamformer_hip_get_device_frame_timings(i, C.byref(t))
+        planes.append(int(t.das_voxels) // (one.shape[1] * one.shape[2]))
+    assert sum(planes) == Z and max(planes) - min(planes) <= 1 and planes == sorted(planes, reverse=True)
+    mm = (C.c_float * 2)()
+    assert lib.beamformer_hip_frame_min_max(mm)
+    assert np.array_equal(np.array(mm[:]), np.array(mm_one[:]), equal_nan=True)
+
+
+def test_pipelined_pushes_export_sum_and_display(bflib, devices):
+    """Five frames pushed back to back through three RF slots on three device contexts, then the last
+    two exported oldest-first, averaged and display-reduced: all equal to the one-device results."""
+    acq = cases.make("config4_small")
+    rng = np.random.default_rng(3)
+    frames_rf = [np.ascontiguousarray(acq.rf if k == 0 else rng.integers(-2000, 2000, acq.rf.shape).astype(acq.rf.dtype))
+                 for k in range(5)]
+    lib = bflib.library()
+    Zs, Ys, Xs = bflib.frame_shape(acq.bp)
+    frame_bytes = (Zs * Ys * Xs * 8 + 63) // 64 * 64
+
+    def run():
+        for slot, fp in enumerate(acq.filters):
+            assert lib.beamformer_create_filter(C.byref(fp), slot, 0)
+        assert lib.beamformer_push_simple_parameters(C.byref(acq.bp))
+        for rf in frames_rf:
+            assert lib.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0), bflib.last_error()
+        out = np.zeros(2 * frame_bytes // 4, np.float32)
+        assert lib.beamformer_get_last_frames(out.ctypes.data_as(C.c_void_p), out.nbytes, 2)
+        avg = np.zeros(frame_bytes // 4, np.float32)
+        assert lib.beamformer_hip_sum_last_frames(2, avg.ctypes.data_as(C.c_void_p), avg.nbytes), bflib.last_error()
+        shown = np.zeros(Zs * Ys * Xs, np.float32)
+        assert lib.beamformer_hip_display_last_frame(55.0, 1.0, 50.0, shown.ctypes.data_as(C.POINTER(C.c_float)), shown.size)
+        return out, avg[: Zs * Ys * Xs * 2], shown
+
+    devices([0])
+    want = run()
+    devices([0, 0, 0])
+    got = run()
+    for a, b in zip(want, got):
+        assert same_bits(a, b)
+    # the two exported frames differ (different RF) and the newest equals a fresh single push of frames_rf[-1]
+    assert not same_bits(got[0][: frame_bytes // 4], got[0][frame_bytes // 4:])
+
+
+def test_device_resident_rf_sharded_block_and_pair_count(bflib, devices, oracle):
+    """RF that is already on the ingest device (read in place there, copied to the peers), a block with an
+    output shard (the devices split the shard, not the grid), and the geometry-only pair count summed
+    over devices."""
+    import torch
+    acq = cases.make("config4_small")
+    lib = bflib.library()
+    Zs, Ys, Xs = bflib.frame_shape(acq.bp)
+    z0, zc = 5, Zs - 9
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters, z=(z0, zc))
+    devices([0, 0])
+    for slot, fp in enumerate(acq.filters):
+        assert lib.beamformer_create_filter(C.byref(fp), slot, 0)
+    assert lib.beamformer_push_simple_parameters(C.byref(acq.bp))
+    assert lib.beamformer_hip_set_output_shard(0, z0, zc)
+    try:
+        rf = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1)).to("cuda:0")
+        torch.cuda.synchronize()
+        lib.beamformer_hip_enable_pair_counting(1)
+        assert lib.beamformer_hip_push_device_data_with_compute(C.c_void_p(rf.data_ptr()), rf.numel(), 0, 0), bflib.last_error()
+        got = bflib.get_last_frame(acq.bp, shard_planes=zc)
+        t = P.HipFrameTimings()
+        assert lib.beamformer_hip_get_last_frame_timings(C.byref(t))
+    finally:
+        lib.beamformer_hip_enable_pair_counting(0)
+        lib.beamformer_hip_set_output_shard(0, 0, 0)
+    assert int(t.das_voxels) == zc * Ys * Xs
+    assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max() <= cases.tolerance(acq)
+
+
+def test_device_set_rules(bflib, devices):
+    lib = bflib.library()
+    devices([0, 0])
+    acq = cases.make("config1_small")
+    bflib.beamform(acq.bp, acq.rf, acq.filters)
+    two = (C.c_int32 * 2)(0, 0)
+    three = (C.c_int32 * 3)(0, 0, 0)
+    assert lib.beamformer_hip_set_devices(two, 2)                       # the set in use
+    assert not lib.beamformer_hip_set_devices(three, 3)                 # a different one: only after shutdown
+    assert not lib.beamformer_hip_set_device(0)
+    assert not lib.beamformer_hip_set_stream(C.c_void_p(1))             # a stream belongs to one device
+    assert not lib.beamformer_hip_set_devices(two, 0) and not lib.beamformer_hip_set_devices(two, 9)
