@@ -9,13 +9,21 @@ With N > 1 (one process per GPU, launched by torch.distributed.run) the volume i
 broadcasts it over RCCL/xGMI (the one collective of the path), every rank beamforms its
 slab.  No reduction collective.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the DAS kernel against the HBM roofline
-with the ALGORITHMIC gather bytes of BASELINE.md section 4; `cpu_baseline` times the CPU
-oracle (a port of the reference shaders, the reference itself cannot be built here) on a
-bounded sub-grid of the same frame on the host cores.
+`--in-process` runs the same N-way slab split inside ONE process through the library's own
+multi-device mode (beamformer_hip_set_devices: RF copied to the peers with hipMemcpyPeerAsync,
+no torch.distributed) -- what a C / MATLAB client of the push-RF / pull-image API gets.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the DAS kernel against the HBM roofline with
+the ALGORITHMIC gather bytes of BASELINE.md section 4 (the contract's `frac`: it exceeds 1
+because those bytes are L1/L2 hits, not HBM reads), next to `binding` -- the resource that
+actually limits the kernel, priced against the ceiling tools/microbench.hip measured
+(profiles/r02_microbench.json) -- and the measured HBM traffic (`traffic`, `hbm_measured_GBps`).
+`cpu_baseline` times the CPU oracle (a port of the reference shaders; the reference itself
+cannot be built here) on evenly spaced planes of the same frame on the host cores.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -29,6 +37,13 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
+PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
+              "factored kernel with LDS row cache", "HERCULES aligned-grid kernel"]
+KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel",
+                "das_hercules_kernel"]
+# the sources whose hash ties a committed PMC figure to the code that produced it (tools/pmc_das.py)
+KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_hercules.hip", "bf_kernels.h"]
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -38,13 +53,17 @@ def parse():
     ap.add_argument("--config", type=int, default=4, help="BASELINE.json configs index (1-based)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies, 5 LDS row-cache experiment")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU-baseline budget (DAS time summed over its three legs)")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies, 5 LDS row-cache experiment, 6 HERCULES aligned-grid kernel also on narrow grids")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="multi-GPU: broadcast and compute back to back on one stream instead of pipelined")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run the N-rank code path with every rank on GPU 0 and gloo for the "
                          "collectives (RCCL refuses two ranks per device); the value is NOT the metric")
+    ap.add_argument("--in-process", action="store_true",
+                    help="N devices inside this one process (beamformer_hip_set_devices) instead of one process per GPU")
+    ap.add_argument("--devices", type=str, default="",
+                    help="--in-process: comma separated HIP ordinals (default 0..N-1; an ordinal may repeat, e.g. 0,0 on a one-GPU box: then NOT the metric)")
     ap.add_argument("--planes", type=int, default=0, help="profiling aid: beamform only this many centre z-planes (value is then NOT the metric)")
     return ap.parse_args()
 
@@ -56,6 +75,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     rehearse = args.rehearse_on_one_gpu
+    in_process = args.in_process and not distributed
+    ordinals = [0]
+    if in_process:
+        ordinals = [int(v) for v in args.devices.split(",") if v != ""] or list(range(max(1, args.gpus)))
     if distributed:
         import torch.distributed as dist
         if rehearse:
@@ -67,12 +90,17 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     else:
         dist = None
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if distributed else 0)
+        torch.cuda.set_device(ordinals[0])
+    device = torch.device("cuda", local_rank if distributed else ordinals[0])
+    n_gpus = len(ordinals) if in_process else world
 
     from ogl_beamforming_amd import configs, lib, params as P, sharding
     L = lib.library()
-    assert L.beamformer_hip_set_device(device.index), lib.last_error()
+    if in_process:
+        arr = (C.c_int32 * len(ordinals))(*ordinals)
+        assert L.beamformer_hip_set_devices(arr, len(ordinals)), lib.last_error()
+    else:
+        assert L.beamformer_hip_set_device(device.index), lib.last_error()
     L.beamformer_hip_set_das_path(args.das_path)
 
     # every rank builds the parameter block (cheap, deterministic); only rank 0 owns the RF
@@ -90,24 +118,28 @@ def main():
         voxels_total = X * Y * z_count
     if distributed or args.planes:
         assert L.beamformer_hip_set_output_shard(0, z_first, z_count), lib.last_error()
+    planes_rank0 = sharding.slab(0, n_gpus, z_count)[1] if in_process else z_count   # planes of the launch `roofline` prices
 
     rf_host = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1))
     rf_dev = torch.empty(rf_host.numel(), dtype=torch.uint8, device=device)
     if rank == 0:
         rf_dev.copy_(rf_host)
     torch.cuda.synchronize(device)
-    # One explicit stream carries the RCCL broadcast and every kernel of the library, so a frame's
-    # DAS is ordered behind its broadcast without host synchronisation.  (torch's default stream
-    # has handle 0, which the library reads as "use your own stream": never pass that.)
-    stream = torch.cuda.Stream(device=device)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    assert L.beamformer_hip_set_stream(C.c_void_p(stream.cuda_stream)), lib.last_error()
+    stream = None
+    if not in_process:
+        # One explicit stream carries the RCCL broadcast and every kernel of the library, so a frame's
+        # DAS is ordered behind its broadcast without host synchronisation.  (torch's default stream
+        # has handle 0, which the library reads as "use your own stream": never pass that.)
+        stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(stream)
+        assert stream.cuda_stream != 0
+        assert L.beamformer_hip_set_stream(C.c_void_p(stream.cuda_stream)), lib.last_error()
 
     # Multi-GPU schedule: the broadcast of frame n+1 runs on its own stream into the
     # other of two RF buffers while the kernels of frame n run; events order "broadcast landed ->
     # compute" and "frame that read this buffer finished -> next broadcast into it".  A step is
     # one broadcast issued plus one frame computed; the pipeline is primed before the timed region.
+    # (--in-process: the library does the equivalent itself, three RF slots deep.)
     pipelined = distributed and not args.serial_broadcast
     rf_bounce = torch.empty(rf_host.numel(), dtype=torch.uint8) if (distributed and rehearse) else None
     if pipelined:
@@ -163,6 +195,8 @@ def main():
         issue_broadcast()                          # prime: frame 0's RF
 
     def fence():
+        if in_process:
+            assert L.beamformer_hip_synchronize(), lib.last_error()     # every device of the library
         torch.cuda.synchronize(device)
         if distributed:
             dist.barrier()
@@ -174,6 +208,9 @@ def main():
     fence()
     t = P.HipFrameTimings()
     assert L.beamformer_hip_get_last_frame_timings(C.byref(t)), lib.last_error()
+    pairs_all_devices = int(t.das_pairs)           # in-process: summed over the library's devices
+    if in_process:
+        assert L.beamformer_hip_get_device_frame_timings(0, C.byref(t)), lib.last_error()
     pairs_local = int(t.das_pairs)
     taps, sample_bytes, das_path = int(t.das_taps), int(t.das_sample_bytes), int(t.das_path)
     L.beamformer_hip_enable_pair_counting(0)
@@ -187,10 +224,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # Multi-GPU runs check what the schedule delivered: the slab of the last timed frame must be
-    # bit-identical to a recomputation from the same RF buffer after a full fence (a broadcast
-    # that had not landed, or a buffer overwritten early, would show here).  Outside the timed region.
-    verified = None
+    # Multi-GPU runs check what the schedule delivered, outside the timed region:
+    #  (1) the slab of the last timed frame must be bit-identical to a recomputation from the same RF
+    #      buffer after a full fence (a broadcast that had not landed, or a buffer overwritten early);
+    #  (2) every rank's RF buffer must hold rank 0's bytes (a rank that consistently beamforms stale,
+    #      zero or partially landed RF passes (1)): a 64-bit checksum is all-reduced (MIN == MAX).
+    verified, rf_checksum_ok = None, None
     if distributed:
         last_buf = bufs[(state["computed"] - 1) % 2] if pipelined else rf_dev
         first = lib.get_last_frame(bp, shard_planes=z_count).copy()
@@ -199,9 +238,19 @@ def main():
         again = lib.get_last_frame(bp, shard_planes=z_count)
         verified = bool(np.array_equal(first.view(np.uint32), again.view(np.uint32)))
         assert verified, f"rank {rank}: the pipelined frame differs from its recomputation"
+        words = last_buf[: last_buf.numel() // 8 * 8].view(torch.int64)
+        weights = torch.arange(1, words.numel() + 1, device=words.device, dtype=torch.int64)
+        check = (words * weights).sum().reshape(1)               # wraps mod 2^64: position sensitive
+        check = check.cpu() if rehearse else check
+        lo, hi = check.clone(), check.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rf_checksum_ok = bool(int(lo) == int(hi))
+        assert rf_checksum_ok, f"rank {rank}: RF buffer differs from rank 0's after the broadcast"
 
     # DAS kernel duration: HIP event pairs recorded by the library on the stream it launches
-    # on (beamformer_compute_timings = the reference's per-stage stats table)
+    # on (beamformer_compute_timings = the reference's per-stage stats table; in-process: the
+    # slowest device per stage)
     stats = P.ComputeStatsTable()
     assert L.beamformer_compute_timings(C.byref(stats), -1), lib.last_error()
     n_stage = int(stats.shader_count)
@@ -213,6 +262,15 @@ def main():
     rows = [(last_id - k) % 32 for k in range(args.steps)]
     das_s = float(np.mean([stats.times[r][das_col] for r in rows]))
     stage_ms = {P.ShaderKind(ids[i]).name: float(np.mean([stats.times[r][i] for r in rows])) * 1e3 for i in range(n_stage)}
+    device_das_ms = None
+    if in_process and n_gpus > 1:
+        device_das_ms = []
+        for i in range(n_gpus):
+            ti = P.HipFrameTimings()
+            assert L.beamformer_hip_get_device_frame_timings(i, C.byref(ti)), lib.last_error()
+            kinds = [int(ti.stage_kind[k]) for k in range(int(ti.stage_count))]
+            device_das_ms.append(float(ti.stage_ms[kinds.index(int(P.ShaderKind.DAS))]))
+        das_s = device_das_ms[0] * 1e-3              # the launch `roofline` prices is device 0's
 
     if distributed:
         agg = torch.tensor([elapsed, das_s, float(pairs_local)], dtype=torch.float64, device="cpu" if rehearse else device)
@@ -220,9 +278,9 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = agg.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, das_s_max, pairs_total = float(mx[0]), float(mx[1]), int(sm[2].item())
+        elapsed, pairs_total = float(mx[0]), int(sm[2].item())
     else:
-        das_s_max, pairs_total = das_s, pairs_local
+        pairs_total = pairs_all_devices
 
     # a measured copy figure next to the 8 TB/s nominal peak (1 GiB device-to-device
     # copies: bytes read + bytes written over the event-timed duration)
@@ -232,10 +290,10 @@ def main():
         b_buf = torch.empty_like(a_buf)
         b_buf.copy_(a_buf)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
+        e0.record()
         for _ in range(10):
             b_buf.copy_(a_buf)
-        e1.record(stream)
+        e1.record()
         e1.synchronize()
         hbm_copy = 10 * 2 * a_buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a_buf, b_buf
@@ -245,12 +303,23 @@ def main():
         value = voxels_total / (elapsed / args.steps)
         voxel_bytes = 8 if int(info.data_kind) == int(P.DataKind.Float32Complex) else 4
         cw = 4 if bp.coherency_weighting else 0
-        # per launch = this rank's slab; ranks are symmetric, report rank 0's launch
-        bytes_alg = pairs_local * taps * sample_bytes + (X * Y * z_count) * (voxel_bytes + cw)
+        # per launch = rank 0's / device 0's slab; the others are symmetric
+        gather_bytes = pairs_local * taps * sample_bytes
+        bytes_alg = gather_bytes + (X * Y * planes_rank0) * (voxel_bytes + cw)
         achieved = bytes_alg / das_s / 1e9
+        whole_metric_frame = args.scale == 1.0 and not args.planes and n_gpus == 1
+        traffic, traffic_source = measured_traffic(args.config, KERNEL_NAMES[das_path]) if whole_metric_frame else (None, "not the profiled launch (scale, planes or device count differ)")
+        if distributed:
+            how = (f"{world} z-slab(s), one process per GPU, RF broadcast via " + ("gloo through the host (one-GPU rehearsal)" if rehearse else "RCCL")
+                   + (", broadcast of frame n+1 overlaps frame n" if pipelined else ", serial"))
+        elif in_process and n_gpus > 1:
+            how = (f"{n_gpus} z-slab(s) inside one process (beamformer_hip_set_devices, ordinals {ordinals}): RF copied to the peers with "
+                   "hipMemcpyPeerAsync on per-destination streams, three RF slots deep")
+        else:
+            how = "none"
         out = {
             "metric": "beamformed voxels/s (and %HBM-roofline), 256-ch 3D DAS 512^3, 1/2/4/8 GPUs",
-            "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "voxels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
@@ -259,30 +328,31 @@ def main():
                             f" -> {' -> '.join(P.ShaderKind(v).name for v in bp.compute_stages[:bp.compute_stages_count])}"
                             f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "
                             f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
-                **({"notes": acq.notes} if acq.notes else {}),
+                "notes": ((acq.notes + "; ") if acq.notes else "") +
+                         "every stage is launched directly on a HIP stream, not replayed from a captured hipGraph: a frame is <= 5 launches and "
+                         "replay measured slower than direct launches (profiles/r02_graph_probe.json, DESIGN.md section 8)",
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
-                "f_number": bp.f_number, "sharding": (f"{world} z-slab(s), RF broadcast via " + ("gloo through the host (one-GPU rehearsal)" if rehearse else "RCCL")
-                             + (", broadcast of frame n+1 overlaps frame n" if pipelined else ", serial")) if distributed else "none",
-                "das_path": PATH_NAMES[das_path], "slab_verified": verified,
-                "stage_ms": stage_ms,
+                "f_number": bp.f_number, "sharding": how,
+                "das_path": PATH_NAMES[das_path], "slab_verified": verified, "rf_checksum_equal_on_all_ranks": rf_checksum_ok,
+                "stage_ms": stage_ms, **({"device_das_ms": device_das_ms} if device_das_ms else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK,
+                "frac_note": "contract formula: ALGORITHMIC gather bytes / kernel time / 8 TB/s.  It exceeds 1 because the taps are served by L1/L2, "
+                             "not HBM: HBM is not the binding resource (hbm_measured_GBps), `binding` is",
+                "traffic": traffic, "traffic_source": traffic_source,
+                "hbm_measured_GBps": (traffic / das_s / 1e9) if traffic else None,
                 "hbm_copy_measured": hbm_copy,        # GB/s (read + write) of a 1 GiB device-to-device copy on this box
-                "frac": achieved * 1e9 / HBM_PEAK, "traffic": measured_traffic(args, world, das_path),
                 "kernel": KERNEL_NAMES[das_path], "kernel_ms": das_s * 1e3,
                 "algorithmic_bytes_per_launch": bytes_alg,
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
                          "compulsory HBM traffic is ~1e4x smaller (BASELINE.md section 4)",
-                # what actually binds the kernel: every tap is a per-lane L1 gather and the
-                # texture-address path retires 64 B per clock per CU
-                "l1_gather": {"achieved": pairs_local * taps * sample_bytes / das_s / 1e9, "unit": "GB/s",
-                              "peak": 64 * 256 * 2.4e9 / 1e9, "peak_model": "64 B/clk/CU x 256 CUs x 2.4 GHz",
-                              "frac": pairs_local * taps * sample_bytes / das_s / (64 * 256 * 2.4e9)},
+                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s),
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(acq, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
@@ -291,58 +361,115 @@ def main():
         dist.destroy_process_group()
 
 
-PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
-              "factored kernel with LDS row cache", "HERCULES aligned-grid kernel"]
-KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel", "das_hercules_kernel"]
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        p = os.path.join(ROOT, "ogl_beamforming_amd", "csrc", name)
+        if os.path.exists(p):
+            h.update(name.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
-def measured_traffic(args, world, das_path):
-    """HBM bytes per DAS launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/das_traffic.json); None when this run's configuration was not profiled."""
-    if world != 1 or args.scale != 1.0 or args.planes or args.config != 4:
-        return None
+def measured_traffic(config, kernel):
+    """HBM-side bytes per DAS launch of the whole metric frame from the committed rocprofv3 PMC passes
+    (profiles/das_traffic.json, written by tools/summarize_profiles.py from tools/pmc_das.py runs):
+    (bytes, source) -- bytes is None when the committed figure was taken from other kernel sources."""
+    path = os.path.join(ROOT, "profiles", "das_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "das_traffic.json")) as f:
-            table = json.load(f)["config4_scale1_n1"]
-        return table[KERNEL_NAMES[das_path]]["hbm_bytes_per_launch"]
+        with open(path) as f:
+            table = json.load(f)
+        entry = table[f"config{config}"][kernel]
     except (OSError, KeyError, ValueError):
-        return None
+        return None, "no committed PMC pass for this configuration and kernel"
+    if entry.get("kernel_source_sha16") != kernel_source_hash():
+        return None, f"profiles/das_traffic.json is stale: taken at kernel sources {entry.get('kernel_source_sha16')}, now {kernel_source_hash()}"
+    return entry["hbm_bytes_per_launch"], (f"profiles/das_traffic.json ({entry.get('round', '?')}): rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of "
+                                          f"`{entry.get('command', 'bench.py')}`, kernel sources {entry.get('kernel_source_sha16')}")
+
+
+def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s):
+    """The physical resource that limits the DAS launch, priced against measured ceilings:
+      * the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up to
+        16 bytes per lane takes 16 clocks per CU whatever its width (tools/microbench.hip, pattern
+        "das_like", window resident in L1) -- achieved is measured live in this run;
+      * VALU issue: busy fraction of the SIMDs from the committed PMC pass of this kernel (not live)."""
+    out = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_microbench.json")) as f:
+            micro = json.load(f)
+        inst = "global_load_dwordx4" if bytes_per_gather >= 16 else "global_load_dwordx2" if bytes_per_gather == 8 else "global_load_dword"
+        rows = [g for g in micro["gather"] if g["inst"] == inst and g["level"] == "L1" and g["pattern"] == "das_like"]
+        best = max(rows, key=lambda g: g["bytes_per_clk_per_cu_wall"])
+        cus = int(micro["compute_units"])
+        # a gather of 2 x 16 bytes per lane (cubic IQ) is two such instructions: same bytes per clock
+        peak = best["bytes_per_clk_per_cu_wall"] * cus * best["clock_ghz"] * 1e9
+        out = {
+            "resource": f"per-CU vector-memory (texture-address) path: {inst} per-lane gathers, {64 * min(bytes_per_gather, 16) / best['bytes_per_clk_per_cu_wall']:.1f} clk per wave64 instruction",
+            "achieved": gather_bytes / das_s / 1e9, "unit": "GB/s",
+            "peak": peak / 1e9,
+            "peak_model": f"{best['bytes_per_clk_per_cu_wall']:.1f} B/clk/CU (measured, L1-resident window, DAS-like addresses, {best['waves_per_simd']} waves/SIMD) x {cus} CUs x {best['clock_ghz']:.3f} GHz (clock sustained in that probe)",
+            "frac": gather_bytes / das_s / peak,
+            "source": "profiles/r02_microbench.json (tools/microbench.hip); achieved measured in this run",
+        }
+    except (OSError, KeyError, ValueError):
+        out = {"resource": "unpriced: profiles/r02_microbench.json missing"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_das_bound.json")) as f:
+            bound = json.load(f)
+        entry = bound[f"config{config}"][kernel]
+        out["valu_busy_frac"] = entry["valu_busy_frac"]
+        out["ta_busy_frac"] = entry.get("ta_busy_frac")
+        out["valu_source"] = (f"profiles/r02_das_bound.json: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
+                              f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash() else " (STALE: sources changed since)"))
+        if entry["valu_busy_frac"] > out.get("frac", 0):
+            out["resource_note"] = "VALU issue is the tighter bound for this kernel (valu_busy_frac)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 def cpu_baseline(acq, budget_s):
-    """The CPU oracle (port of the reference shaders) on a bounded sub-grid of the same
-    frame: all x, a few rows of the centre z-plane; voxels are independent, so voxels/s
-    extrapolates linearly."""
+    """The CPU oracle (port of the reference shaders) on a bounded sample of the same frame: all x,
+    a few rows, on EVENLY SPACED z-planes (the f-number culling -- and with it the work per voxel --
+    varies with depth); voxels are independent, so voxels/s extrapolates linearly.  Three legs as
+    BASELINE.md section 3 asks: every core the process may use, the 16-core share a one-GPU box owns,
+    one thread."""
     from oracle import binding as oracle
     bp = acq.bp
     X, Y, Z = (max(1, v) for v in bp.output_points[:3])
-    cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
-    # a one-GPU box owns a 16-core share of the host (gpurun's guidance for worker pools)
-    cores = min(cores, int(os.environ.get("BENCH_CPU_THREADS", "16")))
+        affinity = os.cpu_count() or 1
     per_voxel_pairs = bp.channel_count * bp.acquisition_count
 
     def sample(threads, seconds):
-        # ~1.2e7 pairs/s/core for the scalar port; size the sample for the budget
-        target_voxels = max(X, int(seconds * 1.2e7 * threads / per_voxel_pairs))
-        rows = max(1, min(Y, target_voxels // X))
+        # ~1.2e7 pairs/s/core for the scalar port (less per core when hyperthreads share cores); size the sample for the budget
+        target_voxels = max(X, int(seconds * 1.0e7 * min(threads, 64) / per_voxel_pairs))
+        planes = max(1, min(Z, 8, target_voxels // X))
+        rows = max(1, min(Y, target_voxels // (X * planes)))
+        z_stride = max(1, Z // planes)
+        y_stride = max(1, Y // rows)
         timing = {}
         t0 = time.perf_counter()
-        _, pairs = oracle.beamform(bp, acq.rf, acq.filters, threads=threads, z=(Z // 2, 1), y=((Y - rows) // 2, rows), timing=timing)
+        _, pairs = oracle.beamform(bp, acq.rf, acq.filters, threads=threads, z=(z_stride // 2, planes), y=(y_stride // 2, rows),
+                                   stride=(z_stride, y_stride), timing=timing)
         wall = time.perf_counter() - t0
         das_s = timing["das_seconds"]
-        return X * rows / das_s, (f"oracle DAS over {X}x{rows}x1 voxels (z plane {Z // 2}, {rows} centre rows) of the {X}x{Y}x{Z} frame, "
-                                  f"{pairs} pairs in {das_s:.2f} s DAS time ({wall:.2f} s incl. the single-threaded pre-DAS stages over the whole RF)")
+        return {"value": X * rows * planes / das_s, "unit": "voxels/s", "cores": threads,
+                "sample": (f"oracle DAS over {X}x{rows}x{planes} voxels ({planes} evenly spaced z-planes from {z_stride // 2} step {z_stride}, {rows} evenly spaced rows each) "
+                           f"of the {X}x{Y}x{Z} frame, {pairs} pairs in {das_s:.2f} s DAS time ({wall:.2f} s incl. the single-threaded pre-DAS stages over the whole RF)")}
 
-    value, text = sample(cores, 0.6 * budget_s)
-    one, one_text = sample(1, 0.4 * budget_s) if cores > 1 else (value, text)
+    share = min(affinity, int(os.environ.get("BENCH_CPU_THREADS", "16")))
+    legs = {"all_cores": sample(affinity, 0.35 * budget_s)}
+    legs["box_share"] = sample(share, 0.35 * budget_s) if share != affinity else legs["all_cores"]
+    legs["one_thread"] = sample(1, 0.30 * budget_s) if affinity > 1 else legs["all_cores"]
+    head = legs["all_cores"]
     return {
-        "value": value, "unit": "voxels/s", "cores": cores, "kind": "port", "sample": text,
-        "one_thread": {"value": one, "unit": "voxels/s", "sample": one_text},
-        "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+        "value": head["value"], "unit": "voxels/s", "cores": head["cores"], "kind": "port", "sample": head["sample"],
+        "box_share": legs["box_share"], "one_thread": legs["one_thread"],
+        "nproc": os.cpu_count(), "affinity": affinity,
     }
 
 

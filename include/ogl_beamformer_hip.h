@@ -40,8 +40,8 @@ BEAMFORMER_LIB_EXPORT int32_t  beamformer_hip_get_device(void);
  *   - the channel-mapped RF is then copied to every other device (hipMemcpyPeerAsync over xGMI, one copy
  *     stream per destination, three RF slots deep so the copies of frame n+1 run beside the kernels of
  *     frame n) and each device runs the whole stage list on its own contiguous z-slab of the block's
- *     grid (of its output shard, if one is set): slab sizes differ by at most one plane, earlier devices
- *     take the larger ones.  No reduction collective -- voxels are independent (das.glsl:368-407);
+ *     grid (of its output shard, if one is set): device i of n takes planes [i P / n, (i + 1) P / n) of
+ *     the P planes.  No reduction collective -- voxels are independent (das.glsl:368-407);
  *   - beamformer_get_last_frames returns whole frames: the slabs stitched in z order, each frame rounded
  *     to 64 bytes exactly as one device exports it (lib/ogl_beamformer_lib.c:656-702 semantics);
  *     a slab is bit-identical to the same planes of a one-device frame;

@@ -56,6 +56,7 @@ typedef struct {
 	uint32_t tile_shift[3];           /* log2 of the block's voxel tile extent per axis (256 voxels, or 64 with a channel split) */
 	uint32_t split_shift;             /* log2 K: K waves of a block share 64 voxels, each summing C/K channels */
 	uint32_t blocks[3];               /* blocks per axis */
+	uint32_t depth_major;             /* tile walk: 1 = z fastest (consecutive tiles share a lateral column), 0 = x, y, z */
 	uint32_t zero_offset;             /* factored kernel: byte offset (from rf) of >= 32 zero bytes the host keeps
 	                                     behind the DAS input, the gather target of out-of-range lanes */
 } BfDasArgs;
@@ -68,6 +69,7 @@ typedef struct {
 	uint32_t channel_chunk;   /* channels per receive-table rebuild */
 	uint32_t lds_bytes;       /* 16 * (channel_chunk << u_shift) + 16 * (transmits << v_shift) */
 	uint32_t tiles[3];        /* tiles along u, along v, z planes of the shard */
+	uint32_t depth_major;     /* tile walk: 1 = z fastest (consecutive tiles share a lateral column), 0 = x, y, z */
 	uint32_t window_shift;    /* staged kernel: log2 of the RF window (samples) copied to LDS per transmit */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes the host keeps behind
 	                             the DAS input: where out-of-range lanes gather from */
@@ -84,6 +86,7 @@ typedef struct {
 	uint32_t inner_coord;     /* transducer coordinate of the inner axis: 0 = x, 1 = y */
 	uint32_t inner_is_transmit;   /* inner loop walks decoded transmit elements (else receive channels) */
 	uint32_t tiles[3];        /* 64-voxel x segments, groups of 4 output rows, z planes of the shard */
+	uint32_t depth_major;     /* tile walk: 1 = z fastest, 0 = x, y, z */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes behind the DAS input */
 } BfHerculesArgs;
 

@@ -293,9 +293,18 @@ __global__ __launch_bounds__(BF_DAS_MAX_THREADS) void das_kernel(const BfDasArgs
 		/* ragged tail: ids whose run is shorter map onto the unassigned remainder */
 		return;
 	}
-	uint32_t bx = tile % p.blocks[0];
-	uint32_t by = (tile / p.blocks[0]) % p.blocks[1];
-	uint32_t bz = tile / (p.blocks[0] * p.blocks[1]);
+	/* depth-major walk: consecutive tiles (in flight together on an XCD) are one lateral column at
+	 * consecutive depths, whose RF windows overlap almost entirely (das_separable.hip) */
+	uint32_t bx, by, bz;
+	if (p.depth_major) {
+		bz = tile % p.blocks[2];
+		bx = (tile / p.blocks[2]) % p.blocks[0];
+		by = tile / (p.blocks[2] * p.blocks[0]);
+	} else {
+		bx = tile % p.blocks[0];
+		by = (tile / p.blocks[0]) % p.blocks[1];
+		bz = tile / (p.blocks[0] * p.blocks[1]);
+	}
 
 	uint32_t tid = threadIdx.x;
 	uint32_t lx  = tid & ((1u << p.tile_shift[0]) - 1u);

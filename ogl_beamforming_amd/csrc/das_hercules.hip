@@ -133,9 +133,18 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	const uint32_t per   = (total + 7u) / 8u;
 	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 	if (tile >= total) return;
-	const uint32_t tx_ = tile % q.tiles[0];
-	const uint32_t ty_ = (tile / q.tiles[0]) % q.tiles[1];
-	const uint32_t zl  = tile / (q.tiles[0] * q.tiles[1]);
+	/* depth-major walk (as das_separable.hip): the tiles an XCD has in flight together are one lateral
+	 * column at consecutive depths, whose RF windows overlap almost entirely */
+	uint32_t zl, tx_, ty_;
+	if (q.depth_major) {
+		zl  = tile % q.tiles[2];
+		tx_ = (tile / q.tiles[2]) % q.tiles[0];
+		ty_ = tile / (q.tiles[2] * q.tiles[0]);
+	} else {
+		tx_ = tile % q.tiles[0];
+		ty_ = (tile / q.tiles[0]) % q.tiles[1];
+		zl  = tile / (q.tiles[0] * q.tiles[1]);
+	}
 	const uint32_t z   = p.z_first + zl;
 
 	const uint32_t lane = threadIdx.x & 63u;

@@ -414,6 +414,11 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
 	}
 	if (!best_waves) return false;
 	q.u_axis = (uint32_t)u_axis;
+	{
+		/* BEAMFORMER_HIP_TILE_WALK=plane restores the x -> y -> z walk (measurement aid) */
+		const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");
+		q.depth_major = !(walk && walk[0] == 'p');
+	}
 	const uint32_t best_u = q.u_shift, best_v = q.v_shift;
 	uint32_t nu = a.size[u_axis], nv = a.size[1 - u_axis];
 	q.tiles[0] = (nu + (1u << best_u) - 1) >> best_u;
@@ -530,6 +535,8 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 	q.tiles[0] = (a.size[0] + 63u) / 64u;
 	q.tiles[1] = (a.size[1] + 3u) / 4u;
 	q.tiles[2] = zcount;
+	const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z (measurement aid) */
+	q.depth_major = !(walk && walk[0] == 'p');
 	return true;
 }
 
@@ -729,6 +736,10 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			while (!(c.das_path_mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
 			choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
 			for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+			{
+				const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z (measurement aid) */
+				a.depth_major = !(walk && walk[0] == 'p');
+			}
 
 			if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
@@ -825,12 +836,13 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 }
 
 /* z-slab of device `i` of `n` over `planes` planes starting at `first`: contiguous, sizes differing by
- * at most one, earlier devices take the larger slabs (ogl_beamforming_amd/sharding.py uses the same rule) */
+ * at most one -- the rule of ogl_beamforming_amd/sharding.py (one process per GPU), so both ways of
+ * spreading a frame over a node cut it at the same planes */
 static void device_slab(uint32_t i, uint32_t n, uint32_t first, uint32_t planes, uint32_t &z_first, uint32_t &z_count)
 {
-	uint32_t base = planes / n, extra = planes % n;
-	z_count = base + (i < extra ? 1u : 0u);
-	z_first = first + i * base + (i < extra ? i : extra);
+	uint32_t begin = (uint32_t)((uint64_t)i * planes / n), end = (uint32_t)((uint64_t)(i + 1) * planes / n);
+	z_first = first + begin;
+	z_count = end - begin;
 }
 
 /* Several devices, one frame: the channel-mapped RF that the ingest device (devices[0])

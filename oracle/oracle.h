@@ -163,6 +163,7 @@ typedef struct {
 	/* build extension: z-slab of the output grid (whole grid when z_count == 0) */
 	uint32_t z_first, z_count;
 	uint32_t y_first, y_count;    /* likewise rows (whole when y_count == 0); output holds only the sub-grid */
+	uint32_t z_stride, y_stride;  /* sub-grid sampling: plane z_first + k z_stride, row y_first + k y_stride (0 = 1) */
 	int32_t  threads;             /* OpenMP threads, 0 = default */
 } OracleDAS;
 /* das.glsl:368-407: output[...] += sum, incoherent[...] += |.| sums.
@@ -220,6 +221,9 @@ int  oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out
 /* the same frame restricted to z planes [z_first, z_first+z_count) and rows
  * [y_first, y_first+y_count) (0 counts = whole axis); out holds X * rows * planes voxels.
  * das_seconds (optional) receives the wall time spent inside oracle_das. */
+/* Sampling strides of the sub-grid for later oracle_beamform_subgrid calls (1, 1 = contiguous): plane
+ * z_first + k z_stride, row y_first + k y_stride.  bench.py's CPU baseline times evenly spaced planes. */
+void oracle_set_subgrid_stride(uint32_t z_stride, uint32_t y_stride);
 int  oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, float *out, uint64_t *pairs_out,
                              int threads, uint32_t z_first, uint32_t z_count, uint32_t y_first, uint32_t y_count,
                              double *das_seconds);

@@ -296,7 +296,8 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 
 	#pragma omp parallel for schedule(dynamic, 4) reduction(+:pairs) num_threads(oracle_thread_count(p->threads))
 	for (int64_t row = 0; row < rows; row++) {
-		uint32_t zl = (uint32_t)(row / yn), yl = (uint32_t)(row % yn), z = z0 + zl, y = y0 + yl;
+		uint32_t zl = (uint32_t)(row / yn), yl = (uint32_t)(row % yn);
+		uint32_t z = z0 + zl * (p->z_stride ? p->z_stride : 1u), y = y0 + yl * (p->y_stride ? p->y_stride : 1u);
 		for (uint32_t x = 0; x < X; x++) {
 			REAL point[3] = {
 				(REAL)x / (REAL)(X > 2 ? X - 1 : 1),

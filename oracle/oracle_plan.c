@@ -214,6 +214,8 @@ typedef struct {
 	double   das_seconds;
 } Exec;
 
+static uint32_t subgrid_z_stride = 1, subgrid_y_stride = 1;   /* oracle_set_subgrid_stride */
+
 static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_pointer, int64_t rf_elements_left)
 {
 	const OraclePlan  *plan = e->plan;
@@ -320,6 +322,7 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		d.readi_hadamard = e->readi_hadamard;
 		d.threads = e->threads;
 		d.z_first = e->z_first; d.z_count = e->z_count; d.y_first = e->y_first; d.y_count = e->y_count;
+		d.z_stride = subgrid_z_stride; d.y_stride = subgrid_y_stride;
 		double t0 = oracle_now();
 		e->pairs += oracle_das(&d, (const float *)pp_das, e->frame, e->incoherent);
 		e->das_seconds += oracle_now() - t0;
@@ -336,6 +339,12 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 int oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out, uint64_t *pairs_out, int threads)
 {
 	return oracle_beamform_subgrid(pb, raw, out, pairs_out, threads, 0, 0, 0, 0, 0);
+}
+
+void oracle_set_subgrid_stride(uint32_t z_stride, uint32_t y_stride)
+{
+	subgrid_z_stride = z_stride ? z_stride : 1;
+	subgrid_y_stride = y_stride ? y_stride : 1;
 }
 
 int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, float *out, uint64_t *pairs_out,

@@ -48,14 +48,15 @@ def test_slabs_stitch_to_the_one_device_frame(name, count, bflib, devices):
     devices([0] * count)
     many = bflib.beamform(acq.bp, acq.rf, acq.filters)
     assert same_bits(one, many)
-    # per-device slabs: contiguous, sizes differing by at most one, larger ones first
+    # per-device slabs: the cut of ogl_beamforming_amd/sharding.py (what one-process-per-GPU runs use)
+    from ogl_beamforming_amd import sharding
     Z = one.shape[0]
     planes = []
     for i in range(count):
         t = P.HipFrameTimings()
         assert lib.beamformer_hip_get_device_frame_timings(i, C.byref(t))
         planes.append(int(t.das_voxels) // (one.shape[1] * one.shape[2]))
-    assert sum(planes) == Z and max(planes) - min(planes) <= 1 and planes == sorted(planes, reverse=True)
+    assert planes == [c for _, c in sharding.slabs(count, Z)]
     mm = (C.c_float * 2)()
     assert lib.beamformer_hip_frame_min_max(mm)
     assert np.array_equal(np.array(mm[:]), np.array(mm_one[:]), equal_nan=True)

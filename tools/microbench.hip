@@ -233,10 +233,14 @@ template <int OP> static void valu_case(bool first)
 		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
 		Result r = run([&] { hipLaunchKernelGGL((valu_probe<OP>), dim3(blocks), dim3(64 * waves_per_block), 0, 0, d_stamps, d_sink, iters); }, waves);
 		double inst = 32.0 * iters;
-		double per_simd = wps * inst / r.cycles_per_wave;          /* wave-instructions per clock per SIMD */
-		emit("%s{\"op\":\"%s\",\"waves_per_simd\":%d,\"wave_inst_per_clk_per_simd\":%.4f,\"cycles_per_wave_inst\":%.3f,"
-		     "\"lanes_per_clk_per_cu\":%.1f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", (first && wps == 1) ? "" : ",\n  ",
-		     op_name[OP], wps, per_simd, 1.0 / per_simd, per_simd * 64 * 4, r.clock_ghz, r.wall_ms);
+		double per_simd = wps * inst / r.cycles_per_wave;          /* wave-instructions per clock per SIMD, from the waves' own stamps */
+		/* the same from the launch's wall time (HIP events) at the measured clock: includes launch ramp and
+		 * waves that do not all overlap, so it is the conservative figure (the one DESIGN.md quotes) */
+		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+		double cyc_wall = wall_cycles / (inst * wps);
+		emit("%s{\"op\":\"%s\",\"waves_per_simd\":%d,\"cycles_per_wave_inst_per_simd_wall\":%.3f,\"cycles_per_wave_inst_per_simd_stamps\":%.3f,"
+		     "\"lanes_per_clk_per_cu_wall\":%.1f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", (first && wps == 1) ? "" : ",\n  ",
+		     op_name[OP], wps, cyc_wall, 1.0 / per_simd, 64.0 * 4 / cyc_wall, r.clock_ghz, r.wall_ms);
 	}
 }
 
@@ -251,11 +255,14 @@ template <int WIDTH, int PAT> static void gather_case(const char *level, uint32_
 		Result r = run([&] { hipLaunchKernelGGL((gather_probe<WIDTH, PAT>), dim3(blocks), dim3(64 * waves_per_block), 0, 0,
 		                                        d_window, window, per_block ? 1u : 0u, d_stamps, d_sink, iters); }, waves);
 		double bytes_per_wave = 4.0 * iters * 64 * WIDTH;
-		double b_clk_cu = 4.0 * wps * bytes_per_wave / r.cycles_per_wave;
+		double b_clk_cu = 4.0 * wps * bytes_per_wave / r.cycles_per_wave;            /* from the waves' own stamps */
+		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+		double b_clk_cu_wall = bytes_per_wave * waves / wall_cycles / n_cu;          /* from the launch's wall time: conservative */
 		emit("%s{\"inst\":\"global_load_%s\",\"level\":\"%s\",\"window_bytes\":%u,\"pattern\":\"%s\",\"waves_per_simd\":%d,"
-		     "\"bytes_per_clk_per_cu\":%.2f,\"clk_per_wave_inst_per_cu\":%.2f,\"clock_ghz\":%.3f,\"chip_TBps\":%.2f,\"wall_ms\":%.3f}",
+		     "\"bytes_per_clk_per_cu_wall\":%.2f,\"bytes_per_clk_per_cu_stamps\":%.2f,\"clk_per_wave_inst_per_cu_wall\":%.2f,"
+		     "\"clock_ghz\":%.3f,\"chip_TBps_wall\":%.2f,\"wall_ms\":%.3f}",
 		     first ? "" : ",\n  ", WIDTH == 16 ? "dwordx4" : (WIDTH == 8 ? "dwordx2" : "dword"), level, window, pat_name[PAT], wps,
-		     b_clk_cu, 64.0 * WIDTH / b_clk_cu, r.clock_ghz, b_clk_cu * n_cu * r.clock_ghz * 1e9 / 1e12, r.wall_ms);
+		     b_clk_cu_wall, b_clk_cu, 64.0 * WIDTH / b_clk_cu_wall, r.clock_ghz, b_clk_cu_wall * n_cu * r.clock_ghz * 1e9 / 1e12, r.wall_ms);
 		first = false;
 	}
 }
@@ -272,9 +279,11 @@ template <int KIND, int PAT> static void lds_case(bool &first)
 		                                        d_stamps, d_sink, iters, window); }, waves);
 		double bytes_per_wave = 4.0 * iters * 64 * WIDTH;
 		double b_clk_cu = 4.0 * wps * bytes_per_wave / r.cycles_per_wave;
-		emit("%s{\"inst\":\"%s\",\"pattern\":\"%s\",\"waves_per_simd\":%d,\"bytes_per_clk_per_cu\":%.2f,"
-		     "\"clk_per_wave_inst_per_cu\":%.2f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
-		     first ? "" : ",\n  ", lds_name[KIND], pat_name[PAT], wps, b_clk_cu, 64.0 * WIDTH / b_clk_cu, r.clock_ghz, r.wall_ms);
+		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+		double b_clk_cu_wall = bytes_per_wave * waves / wall_cycles / n_cu;
+		emit("%s{\"inst\":\"%s\",\"pattern\":\"%s\",\"waves_per_simd\":%d,\"bytes_per_clk_per_cu_wall\":%.2f,"
+		     "\"bytes_per_clk_per_cu_stamps\":%.2f,\"clk_per_wave_inst_per_cu_wall\":%.2f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
+		     first ? "" : ",\n  ", lds_name[KIND], pat_name[PAT], wps, b_clk_cu_wall, b_clk_cu, 64.0 * WIDTH / b_clk_cu_wall, r.clock_ghz, r.wall_ms);
 		first = false;
 	}
 }
@@ -291,8 +300,9 @@ int main(int argc, char **argv)
 	bool quick = argc > 1 && !strcmp(argv[1], "--quick");
 
 	emit("{\"device\":\"%s\",\"arch\":\"%s\",\"compute_units\":%d,\"clock_rate_khz\":%d,\n", prop.name, prop.gcnArchName, n_cu, prop.clockRate);
-	emit(" \"method\":\"in-kernel s_memtime (shader clock) and s_memrealtime (100 MHz) around a loop of inline-asm instructions; median over waves; "
-	     "every CU busy with the stated waves per SIMD\",\n");
+	emit(" \"method\":\"loops of inline-asm instructions, every CU busy with the stated waves per SIMD; clock_ghz = in-kernel s_memtime / s_memrealtime "
+	     "(100 MHz), median over waves; *_wall rates = work / (HIP-event wall time x that clock), *_stamps rates = from each wave's own s_memtime span "
+	     "(optimistic when the waves of a CU do not all overlap)\",\n");
 
 	emit(" \"valu\":[\n  ");
 	valu_case<OP_FMA>(true);

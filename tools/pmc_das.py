@@ -30,8 +30,8 @@ GROUPS = [
      "SQ_WAIT_ANY", "SQ_INST_CYCLES_VMEM_RD", "SQ_THREAD_CYCLES_VALU"],
     ["SQ_INSTS_SMEM", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_CVT",
      "SQ_INSTS_VALU_INT32", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
-    ["TA_BUSY_avr", "TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum",
-     "TA_DATA_STALLED_BY_TC_CYCLES_sum"],
+    ["TA_BUSY_avr", "TA_TA_BUSY_sum"],
+    ["TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum"],
     ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TA_TCP_STATE_READ_sum"],
     ["TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum",
      "TCP_GATE_EN1_sum"],
