@@ -48,6 +48,7 @@ typedef struct {
 	int32_t  acquisition_count, channel_count, sample_count, sparse;
 	float    sampling_frequency, inv_sampling_frequency, demodulation_frequency;
 	float    inv_speed_of_sound, time_offset, f_number;
+	float    speed_of_sound;          /* with inv_speed_of_sound: div_speed_of_sound() of das_common.h */
 	float    turns_per_sample;        /* demodulation_frequency / sampling_frequency: IQ phase per sample, in turns */
 	float    first_transmit_weight;   /* HERCULES: 1/sqrt(acquisition_count) (das.glsl:272-273) */
 	uint32_t size[3];                 /* whole output grid */

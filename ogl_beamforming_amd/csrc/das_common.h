@@ -37,6 +37,20 @@ __device__ __forceinline__ float hw_fract(float x)     { return __builtin_amdgcn
 __device__ __forceinline__ float hw_sin_turns(float x) { return __builtin_amdgcn_sinf(x); }   /* sin(2 pi x) */
 __device__ __forceinline__ float hw_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }   /* cos(2 pi x) */
 
+/* distance / speed_of_sound, correctly rounded in all but rare cases: the product with the reciprocal
+ * plus one Newton correction (2 FMAs).  The plain product carries the reciprocal's own rounding error as
+ * a SYSTEMATIC relative bias of every delay (1.9e-8 for c = 1540 m/s): 4e-5 of a sample at index 2000,
+ * i.e. 1.2e-4 rad of demodulation phase common to all taps -- which is 1.2e-4 of a coherent peak, the
+ * whole parity budget.  Used wherever a delay is computed once per table entry or per voxel term (the
+ * reference divides: sample_index, das.glsl:126-130); the per-pair loops of das.hip / das_hercules.hip keep
+ * the reciprocal. */
+__device__ __forceinline__ float div_speed_of_sound(float distance, const BfDasArgs &p)
+{
+	float q = distance * p.inv_speed_of_sound;
+	float e = __builtin_fmaf(-q, p.speed_of_sound, distance);
+	return __builtin_fmaf(e, p.inv_speed_of_sound, q);
+}
+
 /* (int)floor(x) in one instruction (hipcc emits v_floor_f32 + v_cvt_i32_f32) */
 __device__ __forceinline__ int cvt_floor_i32(float x)
 {

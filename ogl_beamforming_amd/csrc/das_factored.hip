@@ -110,7 +110,6 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		const int   S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
 		const int   last = S - 1;
 		const float Sf = (float)S;
-		const float fs_over_c = p.sampling_frequency * p.inv_speed_of_sound;
 		const float turns_per_sample = p.demodulation_frequency * p.inv_sampling_frequency;
 
 		/* transducer-space point; FORCES voxels arrive already transformed (beamformer_core.c:913-915) */
@@ -155,8 +154,8 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				float dist    = hw_sqrt(dx * dx + zz);
 				/* RCA: the time offset rides with the transmit term; FORCES: with the receive term
 				 * (sample_index, das.glsl:126-130) */
-				float index   = FAMILY == BF_DAS_RCA ? dist * fs_over_c
-				                                     : (dist * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+				float index   = FAMILY == BF_DAS_RCA ? div_speed_of_sound(dist, p) * p.sampling_frequency
+				                                     : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
 				float apod    = pass ? apodize(a_arg) : 0.f;
 				R[k].index = pass ? index : -1.0e9f;
 				R[k].apod  = apod;
@@ -187,11 +186,11 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				float t_index;
 				if constexpr (FAMILY == BF_DAS_RCA) {
 					const BfTransmit t = p.transmits[a];
-					t_index = (transmit_distance(t, wx, wy, wz) * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+					t_index = (div_speed_of_sound(transmit_distance(t, wx, wy, wz), p) + p.time_offset) * p.sampling_frequency;
 				} else {
 					float tx_channel = p.sparse ? (float)p.sparse_elements[a - first_transmit] : (float)a;
 					float tdx        = xx - p.pitch[0] * tx_channel;
-					t_index = hw_sqrt(transmit_yz_squared + tdx * tdx) * fs_over_c;
+					t_index = div_speed_of_sound(hw_sqrt(transmit_yz_squared + tdx * tdx) * p.sampling_frequency, p);   /* das.glsl:312 */
 				}
 				float tc = 1.f, ts = 0.f;
 				if constexpr (CPLX) {

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 			if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
 			else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
 		}
-		float t_idx = (dist * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+		float t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
 		f32x4 entry = {1.f, 0.f, t_idx, 0.f};
 		if constexpr (CPLX) {
 			float turns = phase_turns(phase_k, t_idx);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 			if (a_arg < 0.5f) {
 				float cs    = hw_cos_turns(0.5f * a_arg);
 				float apod  = cs * cs;
-				float r_idx = hw_sqrt(dx * dx + xz * xz) * p.inv_speed_of_sound * p.sampling_frequency;
+				float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), p) * p.sampling_frequency;
 				entry.x = r_idx;
 				entry.w = apod;
 				if constexpr (CPLX) {

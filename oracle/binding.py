@@ -67,6 +67,8 @@ def library():
         lib.oracle_beamform_subgrid.restype = C.c_int
         lib.oracle_beamform_subgrid.argtypes = [C.POINTER(OracleParameterBlock), C.c_void_p, fp, C.POINTER(C.c_uint64), C.c_int,
                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+        lib.oracle_set_nearest_ambiguity_buffer.restype = None
+        lib.oracle_set_nearest_ambiguity_buffer.argtypes = [C.c_void_p]
         lib.oracle_set_subgrid_stride.restype = None
         lib.oracle_set_subgrid_stride.argtypes = [C.c_uint32, C.c_uint32]
         lib.oracle_plan.restype = C.c_int
@@ -132,11 +134,13 @@ def plan(bp, filters=()):
     return out if ok else None
 
 
-def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, stride=(1, 1)):
+def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, stride=(1, 1), flags=None):
     """Whole frame on the CPU, 16-channel chunks as the reference runs it.  z / y = (first,
     count) restrict the computed planes / rows (count 0 = whole axis); stride = (z, y) steps
     between the computed planes / rows.  Returns (frame (Z, Y, X) float32|complex64, pairs);
-    timing (a dict) receives das_seconds."""
+    timing (a dict) receives das_seconds; flags (a dict) receives, for nearest interpolation, "budget": per
+    voxel the sum of |other sample - chosen sample| over the taps whose index sat within 2^-10 of a rounding
+    boundary (what tap flips can move the coherent sum by), and "near_half" = budget > 0."""
     pb = parameter_block(bp, filters)
     p = plan(bp, filters)
     if p is None:
@@ -150,12 +154,18 @@ def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, str
     das_seconds = C.c_double(0)
     rf = np.ascontiguousarray(rf)
     library().oracle_set_subgrid_stride(stride[0], stride[1])
+    budget = np.zeros(voxels, np.float32) if flags is not None else None
+    library().oracle_set_nearest_ambiguity_buffer(budget.ctypes.data_as(C.c_void_p) if budget is not None else None)
     try:
         ok = library().oracle_beamform_subgrid(C.byref(pb), rf.ctypes.data_as(C.c_void_p),
                                                out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(pairs), threads,
                                                z[0], z[1], y[0], y[1], C.byref(das_seconds))
     finally:
         library().oracle_set_subgrid_stride(1, 1)
+        library().oracle_set_nearest_ambiguity_buffer(None)
+    if flags is not None:
+        flags["budget"] = budget.reshape(nz, ny, pts[0])
+        flags["near_half"] = flags["budget"] > 0
     if not ok:
         raise RuntimeError("oracle_beamform failed")
     if timing is not None:

@@ -221,6 +221,12 @@ int  oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out
 /* the same frame restricted to z planes [z_first, z_first+z_count) and rows
  * [y_first, y_first+y_count) (0 counts = whole axis); out holds X * rows * planes voxels.
  * das_seconds (optional) receives the wall time spent inside oracle_das. */
+/* Nearest-interpolation parity aid: while a buffer is set (one float per voxel of the computed (sub-)grid,
+ * zeroed by the caller), oracle_das adds to each voxel the ambiguity budget of its sum: for every tap whose
+ * sample index lies within 2^-10 of a rounding boundary (k + 1/2, or an end of the valid range), where an
+ * implementation that differs by float rounding legitimately picks the other sample, |other - chosen|.
+ * A voxel with a zero entry has no such tap.  NULL switches it off. */
+void oracle_set_nearest_ambiguity_buffer(float *budget);
 /* Sampling strides of the sub-grid for later oracle_beamform_subgrid calls (1, 1 = contiguous): plane
  * z_first + k z_stride, row y_first + k y_stride.  bench.py's CPU baseline times evenly spaced planes. */
 void oracle_set_subgrid_stride(uint32_t z_stride, uint32_t y_stride);

@@ -18,6 +18,17 @@ static int oracle_thread_count(int requested)
 #endif
 }
 
+/* Nearest interpolation is discontinuous at index = k + 1/2 (and at the two ends of the valid range):
+ * an implementation whose index differs by float rounding picks the other sample there.  For every
+ * such tap the oracle adds |other sample - chosen sample| (the most the flip can move the coherent
+ * sum; apodization and weights are <= 1) to a per-thread budget; das_run adds each voxel's budget to
+ * the caller's buffer (when set), so a parity test can demand |gpu - oracle| <= tolerance + budget on
+ * EVERY voxel instead of allowing a fraction of mismatches.  Test infrastructure, not the shader. */
+#define ORACLE_NEAR_HALF (1.0 / 1024.0)
+static _Thread_local float oracle_near_half_budget;
+static float *oracle_near_half_buffer;          /* one float per sub-grid voxel, or NULL */
+void oracle_set_nearest_ambiguity_buffer(float *budget) { oracle_near_half_buffer = budget; }
+
 #define REAL     float
 #define FN(n)    n##_f32
 #define R_SQRT   sqrtf

@@ -68,6 +68,22 @@ static inline FN(c2) FN(sample_rf)(const OracleDAS *p, const float *rf, int rf_o
 	case BeamformerInterpolationMode_Nearest:{
 		if (index >= 0 && index < ((REAL)p->sample_count - (REAL)0.5))
 			result = FN(rotate_iq)(p, FN(load)(p, rf, rf_offset + (int)R_ROUND(index)), index / fs);
+		/* test infrastructure, not part of the shader: a tap within 2^-10 of a rounding boundary adds the
+		 * size of the possible flip to the voxel's ambiguity budget (oracle_das.c) */
+		if (oracle_near_half_buffer) {
+			REAL f = index - R_FLOOR(index), S = (REAL)p->sample_count;
+			int  k = (int)R_ROUND(index), other = -1, valid = index >= 0 && index < S - (REAL)0.5;
+			int  boundary = 0;
+			if (R_FABS(f - (REAL)0.5) < (REAL)ORACLE_NEAR_HALF) { boundary = 1; other = f < (REAL)0.5 ? k + 1 : k - 1; }
+			if (R_FABS(index) < (REAL)ORACLE_NEAR_HALF || R_FABS(index - (S - (REAL)0.5)) < (REAL)ORACLE_NEAR_HALF) boundary = 1;
+			if (boundary) {
+				FN(c2) a = {0, 0}, b = {0, 0};
+				if (valid) a = FN(load)(p, rf, rf_offset + k);
+				if (other >= 0 && other < p->sample_count) b = FN(load)(p, rf, rf_offset + other);
+				REAL dx = a.x - b.x, dy = a.y - b.y;
+				oracle_near_half_budget += (float)R_SQRT(dx * dx + dy * dy) + 1e-30f;
+			}
+		}
 	}break;
 	case BeamformerInterpolationMode_Linear:{
 		if (index >= 0 && index < (REAL)(p->sample_count - 1)) {
@@ -307,6 +323,7 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 			REAL world[3], xdc[3];
 			FN(m4_point)(p->voxel_transform, point, world);
 			FN(acc) acc = {{0, 0, 0}, 0};
+			oracle_near_half_budget = 0.f;
 			switch (p->acquisition_kind) {
 			case BeamformerAcquisitionKind_FORCES:
 			case BeamformerAcquisitionKind_UFORCES:
@@ -327,6 +344,7 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 			default: break;
 			}
 			uint64_t out_index = (uint64_t)X * yn * zl + (uint64_t)X * yl + x;
+			if (oracle_near_half_buffer) oracle_near_half_buffer[out_index] += oracle_near_half_budget;
 			if (p->coherency_weighting) incoherent[out_index] += acc.c[2];
 			output[elements * out_index] += acc.c[0];
 			if (elements == 2) output[elements * out_index + 1] += acc.c[1];

@@ -11,23 +11,40 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 
 
-def compare(gpu, ref, acq):
+def reference(oracle, acq):
+    """(frame, pairs, flags) of the oracle; for nearest interpolation flags carries the per-voxel
+    ambiguity budget of taps that sit within 2^-10 of a rounding boundary (oracle/oracle.h)"""
+    flags = {} if acq.bp.interpolation_mode == int(P.InterpolationMode.Nearest) else None
+    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters, flags=flags)
+    return ref, pairs, flags
+
+
+def compare(gpu, ref, acq, flags=None):
     assert gpu.shape == ref.shape and gpu.dtype == ref.dtype
     nan_gpu, nan_ref = np.isnan(gpu), np.isnan(ref)
     assert np.array_equal(nan_gpu, nan_ref), "NaN positions (coherency weighting with zero incoherent sum) differ"
     ok = ~nan_ref
     scale = np.max(np.abs(ref[ok])) if ok.any() else 1.0
     assert scale > 0, "oracle image is empty: the case does not exercise the path"
-    err = np.abs(gpu[ok] - ref[ok]) / scale
-    if acq.bp.interpolation_mode == int(P.InterpolationMode.Nearest):
-        # a sample index within float rounding of k + 0.5 may pick the other tap; the chance
-        # grows with the pairs summed per voxel (~1e-4 each)
-        allowed = min(0.05, max(1e-3, 3e-4 * acq.bp.channel_count * acq.bp.acquisition_count))
-        bad = float(np.mean(err > 1e-3))
-        assert bad < allowed, f"nearest: mismatch fraction {bad:.2e} (allowed {allowed:.2e})"
-        assert np.median(err) < 1e-5
-        return float(np.median(err))
     tol = cases.tolerance(acq)
+    if acq.bp.interpolation_mode == int(P.InterpolationMode.Nearest):
+        # A sample index within float rounding of k + 1/2 may pick the other tap.  The oracle reports, per
+        # voxel, how far such flips can move the coherent sum (flags["budget"], zero where no tap is near a
+        # boundary): without coherency weighting EVERY voxel must agree within tolerance + budget; with it
+        # (a quotient of two sums the flips both touch) the voxels that hold no such tap must meet SURVEY
+        # 8c's bar: fewer than 1e-3 of them off by more than 1e-3.
+        assert flags is not None, "nearest interpolation is compared against the oracle's ambiguity budget"
+        err = np.abs(gpu - ref)
+        if not acq.bp.coherency_weighting:
+            slack = tol * scale + 1.01 * flags["budget"]
+            assert (err[ok] <= slack[ok]).all(), f"nearest: max excess {np.max(err[ok] - slack[ok]):.3e} over tolerance + tap ambiguity"
+        clean = ok & ~flags["near_half"]
+        if clean.any():
+            bad = float(np.mean(err[clean] > max(tol, 1e-3) * scale))
+            assert bad < 1e-3, f"nearest: mismatch fraction {bad:.2e} on the {int(clean.sum())} voxels without boundary taps"
+        assert np.median(err[ok]) / scale < (1e-5 if tol <= 1e-4 else tol)
+        return float(np.median(err[ok]) / scale)
+    err = np.abs(gpu[ok] - ref[ok]) / scale
     assert err.max() <= tol, f"max relative error {err.max():.3e} > {tol:.0e}"
     return float(err.max())
 
@@ -92,18 +109,18 @@ def expected_path(name, bp):
 def test_frame_parity(name, bflib, oracle):
     """default (automatic) DAS path"""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     bflib.library().beamformer_hip_set_das_path(0)
     gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
     assert last_das_path(bflib) == expected_path(name, acq.bp)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 @pytest.mark.parametrize("name", sorted(SEPARABLE))
 def test_general_kernel_on_separable_geometry(name, bflib, oracle):
     """the general kernel on the cases the fast path would otherwise take"""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(1)
     try:
@@ -111,7 +128,7 @@ def test_general_kernel_on_separable_geometry(name, bflib, oracle):
         assert last_das_path(bflib) == 0
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 @pytest.mark.parametrize("name", sorted(SEPARABLE))
@@ -119,7 +136,7 @@ def test_lds_staged_kernel(name, bflib, oracle):
     """the opt-in LDS-staged variant; geometries outside its window bound fall back to the
     gather kernel"""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(3)
     try:
@@ -127,7 +144,7 @@ def test_lds_staged_kernel(name, bflib, oracle):
         assert last_das_path(bflib) == (2 if name in STAGED else 1)
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))
@@ -135,7 +152,7 @@ def test_general_kernel_without_channel_split(name, bflib, oracle):
     """These acquisitions are small, so the default launch splits the channel loop over waves;
     0x11 forces the one-thread-per-voxel form of the same kernel that full-size frames use."""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(0x11)
     try:
@@ -143,7 +160,7 @@ def test_general_kernel_without_channel_split(name, bflib, oracle):
         assert last_das_path(bflib) == 0
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 HERCULES = sorted(n for n in cases.CASES if hercules_family(cases.make(n).bp))
@@ -155,7 +172,7 @@ def test_hercules_aligned_kernel(name, bflib, oracle):
     automatic rule): both loop orders, sparse transmits, every interpolation, real and IQ data, with and
     without coherency weighting, checked and unchecked inner loops"""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(6)
     try:
@@ -163,7 +180,7 @@ def test_hercules_aligned_kernel(name, bflib, oracle):
         assert last_das_path(bflib) == 5
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 FACTORED = sorted(n for n in cases.CASES if factored_applies(cases.make(n).bp))
@@ -176,7 +193,7 @@ def test_factored_kernel(name, split, bflib, oracle):
     kernel would take and with fewer transmits than the automatic rule asks for -- with the
     channel split these small frames get by default and without it"""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(0x04 if split else 0x14)
     try:
@@ -184,7 +201,7 @@ def test_factored_kernel(name, split, bflib, oracle):
         assert last_das_path(bflib) == 3
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 def rowcache_applies(bp):
@@ -202,7 +219,7 @@ def test_rowcache_kernel(name, bflib, oracle):
     """das_rowcache.hip (opt-in experiment: the factored kernel with the RF row segments of a block
     cached in LDS), forced with mode 0x15 (whole 256-voxel tiles, no channel split)"""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(0x15)
     try:
@@ -210,7 +227,7 @@ def test_rowcache_kernel(name, bflib, oracle):
         assert last_das_path(bflib) == 4
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq)
+    compare(gpu, ref, acq, flags)
 
 
 DECODING = sorted(n for n in cases.CASES
@@ -223,16 +240,16 @@ def test_decode_dense_kernel_and_fwht_agree(name, bflib, oracle):
     (orders 2^k, 12*2^k, 20*2^k); 0x20 keeps the O(T^2) kernel.  Both match the oracle; on Int16
     RF decoded first every partial sum is an exact integer, so the two frames are bit-identical."""
     acq = cases.make(name)
-    ref, pairs = oracle.beamform(acq.bp, acq.rf, acq.filters)
+    ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     fast = bflib.beamform(acq.bp, acq.rf, acq.filters)
-    compare(fast, ref, acq)
+    compare(fast, ref, acq, flags)
     lib.beamformer_hip_set_das_path(0x20)
     try:
         dense = bflib.beamform(acq.bp, acq.rf, acq.filters)
     finally:
         lib.beamformer_hip_set_das_path(0)
-    compare(dense, ref, acq)
+    compare(dense, ref, acq, flags)
     stages = list(acq.bp.compute_stages[: acq.bp.compute_stages_count])
     if acq.bp.data_kind == int(P.DataKind.Int16) and stages[0] == int(P.ShaderKind.Decode):
         assert np.array_equal(fast, dense, equal_nan=True)

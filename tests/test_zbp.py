@@ -230,3 +230,136 @@ def test_throughput_tool_beamforms_a_file(compressed, tmp_path):
     assert last.startswith("total: 20 frames"), r.stdout
     hi = float(last.rsplit(",", 1)[1].strip(" ]"))
     assert np.isfinite(hi) and hi > 0                                # a real image came out
+
+
+# ------------------------------------------------------------------ file -> loader -> pipeline -> frame
+
+def study_parameters(bp, transform_fn, points, lateral, axial, f_number):
+    """execute_study's settings on top of what the loader filled (tests/throughput.c:421-491):
+    the voxel grid, f-number, cubic interpolation, {Demodulate unless complex, Decode, DAS} and the
+    Kaiser low-pass / matched chirp filter for the emission.  Returns the filter."""
+    pts = (C.c_int32 * 3)(*points)
+    lo = np.array([lateral[0], axial[0], 0], np.float32)
+    hi = np.array([lateral[1], axial[1], 0], np.float32)
+    out = np.zeros(16, np.float32)
+    fp = C.POINTER(C.c_float)
+    transform_fn(lo.ctypes.data_as(fp), hi.ctypes.data_as(fp), pts, out.ctypes.data_as(fp))
+    bp.das_voxel_transform[:] = [float(v) for v in out]
+    bp.output_points[:] = [pts[0], pts[1], pts[2], 1]
+    bp.f_number = f_number
+    bp.interpolation_mode = int(P.InterpolationMode.Cubic)
+    bp.decimation_rate = 1
+    stages = []
+    if int(bp.data_kind) not in (int(P.DataKind.Float32Complex), int(P.DataKind.Int16Complex)):
+        stages.append(int(P.ShaderKind.Demodulate))
+    stages += [int(P.ShaderKind.Decode), int(P.ShaderKind.DAS)]
+    for i, st in enumerate(stages):
+        bp.compute_stages[i] = st
+        bp.compute_stage_parameters[i] = 0
+    bp.compute_stages_count = len(stages)
+    f = P.FilterParameters()
+    f.sampling_frequency = bp.sampling_frequency / 2
+    if int(bp.emission_parameters.kind) == 1:                         # chirp: matched filter (:475-485)
+        f.kind = int(P.FilterKind.MatchedChirp)
+        f.matched_chirp.duration = bp.emission_parameters.chirp.duration
+        f.matched_chirp.min_frequency = bp.emission_parameters.chirp.min_frequency - bp.demodulation_frequency
+        f.matched_chirp.max_frequency = bp.emission_parameters.chirp.max_frequency - bp.demodulation_frequency
+        f.complex = 1
+    else:                                                             # sine: Kaiser low-pass (:463-473)
+        f.kind = int(P.FilterKind.Kaiser)
+        f.kaiser.beta = 5.65
+        f.kaiser.cutoff_frequency = 0.5 * bp.emission_parameters.sine.frequency
+        f.kaiser.length = 36
+    return f
+
+
+def simple_parameters_from_oracle(ref):
+    """BeamformerSimpleParameters from the fields oracle/zbp.py derives (never touches the product loader)"""
+    bp = P.SimpleParameters()
+    for field in ("sample_count", "channel_count", "acquisition_count", "sampling_mode", "acquisition_kind", "decode_mode",
+                  "data_kind", "contrast_mode", "single_focus", "single_orientation", "transmit_receive_orientation"):
+        setattr(bp, field, int(ref.get(field, 0)))
+    for field in ("sampling_frequency", "demodulation_frequency", "speed_of_sound", "time_offset"):
+        setattr(bp, field, float(ref[field]))
+    Cn, A = ref["channel_count"], ref["acquisition_count"]
+    bp.channel_mapping[:Cn] = [int(v) for v in ref["channel_mapping"]]
+    bp.xdc_transform[:] = [float(v) for v in ref["xdc_transform"]]
+    bp.xdc_element_pitch[:] = [float(v) for v in ref["xdc_element_pitch"]]
+    bp.raw_data_dimensions[:] = [int(v) for v in ref["raw_data_dimensions"]]
+    bp.focal_vector[:] = [float(v) for v in ref.get("focal_vector", (0.0, 0.0))]
+    for name in ("sparse_elements", "transmit_receive_orientations", "steering_angles", "focal_depths"):
+        if name in ref:
+            arr = getattr(bp, name)
+            for i, v in enumerate(ref[name]):
+                arr[i] = v.item() if hasattr(v, "item") else v
+    kind, *values = ref["emission"]
+    bp.emission_parameters.kind = 0 if kind == "sine" else 1
+    target = bp.emission_parameters.sine if kind == "sine" else bp.emission_parameters.chirp
+    for f, v in zip(("cycles", "frequency") if kind == "sine" else ("duration", "min_frequency", "max_frequency"), values):
+        setattr(target, f, float(v))
+    return bp
+
+
+def study_files():
+    """four acquisitions with RF embedded: plane waves (uncompressed and zstd), Hadamard-encoded HERCULES with
+    a chirp emission, a channel mapping and padded raw rows, virtual line sources with per-transmit
+    depth / origin (the atan2 / hypot conversion) and mixed orientations, and FORCES"""
+    rng = np.random.default_rng(77)
+    half = 47 / 2 * 0.3e-3
+    xdc = np.eye(4, dtype=np.float32)
+    xdc[3, 0] = half                                                   # world -> transducer: column-major translation
+    xdc[3, 1] = half
+    xdc = xdc.reshape(-1)
+    C_, A, S = 48, 12, 640
+    rows, row_len = 64, A * S + 40                                     # unused raw rows and row padding
+    base = dict(sampling_mode=0, dims=(row_len, rows), samples=S, channels=C_, events=A, pitch=(0.3e-3, 0.3e-3),
+                transform=xdc, speed_of_sound=1540.0, sampling_frequency=25e6, demodulation_frequency=6.25e6, time_offset=0.0)
+    mapping = rng.permutation(rows)[:C_].astype(np.int16)
+    rf = rng.integers(-3000, 3000, (rows, row_len)).astype(np.int16)
+    orient = np.array([0x12, 0x21] * (A // 2), np.uint8)
+    data = rf.tobytes()
+    files = {
+        "tpw_zstd": ozbp.write_v2(ozbp.RCA_TPW, 0, 0, emission=("sine", 2.0, 6.25e6), tilting_angles=np.linspace(-10, 10, A),
+                                  orientations=np.full(A, 0x22, np.uint8), channel_mapping=mapping,
+                                  data=ozbp.zstd_compress(data), compressed=True, **base),
+        "hercules_hadamard_chirp": ozbp.write_v2(ozbp.HERCULES, 0, 1, emission=("chirp", 4e-6, 4.25e6, 8.25e6),
+                                                 focus=(np.inf, 0.0, 0.0, 0x12), channel_mapping=mapping, data=data, **base),
+        "vls_mixed": ozbp.write_v2(ozbp.RCA_VLS, 0, 0, emission=("sine", 2.0, 6.25e6),
+                                   focal_depths=np.r_[np.linspace(-30e-3, -15e-3, A // 2), np.linspace(20e-3, 35e-3, A - A // 2)],
+                                   origin_offsets=np.linspace(-4e-3, 4e-3, A), orientations=orient, channel_mapping=mapping,
+                                   data=data, **base),
+        "forces": ozbp.write_v2(ozbp.FORCES, 0, 1, emission=("sine", 2.0, 6.25e6), channel_mapping=mapping, data=data, **base),
+    }
+    return files, rf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tpw_zstd", "hercules_hadamard_chirp", "vls_mixed", "forces"])
+def test_file_to_frame_parity(name, bflib, oracle, tmp_path):
+    """.bp (+ zstd) -> beamformer_hip_zbp_load -> the harness's study settings -> product pipeline -> frame,
+    against the oracle beamforming the SAME bytes with parameters derived by oracle/zbp.py (the restatement
+    of tests/throughput.c:151-374) and the oracle's own das_transform and filters: the two chains share
+    nothing but the file."""
+    files, rf = study_files()
+    path = tmp_path / f"{name}.bp"
+    path.write_bytes(files[name])
+    points, lateral, axial, f_number = (40, 1, 56), (-5e-3, 5e-3), (6e-3, 16e-3), 0.8
+    L = bflib.library()
+    # product chain
+    bp, data = bflib.load_zbp(str(path))
+    assert data.tobytes() == rf.tobytes()
+    fp_prod = study_parameters(bp, L.beamformer_hip_host_das_transform, points, lateral, axial, f_number)
+    L.beamformer_hip_set_das_path(0)
+    gpu = bflib.beamform(bp, data.view(np.int16).reshape(rf.shape), [fp_prod])
+    # oracle chain
+    ref_bp = simple_parameters_from_oracle(ozbp.parameters(files[name]))
+    fp_ref = study_parameters(ref_bp, oracle.library().oracle_das_transform, points, lateral, axial, f_number)
+    ref, pairs = oracle.beamform(ref_bp, rf, [fp_ref])
+    assert pairs > 0 and np.abs(ref).max() > 0
+    assert gpu.shape == ref.shape == (1, points[2], points[0]) or gpu.shape == ref.shape
+    from tests import cases
+    class _Acq:                                                       # cases.tolerance wants .bp
+        pass
+    acq = _Acq(); acq.bp = ref_bp
+    err = np.abs(gpu - ref).max() / np.abs(ref).max()
+    assert err <= cases.tolerance(acq), (name, err)

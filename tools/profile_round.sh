@@ -38,6 +38,19 @@ out["config4_in_process_two_contexts_on_one_gpu"] = {"ms_per_step": d["ms_per_st
                                                       "note": "orchestration check only: both device contexts share one GPU"}
 json.dump(out, open("gpurun_out/r02/profiles/r02_other_configs.json", "w"), indent=1)
 PY
+for c in 1 2 5; do
+  PYTHONPATH=$ROOT timeout -k 10 200 python tools/graph_probe.py --configs $c > $OUT/graph_probe_$c.json 2> $OUT/graph_probe_$c.err || echo "graph probe $c failed"
+done
+python3 - <<'PY'
+import json
+out = {}
+for c in (1, 2, 5):
+    try:
+        out.update(json.loads(open(f"gpurun_out/r02/graph_probe_{c}.json").read()))
+    except Exception as e:
+        out[f"config{c}"] = {"probe_error": str(e)[:200]}
+json.dump(out, open("gpurun_out/r02/profiles/r02_graph_probe.json", "w"), indent=1)
+PY
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o fast -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/profiles/r02_bench_under_rocprof.json 2> $OUT/rocprof.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -o cfg5 -- python3 $ROOT/bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg5_rocprof.json 2> $OUT/rocprof5.err
