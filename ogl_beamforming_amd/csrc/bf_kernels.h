@@ -49,6 +49,9 @@ typedef struct {
 	float    sampling_frequency, inv_sampling_frequency, demodulation_frequency;
 	float    inv_speed_of_sound, time_offset, f_number;
 	float    speed_of_sound;          /* with inv_speed_of_sound: div_speed_of_sound() of das_common.h */
+	float    samples_per_metre;       /* fs / c rounded ONCE (from double): the per-pair delay scale of das_hercules.hip */
+	float    phase_fix_per_metre;     /* -(fd / fs) * (samples_per_metre - fs/c): turns per metre that cancel the scale's
+	                                     rounding bias in the demodulation phase (added after the range reduction) */
 	float    turns_per_sample;        /* demodulation_frequency / sampling_frequency: IQ phase per sample, in turns */
 	float    first_transmit_weight;   /* HERCULES: 1/sqrt(acquisition_count) (das.glsl:272-273) */
 	uint32_t size[3];                 /* whole output grid */

@@ -129,7 +129,7 @@ __device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx
 /* das.glsl:126-130 */
 __device__ __forceinline__ float sample_index(float distance, const BfDasArgs &p)
 {
-	return (distance * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
+	return (div_speed_of_sound(distance, p) + p.time_offset) * p.sampling_frequency;
 }
 
 /* das.glsl:204-231 */
@@ -183,7 +183,6 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 	const float z_delta_squared  = xz * xz;
 	const float f_number_over_z  = __builtin_fabsf(p.f_number * hw_rcp(xz));
 	const float apodization_test = 0.25f / (f_number_over_z * f_number_over_z);
-	const float fs_over_c        = p.sampling_frequency * p.inv_speed_of_sound;
 	/* the axis the decoded transmit elements run along, chosen once */
 	const float tx_lateral       = rx_cols ? xy : xx;
 	const float tx_pitch         = rx_cols ? p.pitch[1] : p.pitch[0];
@@ -205,7 +204,7 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 				/* "tribal knowledge" weight of the first transmit (das.glsl:272-273): a scalar */
 				const float weight = transmit == 0 ? p.first_transmit_weight : 1.0f;
 				float apodization = weight * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
-				float index = transmit_index + hw_sqrt(z_delta_squared + element_delta_squared) * fs_over_c;
+				float index = transmit_index + div_speed_of_sound(hw_sqrt(z_delta_squared + element_delta_squared) * p.sampling_frequency, p);   /* das.glsl:277 */
 				acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 			}
 			rf_offset += S;
@@ -224,7 +223,6 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 	const float z_delta_squared     = xz * xz;
 	const float transmit_y_delta    = xy - p.pitch[1] * (float)C * 0.5f;
 	const float transmit_yz_squared = transmit_y_delta * transmit_y_delta + z_delta_squared;
-	const float fs_over_c           = p.sampling_frequency * p.inv_speed_of_sound;
 	const float f_over_z            = p.f_number * hw_rcp(xz);
 	const int   hadamard_offset     = (int)p.readi_group * (int)p.readi_group_count;
 
@@ -245,7 +243,7 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 				} else {
 					float tx_channel       = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
 					float transmit_x_delta = xx - p.pitch[0] * tx_channel;
-					float transmit_index   = hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * fs_over_c;
+					float transmit_index   = div_speed_of_sound(hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * p.sampling_frequency, p);
 					acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, receive_index + transmit_index, p));
 				}
 				rf_offset += S;
@@ -262,7 +260,7 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 					} else {
 						float tx_element       = (float)tx_group * (float)A + (float)tx_event;
 						float transmit_x_delta = xx - p.pitch[0] * tx_element;
-						float transmit_index   = hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * fs_over_c;
+						float transmit_index   = div_speed_of_sound(hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * p.sampling_frequency, p);
 						acc.add(group_apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, receive_index + transmit_index, p));
 					}
 					rf_offset += S;

@@ -716,6 +716,11 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			a.demodulation_frequency = bp.demodulation_frequency;
 			a.inv_speed_of_sound     = 1.0f / bp.speed_of_sound;
 			a.speed_of_sound         = bp.speed_of_sound;
+			{
+				const double k = (double)plan.das_sampling_frequency / (double)bp.speed_of_sound;
+				a.samples_per_metre   = (float)k;
+				a.phase_fix_per_metre = (float)(-((double)bp.demodulation_frequency / (double)plan.das_sampling_frequency) * ((double)a.samples_per_metre - k));
+			}
 			a.turns_per_sample       = bp.demodulation_frequency * a.inv_sampling_frequency;
 			a.first_transmit_weight  = 1.0f / sqrtf((float)A);
 			a.time_offset = plan.das_time_offset;

@@ -183,6 +183,48 @@ def test_hercules_aligned_kernel(name, bflib, oracle):
     compare(gpu, ref, acq, flags)
 
 
+def test_hercules_coherent_peak_at_long_delays(bflib, oracle):
+    """A point scatterer seen by a 64 x 64 HERCULES aperture at sample indices around 1400 (Float32Complex RF
+    straight into DAS): at a coherent peak a systematic error of the delay scale shows undiluted -- 1.9e-8
+    relative (the rounding of 1/c) is 1.2e-4 rad of phase, the whole 1e-4 budget.  Both HERCULES kernels
+    against the oracle at 1e-4 of the peak."""
+    from ogl_beamforming_amd import configs as cfg
+    C_, A, S, fs, fd, pitch = 64, 64, 2048, 12.5e6, 6.25e6, 0.2e-3
+    half = (C_ - 1) / 2 * pitch
+    point = np.array([0.7e-3, -0.4e-3, 80e-3])
+    acq = cfg.hercules("hercules_peak", C_, A, S, (64, 6, 5), (point[0] - 1.6e-3, point[1] - 0.3e-3, point[2] - 0.3e-3),
+                       (point[0] + 1.6e-3, point[1] + 0.3e-3, point[2] + 0.3e-3), seed=61, data_kind=P.DataKind.Float32Complex,
+                       decode=0, pitch=pitch, fs=fs, fd=fd, f_number=0.5, cw=False, noise_sigma=0.05)
+    # echo of the scatterer: plane-wave transmit (distance z), receive element (c, t) at (c pitch, t pitch) in
+    # transducer space = world + half (cfg.hercules' xdc transform); baseband: envelope x e^{-j 2 pi fd t0}
+    xs = np.arange(C_) * pitch - half
+    ys = np.arange(A) * pitch - half
+    dist = point[2] + np.sqrt(point[2] ** 2 + (point[0] - xs[:, None]) ** 2 + (point[1] - ys[None, :]) ** 2)
+    n0 = (dist / cfg.SPEED_OF_SOUND * fs).reshape(-1)
+    iq = acq.rf.reshape(C_ * A, S, 2)
+    offsets = np.arange(-24, 25)
+    idx = np.floor(n0).astype(np.int64)[:, None] + offsets[None, :]
+    env = 4.0 * np.exp(-((idx - n0[:, None]) / 10.0) ** 2)
+    phase = -2.0 * np.pi * fd * (n0 / fs)
+    rows = np.broadcast_to(np.arange(C_ * A)[:, None], idx.shape)
+    np.add.at(iq[:, :, 0], (rows, idx), (env * np.cos(phase)[:, None]).astype(np.float32))
+    np.add.at(iq[:, :, 1], (rows, idx), (env * np.sin(phase)[:, None]).astype(np.float32))
+    assert 1200 < n0.min() and n0.max() < 1700
+    ref, pairs, _ = reference(oracle, acq)
+    peak = np.abs(ref).max()
+    assert peak > 0.5 * 4.0 * C_ * A * 0.5                      # coherent: most of the 4096 taps add up
+    lib = bflib.library()
+    for mode, want_path in ((6, 5), (0x11, 0)):
+        lib.beamformer_hip_set_das_path(mode)
+        try:
+            gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+            assert last_das_path(bflib) == want_path
+        finally:
+            lib.beamformer_hip_set_das_path(0)
+        err = np.abs(gpu - ref).max() / peak
+        assert err <= 1e-4, (mode, err)
+
+
 FACTORED = sorted(n for n in cases.CASES if factored_applies(cases.make(n).bp))
 
 
