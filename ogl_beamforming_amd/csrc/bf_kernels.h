@@ -49,9 +49,6 @@ typedef struct {
 	float    sampling_frequency, inv_sampling_frequency, demodulation_frequency;
 	float    inv_speed_of_sound, time_offset, f_number;
 	float    speed_of_sound;          /* with inv_speed_of_sound: div_speed_of_sound() of das_common.h */
-	float    samples_per_metre;       /* fs / c rounded ONCE (from double): the per-pair delay scale of das_hercules.hip */
-	float    phase_fix_per_metre;     /* -(fd / fs) * (samples_per_metre - fs/c): turns per metre that cancel the scale's
-	                                     rounding bias in the demodulation phase (added after the range reduction) */
 	float    turns_per_sample;        /* demodulation_frequency / sampling_frequency: IQ phase per sample, in turns */
 	float    first_transmit_weight;   /* HERCULES: 1/sqrt(acquisition_count) (das.glsl:272-273) */
 	uint32_t size[3];                 /* whole output grid */
@@ -92,6 +89,12 @@ typedef struct {
 	uint32_t tiles[3];        /* 64-voxel x segments, groups of 4 output rows, z planes of the shard */
 	uint32_t depth_major;     /* tile walk: 1 = z fastest, 0 = x, y, z */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes behind the DAS input */
+	/* The kernel measures squared distances in units of unit_scale2 (a float within 1e-3 of 1) and converts a
+	 * distance to samples with samples_per_unit: the host picks the pair so that samples_per_unit x
+	 * sqrt(unit_scale2) equals fs / c to ~1e-11 (plan_hercules), because the rounding of a single fs/c constant
+	 * would be a relative bias common to every tap -- 2e-8, i.e. up to 1e-4 rad of demodulation phase on a
+	 * coherent peak -- and a per-pair division costs 9 % of the kernel. */
+	float    unit_scale2, samples_per_unit;
 } BfHerculesArgs;
 
 typedef struct {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
 		uint32_t m = n < q.inner_count ? n : q.inner_count - 1;
 		float element = (q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
 		float delta = lateral - element * pitch;
-		float d2 = delta * delta;
+		float d2 = delta * delta * q.unit_scale2;
 		q.table[(size_t)y * q.table_pitch + n] = d2;
 		lo = fminf(lo, d2); hi = fmaxf(hi, d2);
 	}
@@ -160,16 +160,15 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 
 	const int S = p.sample_count, A = p.acquisition_count;
 	const BfTransmit t0 = p.transmits[0];
-	/* per pair the delay is distance x (fs / c rounded once); the rounding of that one constant is a relative
-	 * bias common to every tap, which would tilt the demodulation phase of a coherent sum by up to 2e-4 rad:
-	 * phase_fix_per_metre x distance, added to the phase after its range reduction, cancels it (one packed
-	 * fma per two pairs).  The per-voxel transmit term divides by c (div_speed_of_sound). */
-	const float fs_over_c = p.samples_per_metre;
+	/* squared distances are held in the host-chosen unit (BfHerculesArgs::unit_scale2) in which the
+	 * distance -> samples factor is free of rounding bias; the per-voxel transmit term divides by c */
+	const float s2        = q.unit_scale2;
+	const float fs_over_c = q.samples_per_unit;
 	const float T0  = (div_speed_of_sound(transmit_distance(t0, wx, wy, wz), p) + p.time_offset) * p.sampling_frequency;
-	const float z2  = xz * xz;
+	const float z2  = xz * xz * s2;
 	const float f_number_over_z  = __builtin_fabsf(p.f_number * hw_rcp(xz));
-	const float apodization_test = 0.25f / (f_number_over_z * f_number_over_z);
-	const float w_scale = (3.14159265358979f * f_number_over_z) * (3.14159265358979f * f_number_over_z);
+	const float apodization_test = 0.25f / (f_number_over_z * f_number_over_z) * s2;
+	const float w_scale = (3.14159265358979f * f_number_over_z) * (3.14159265358979f * f_number_over_z) * hw_rcp(s2);
 	const float turns_per_sample = p.turns_per_sample;
 
 	const float outer_lateral = q.inner_coord ? xx : xy;           /* the other coordinate */
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	for (int m = 0; m < n_outer; m++) {
 		float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
 		float od  = outer_lateral - outer_element * outer_pitch;
-		float od2 = od * od;
+		float od2 = od * od * s2;
 		/* wave-level decisions for this outer element from the table row's extremes */
 		const bool  lane_none = !(od2 + d2_min < apodization_test);
 		if (__builtin_amdgcn_ballot_w64(!lane_none) == 0) continue;             /* nobody passes anything */
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		float accr = 0.f, mag = 0.f;
 		const f32x2 od2p = splat(od2), z2p = splat(z2), T0p = splat(T0), kp = splat(fs_over_c),
 		            wsp = splat(w_scale), tpsp = splat(turns_per_sample),
-		            oz2p = splat(od2 + z2), wodp = splat(w_scale * od2), fixp = splat(p.phase_fix_per_metre);
+		            oz2p = splat(od2 + z2), wodp = splat(w_scale * od2);
 
 		/* B = 1 or BF_HERC_BATCH elements starting at inner element n; d2in = their table entries */
 		auto group = [&](auto checked_c, auto count_c, int n, const float *d2in, float first_weight) {
@@ -282,13 +281,6 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			TapData<INTERP, CPLX> d[B];
 			#pragma unroll
 			for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, off[k]);
-			/* demodulation phase in turns: range-reduced index x fd/fs, then the scale's bias correction */
-			[[maybe_unused]] f32x2 phase[P];
-			if constexpr (CPLX) {
-				#pragma unroll
-				for (int k = 0; k < P; k++)
-					phase[k] = dist[k] * fixp + f32x2{hw_fract(turns[k].x), hw_fract(turns[k].y)};
-			}
 			#pragma unroll
 			for (int k = 0; k < B; k++) {
 				VT sv;
@@ -299,7 +291,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					sv = tap_finish<INTERP, CPLX>(tap[k], d[k]);
 				}
 				if constexpr (CPLX) {
-					float tr = (k & 1) ? phase[k >> 1].y : phase[k >> 1].x;
+					float tr = hw_fract((k & 1) ? turns[k >> 1].y : turns[k >> 1].x);
 					f32x2 cs = f32x2{hw_cos_turns(tr), hw_sin_turns(tr)} * ap[k];
 					acc1 += sv.x * cs;
 					acc2 += sv.y * cs;

@@ -537,6 +537,26 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 	q.tiles[2] = zcount;
 	const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z (measurement aid) */
 	q.depth_major = !(walk && walk[0] == 'p');
+	/* unit of length: among the 8193 floats nearest 1, the s2 whose k' = float(k / sqrt(s2)) reproduces
+	 * k = fs / c best as k' sqrt(s2) (errors are spread over +-3e-8, the best of 8193 lands near 1e-11).
+	 * Remembered per (fs, c): frames of one plan ask again every launch. */
+	{
+		static float cached_fs = 0.f, cached_c = 0.f, cached_s2 = 1.f, cached_k = 0.f;
+		if (cached_fs != a.sampling_frequency || cached_c != a.speed_of_sound) {
+			const double k_exact = (double)a.sampling_frequency / (double)a.speed_of_sound;
+			double best = 1e9;
+			for (int i = -4096; i <= 4096; i++) {
+				uint32_t bits = 0x3F800000u + (uint32_t)i;              /* floats around 1.0f in ulp steps */
+				float s2; std::memcpy(&s2, &bits, sizeof s2);
+				double s  = std::sqrt((double)s2);
+				float  kk = (float)(k_exact / s);
+				double err = std::fabs((double)kk * s / k_exact - 1.0);
+				if (err < best) { best = err; cached_s2 = s2; cached_k = kk; }
+			}
+			cached_fs = a.sampling_frequency; cached_c = a.speed_of_sound;
+		}
+		q.unit_scale2 = cached_s2; q.samples_per_unit = cached_k;
+	}
 	return true;
 }
 
@@ -716,11 +736,6 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 			a.demodulation_frequency = bp.demodulation_frequency;
 			a.inv_speed_of_sound     = 1.0f / bp.speed_of_sound;
 			a.speed_of_sound         = bp.speed_of_sound;
-			{
-				const double k = (double)plan.das_sampling_frequency / (double)bp.speed_of_sound;
-				a.samples_per_metre   = (float)k;
-				a.phase_fix_per_metre = (float)(-((double)bp.demodulation_frequency / (double)plan.das_sampling_frequency) * ((double)a.samples_per_metre - k));
-			}
 			a.turns_per_sample       = bp.demodulation_frequency * a.inv_sampling_frequency;
 			a.first_transmit_weight  = 1.0f / sqrtf((float)A);
 			a.time_offset = plan.das_time_offset;

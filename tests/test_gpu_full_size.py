@@ -146,7 +146,11 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 0
     assert np.array_equal(np.isnan(general), np.isnan(frame))
     both = ~np.isnan(frame)
-    assert np.abs(general[both] - frame[both]).max() / np.abs(frame[both]).max() < 1e-4
+    # Config 2 carries a scatterer and band-limited (demodulated) data: 1e-4.  Configs 3 and 5 are white noise
+    # straight out of the Hadamard decode: two kernels whose sample index differs by one ulp (1.2e-4 samples at
+    # index 1500) interpolate sample-to-sample jumps of ~1.4 sigma differently, and the extreme over 1.7e7
+    # incoherent sums reaches ~1.3e-4 of the frame's maximum; each kernel is held to the oracle above.
+    assert np.abs(general[both] - frame[both]).max() / np.abs(frame[both]).max() < (1e-4 if n == 2 else 3e-4)
 
 
 @pytest.mark.parametrize("interp, cw, points", [(P.InterpolationMode.Linear, True, (300, 201, 37)),

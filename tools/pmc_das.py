@@ -30,9 +30,9 @@ GROUPS = [
      "SQ_WAIT_ANY", "SQ_INST_CYCLES_VMEM_RD", "SQ_THREAD_CYCLES_VALU"],
     ["SQ_INSTS_SMEM", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_CVT",
      "SQ_INSTS_VALU_INT32", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
-    ["TA_BUSY_avr", "TA_TA_BUSY_sum"],
+    ["TA_BUSY_avr", "TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE"],
     ["TA_FLAT_READ_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum"],
-    ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TA_TCP_STATE_READ_sum"],
+    ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_ACCESSES_sum", "TCP_TA_TCP_STATE_READ_sum", "GRBM_GUI_ACTIVE"],
     ["TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum",
      "TCP_GATE_EN1_sum"],
     ["FETCH_SIZE"],
@@ -90,13 +90,17 @@ def main():
             failed.append({"group": group, "why": r.stderr.decode(errors="replace")[-400:]})
             continue
         seen = {}
+        already = set(counters)          # a counter that rides along in several groups (GRBM_GUI_ACTIVE) is taken from the first
         for f in files:
             for row in csv.DictReader(open(f)):
                 name = row["Kernel_Name"]
                 if args.kernel not in name or COUNT_KERNEL.search(name):
                     continue
-                kernel_names.add(name.split("(")[0][:120])
+                m = re.search(r"(das_\w+)(<[^>]*>)?", name)          # "void (anonymous namespace)::das_factored_kernel<0, 2, true, false>(BfDasArgs)"
+                kernel_names.add((m.group(1) + (m.group(2) or "")) if m else name[:120])
                 key = row["Counter_Name"]
+                if key in already:
+                    continue
                 counters[key] = counters.get(key, 0.0) + float(row["Counter_Value"])
                 seen.setdefault(key, set()).add(row["Dispatch_Id"])
         if seen:

@@ -40,7 +40,7 @@ def main():
         m = re.search(r"--config (\d+)", s["command"])
         config = int(m.group(1)) if m else 4
         planes = re.search(r"--planes (\d+)", s["command"])
-        kernel = re.sub(r"^void ", "", s["kernels"][0]).split("<")[0] if s["kernels"] else "?"
+        kernel = s["kernels"][0].split("<")[0] if s["kernels"] else "?"
         n = s["dispatches_summed"] or 1
         key = f"config{config}"
         if "GRBM_GUI_ACTIVE" in c:
