@@ -100,7 +100,7 @@ typedef struct {
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
 	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel,
-	                              4 factored kernel with LDS row cache, 5 HERCULES aligned-grid kernel */
+	                              4 (retired), 5 HERCULES aligned-grid kernel */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
@@ -149,8 +149,7 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
  * geometry allows and the interpolation is linear, else the per-voxel factored kernel for
  * RCA-family and FORCES frames with three or more transmits, else the gather kernel where the
  * geometry allows, else the general kernel), 1 = always the general kernel, 4 = the
- * factored kernel wherever it applies (also ahead of the gather kernel), 5 = the LDS row-cache
- * variant of the factored kernel where it applies (experiment, measured slower), 3 = prefer the
+ * factored kernel wherever it applies (also ahead of the gather kernel), 3 = prefer the
  * LDS-staged variant of the separable kernel where its window bound holds (measured slower
  * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
  * HERCULES-family frames whose grid is aligned with the array (one lateral transducer coordinate a

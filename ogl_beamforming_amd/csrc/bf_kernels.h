@@ -153,7 +153,6 @@ hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hi
  * 2*1024 floats */
 hipError_t bf_launch_das_factored(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_hercules(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s);
-hipError_t bf_launch_das_rowcache(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_sum(void *out, const void *in, float prescale, uint64_t bytes, hipStream_t s);
 hipError_t bf_launch_display(const void *frame, uint64_t voxels, int complex_data, float threshold_db,
                              float gamma, float db_cutoff, float *out, hipStream_t s);

@@ -568,7 +568,7 @@ static bool factored_applies(const BfDasArgs &a, const std::vector<BfTransmit> &
 {
 	if (mode == 1) return false;
 	int transmits = a.acquisition_count - (a.family == BF_DAS_FORCES && a.sparse ? 1 : 0);
-	if (transmits < 3 && mode != 4 && mode != 5) return false;
+	if (transmits < 3 && mode != 4) return false;
 	if (a.family == BF_DAS_FORCES) return true;
 	if (a.family != BF_DAS_RCA || tx.empty()) return false;
 	for (const BfTransmit &t : tx)
@@ -772,7 +772,7 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 				const uint32_t das_mode = c.das_path_mode & 0xF;
 				const bool tables_first = a.interpolation == 1 || das_mode == 3 ||
 				                          !factored_applies(a, ps->transmit_table, das_mode);
-				if (das_mode != 1 && das_mode != 4 && das_mode != 5 && tables_first &&
+				if (das_mode != 1 && das_mode != 4 && tables_first &&
 				    plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
 					 * allocated with that much slack): the gather target of out-of-range lanes */
@@ -800,19 +800,8 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					a.zero_offset = (uint32_t)used;             /* as for the gather kernel above */
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					/* the LDS row-cache variant (das_rowcache.hip): RCA-family IQ frames, linear or cubic,
-					 * whole 256-voxel tiles.  Opt-in only (mode 5): correct, but measured slower than the
-					 * gather form it is meant to beat */
-					const bool rowcache_fits = a.family == BF_DAS_RCA && a.complex_data && !a.split_shift &&
-					                           (a.interpolation == 1 || a.interpolation == 2);
-					const uint32_t mode = c.das_path_mode & 0xF;
-					if (rowcache_fits && mode == 5) {
-						ok &= HIP_OK(bf_launch_das_rowcache(&a, s));
-						das_path = 4;
-					} else {
-						ok &= HIP_OK(bf_launch_das_factored(&a, s));
-						das_path = 3;
-					}
+					ok &= HIP_OK(bf_launch_das_factored(&a, s));
+					das_path = 3;
 				} else {
 					ok &= HIP_OK(bf_launch_das(&a, s));
 				}

@@ -246,32 +246,6 @@ def test_factored_kernel(name, split, bflib, oracle):
     compare(gpu, ref, acq, flags)
 
 
-def rowcache_applies(bp):
-    stages = list(bp.compute_stages[: bp.compute_stages_count])
-    complex_in = int(P.ShaderKind.Demodulate) in stages or P.DATA_KIND_COMPLEX[int(bp.data_kind)]
-    return (factored_applies(bp) and P.AcquisitionKind(bp.acquisition_kind) in (P.AcquisitionKind.RCA_TPW, P.AcquisitionKind.RCA_VLS, P.AcquisitionKind.Flash)
-            and complex_in and bp.interpolation_mode in (int(P.InterpolationMode.Linear), int(P.InterpolationMode.Cubic)))
-
-
-ROWCACHE = sorted(n for n in cases.CASES if rowcache_applies(cases.make(n).bp))
-
-
-@pytest.mark.parametrize("name", ROWCACHE)
-def test_rowcache_kernel(name, bflib, oracle):
-    """das_rowcache.hip (opt-in experiment: the factored kernel with the RF row segments of a block
-    cached in LDS), forced with mode 0x15 (whole 256-voxel tiles, no channel split)"""
-    acq = cases.make(name)
-    ref, pairs, flags = reference(oracle, acq)
-    lib = bflib.library()
-    lib.beamformer_hip_set_das_path(0x15)
-    try:
-        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-        assert last_das_path(bflib) == 4
-    finally:
-        lib.beamformer_hip_set_das_path(0)
-    compare(gpu, ref, acq, flags)
-
-
 DECODING = sorted(n for n in cases.CASES
                   if cases.make(n).bp.decode_mode and int(P.ShaderKind.Decode) in list(cases.make(n).bp.compute_stages[:cases.make(n).bp.compute_stages_count]))
 
