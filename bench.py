@@ -410,6 +410,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s):
             "peak": peak / 1e9,
             "peak_model": f"{best['bytes_per_clk_per_cu_wall']:.1f} B/clk/CU (measured, L1-resident window, DAS-like addresses, {best['waves_per_simd']} waves/SIMD) x {cus} CUs x {best['clock_ghz']:.3f} GHz (clock sustained in that probe)",
             "frac": gather_bytes / das_s / peak,
+            "peak_bytes_per_clk_per_cu": best["bytes_per_clk_per_cu_wall"], "probe_clock_ghz": best["clock_ghz"],
             "source": "profiles/r02_microbench.json (tools/microbench.hip); achieved measured in this run",
         }
     except (OSError, KeyError, ValueError):
@@ -420,6 +421,13 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s):
         entry = bound[f"config{config}"][kernel]
         out["valu_busy_frac"] = entry["valu_busy_frac"]
         out["ta_busy_frac"] = entry.get("ta_busy_frac")
+        # The chip lowers its clock under this kernel (the probe's loop sustains more): cycles the launch was
+        # resident (GRBM_GUI_ACTIVE / 8 of the committed whole-frame PMC pass) over this run's kernel time
+        # estimate the clock it actually held; against the ceiling at THAT clock the kernel sits higher.
+        if entry.get("planes") == "whole frame" and "peak" in out and out.get("frac"):
+            clock = entry["kernel_cycles_per_launch"] / das_s / 1e9
+            out["sustained_clock_ghz_est"] = clock
+            out["frac_at_sustained_clock"] = out["frac"] * out["probe_clock_ghz"] / clock
         out["valu_source"] = (f"profiles/r02_das_bound.json: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
                               f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash() else " (STALE: sources changed since)"))
         if entry["valu_busy_frac"] > out.get("frac", 0):
