@@ -9,10 +9,11 @@
  * through the C ABI only.
  *
  *   ogl_beamformer_throughput [--loop] [--frame n] [--frames N] [--points x y z]
- *                             [--lateral lo hi] [--axial lo hi] [--f-number f] file.bp
+ *                             [--lateral lo hi] [--axial lo hi] [--f-number f] [--devices a,b,...] file.bp
  *
  * --frames N (default 100) bounds the run; --loop keeps going until SIGINT as the
- * reference's does.
+ * reference's does; --devices spreads every frame over several GPUs (beamformer_hip_set_devices:
+ * z-slabs of the grid, stitched on pull) with no other change to the calling sequence.
  */
 #include "../../include/ogl_beamformer_hip.h"
 
@@ -34,10 +35,11 @@ static int usage(const char *argv0)
 {
 	std::fprintf(stderr,
 	             "usage: %s [--loop] [--frame n] [--frames N] [--points x y z] [--lateral lo hi] [--axial lo hi]\n"
-	             "          [--f-number f] parameters_file.bp\n"
+	             "          [--f-number f] [--devices a,b,...] parameters_file.bp\n"
 	             "    --loop:     re-upload the data until interrupted\n"
 	             "    --frame n:  use frame n of the acquisition (side files <name>_NN.zst)\n"
-	             "    --frames N: number of frames to beamform (default 100)\n", argv0);
+	             "    --frames N: number of frames to beamform (default 100)\n"
+	             "    --devices a,b,...: HIP ordinals to spread each frame over (default: one device)\n", argv0);
 	return 2;
 }
 
@@ -61,6 +63,14 @@ int main(int argc, char **argv)
 		else if (!std::strcmp(a, "--lateral") && i + 2 < argc) { lateral[0] = (float)std::atof(argv[++i]); lateral[1] = (float)std::atof(argv[++i]); }
 		else if (!std::strcmp(a, "--axial") && i + 2 < argc) { axial[0] = (float)std::atof(argv[++i]); axial[1] = (float)std::atof(argv[++i]); }
 		else if (!std::strcmp(a, "--f-number") && i + 1 < argc) f_number = (float)std::atof(argv[++i]);
+		else if (!std::strcmp(a, "--devices") && i + 1 < argc) {
+			int32_t  ids[8]; uint32_t n = 0;
+			for (const char *c = argv[++i]; *c && n < 8; ) {
+				ids[n++] = (int32_t)std::strtol(c, const_cast<char **>(&c), 10);
+				if (*c == ',') c++;
+			}
+			if (!n || !beamformer_hip_set_devices(ids, n)) { std::fprintf(stderr, "bad --devices list\n"); return 2; }
+		}
 		else if (a[0] == '-') return usage(argv[0]);
 		else path = a;
 	}

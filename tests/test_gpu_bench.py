@@ -49,3 +49,16 @@ def test_two_ranks_rehearsed_on_one_gpu(extra):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["slab_verified"] is True
     assert ("overlaps" in d["config"]["sharding"]) == (not extra)
     assert d["roofline"]["pairs_total"] >= d["roofline"]["pairs_per_launch"] > 0
+
+
+def test_in_process_two_device_contexts():
+    """bench.py --in-process: the library's own multi-device mode (beamformer_hip_set_devices), here with the
+    same ordinal twice -- the JSON line, per-device DAS times, pairs summed over devices"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--in-process", "--devices", "0,0", "--scale", "0.125",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and "beamformer_hip_set_devices" in d["config"]["sharding"]
+    assert len(d["config"]["device_das_ms"]) == 2 and all(v > 0 for v in d["config"]["device_das_ms"])
+    assert d["roofline"]["pairs_total"] > d["roofline"]["pairs_per_launch"] > 0
+    assert abs(d["value"] - 64 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

@@ -220,11 +220,13 @@ def test_throughput_tool_usage():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("compressed", [False, True])
-def test_throughput_tool_beamforms_a_file(compressed, tmp_path):
+@pytest.mark.parametrize("compressed, devices", [(False, None), (True, None), (False, "0,0")])
+def test_throughput_tool_beamforms_a_file(compressed, devices, tmp_path):
+    """the reference's harness for this backend, also spread over two device contexts (--devices)"""
     acq, rf, path = acquisition_file(tmp_path, compressed)
     r = subprocess.run([TOOL, "--frames", "20", "--points", "64", "1", "96", "--lateral", "-0.005", "0.005",
-                        "--axial", "0.004", "0.012", path], capture_output=True, text=True, timeout=300)
+                        "--axial", "0.004", "0.012", *(["--devices", devices] if devices else []), path],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("total: 20 frames"), r.stdout
