@@ -453,10 +453,15 @@ def cpu_baseline(acq, budget_s):
     per_voxel_pairs = bp.channel_count * bp.acquisition_count
 
     def sample(threads, seconds):
-        # ~1.2e7 pairs/s/core for the scalar port (less per core when hyperthreads share cores); size the sample for the budget
-        target_voxels = max(X, int(seconds * 1.0e7 * min(threads, 64) / per_voxel_pairs))
+        # ~1.2e7 pairs/s per thread for the scalar port (hyperthreads share cores: 0.6e7 assumed past 64 threads);
+        # the sample is sized for the budget and so that every thread gets several rows (a row is the oracle's
+        # unit of parallel work: X voxels x one 16-channel pass)
+        rate = 1.2e7 * min(threads, 64) + 0.6e7 * max(0, threads - 64)
+        target_voxels = max(X, int(seconds * rate / per_voxel_pairs))
         planes = max(1, min(Z, 8, target_voxels // X))
         rows = max(1, min(Y, target_voxels // (X * planes)))
+        if rows * planes < 2 * threads:                       # fewer rows than threads would idle most of them
+            rows = max(1, min(Y, -(-2 * threads // planes)))
         z_stride = max(1, Z // planes)
         y_stride = max(1, Y // rows)
         timing = {}

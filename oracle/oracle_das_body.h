@@ -310,7 +310,7 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 	uint64_t pairs = 0;
 	int64_t  rows  = (int64_t)zn * yn;
 
-	#pragma omp parallel for schedule(dynamic, 4) reduction(+:pairs) num_threads(oracle_thread_count(p->threads))
+	#pragma omp parallel for schedule(dynamic, 1) reduction(+:pairs) num_threads(oracle_thread_count(p->threads))
 	for (int64_t row = 0; row < rows; row++) {
 		uint32_t zl = (uint32_t)(row / yn), yl = (uint32_t)(row % yn);
 		uint32_t z = z0 + zl * (p->z_stride ? p->z_stride : 1u), y = y0 + yl * (p->y_stride ? p->y_stride : 1u);

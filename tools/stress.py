@@ -1,7 +1,7 @@
 """Soak test on a GPU box: 30 000 small frames through both push entry points, alternating two
 parameter blocks and occasionally re-pushing parameters (replans), with periodic bit-exact
 checks of the exported frame and a watch on host RSS and device memory.
-    PYTHONPATH=. python tools/stress.py"""
+    PYTHONPATH=. python tools/stress.py [frames [device,device,...]]"""
 import ctypes as C, os, sys, time
 import numpy as np, torch
 from ogl_beamforming_amd import configs, lib, params as P
@@ -12,6 +12,9 @@ def rss_mb():
 
 torch.cuda.set_device(0)
 L = lib.library()
+if len(sys.argv) > 2:            # stress.py N 0,0,0 : the same soak through the multi-device mode
+    ids = [int(v) for v in sys.argv[2].split(",")]
+    assert L.beamformer_hip_set_devices((C.c_int32 * len(ids))(*ids), len(ids))
 L.beamformer_set_global_timeout(0xFFFFFFFF)
 assert L.beamformer_reserve_parameter_blocks(2)
 acqs = [configs.config(1, 0.5), configs.config(2, 0.0625)]
