@@ -475,13 +475,16 @@ def cpu_baseline(acq, budget_s):
                            f"of the {X}x{Y}x{Z} frame, {pairs} pairs in {das_s:.2f} s DAS time ({wall:.2f} s incl. the single-threaded pre-DAS stages over the whole RF)")}
 
     share = min(affinity, int(os.environ.get("BENCH_CPU_THREADS", "16")))
-    legs = {"all_cores": sample(affinity, 0.35 * budget_s)}
-    legs["box_share"] = sample(share, 0.35 * budget_s) if share != affinity else legs["all_cores"]
-    legs["one_thread"] = sample(1, 0.30 * budget_s) if affinity > 1 else legs["all_cores"]
-    head = legs["all_cores"]
+    counts = sorted({affinity, max(1, affinity // 2), share, 1}, reverse=True)
+    weight = {n: (0.3 if n > share else 0.25 if n > 1 else 0.2) for n in counts}
+    total = sum(weight.values())
+    legs = {n: sample(n, budget_s * weight[n] / total) for n in counts}
+    best = max(legs.values(), key=lambda leg: leg["value"])
+    # the headline figure is the fastest leg (the scalar port stops scaling well before 256 logical CPUs: its
+    # 16-channel passes are short parallel regions over a shared 20 MB RF chunk); every leg is listed
     return {
-        "value": head["value"], "unit": "voxels/s", "cores": head["cores"], "kind": "port", "sample": head["sample"],
-        "box_share": legs["box_share"], "one_thread": legs["one_thread"],
+        "value": best["value"], "unit": "voxels/s", "cores": best["cores"], "kind": "port", "sample": best["sample"],
+        "all_cores": legs[affinity], "half_of_them": legs[max(1, affinity // 2)], "box_share": legs[share], "one_thread": legs[1],
         "nproc": os.cpu_count(), "affinity": affinity,
     }
 
