@@ -139,8 +139,9 @@ __global__ __launch_bounds__(1024) void gather_probe(const char *base, uint32_t 
 }
 
 /* ------------------------------------------------------------------ LDS reads */
-enum { LDS_B64, LDS_B128, LDS_READ2_B64, LDS_B32, LDS_COUNT };
-static const char *lds_name[LDS_COUNT] = {"ds_read_b64", "ds_read_b128", "ds_read2_b64(16B@8)", "ds_read_b32"};
+enum { LDS_B64, LDS_B128, LDS_READ2_B64, LDS_B32, LDS_BPERMUTE, LDS_COUNT };
+static const char *lds_name[LDS_COUNT] = {"ds_read_b64", "ds_read_b128", "ds_read2_b64(16B@8)", "ds_read_b32",
+                                          "ds_bpermute_b32 (lane crossbar, no LDS memory)"};
 
 template <int KIND, int PAT>
 __global__ __launch_bounds__(1024) void lds_probe(Stamp *stamps, float *sink, int iters, uint32_t window_bytes)
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(1024) void lds_probe(Stamp *stamps, float *sink, in
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t mask = window_bytes / 2u - 1u;
-	constexpr uint32_t WIDTH = KIND == LDS_B64 ? 8 : (KIND == LDS_B32 ? 4 : 16);
-	const uint32_t align = KIND == LDS_B128 ? 16u : (KIND == LDS_B32 ? 4u : 8u);
+	constexpr uint32_t WIDTH = KIND == LDS_B64 ? 8 : ((KIND == LDS_B32 || KIND == LDS_BPERMUTE) ? 4 : 16);
+	const uint32_t align = KIND == LDS_B128 ? 16u : ((KIND == LDS_B32 || KIND == LDS_BPERMUTE) ? 4u : 8u);
 	f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 	uint64_t t0 = memtime(), r0 = memrealtime();
 	for (int i = 0; i < iters; i++) {
@@ -178,6 +179,12 @@ __global__ __launch_bounds__(1024) void lds_probe(Stamp *stamps, float *sink, in
 			asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
 			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]) : "memory");
 			acc.x += d0.x + d1.x + d2.x + d3.x; acc.y += d0.y + d1.y + d2.y + d3.y;
+		} else if constexpr (KIND == LDS_BPERMUTE) {
+			/* each lane pulls a dword from the lane named by its byte address / 4 (mod 64) */
+			float d0, d1, d2, d3, src = acc.y + (float)lane;
+			asm volatile("ds_bpermute_b32 %0, %4, %8\n\tds_bpermute_b32 %1, %5, %8\n\tds_bpermute_b32 %2, %6, %8\n\tds_bpermute_b32 %3, %7, %8\n\ts_waitcnt lgkmcnt(0)"
+			             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(src) : "memory");
+			acc.x += d0 + d1 + d2 + d3;
 		} else {
 			float d0, d1, d2, d3;
 			asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
@@ -271,7 +278,7 @@ template <int KIND, int PAT> static void lds_case(bool &first)
 {
 	const int iters = 4000;
 	const uint32_t window = 32768;
-	constexpr int WIDTH = KIND == LDS_B64 ? 8 : (KIND == LDS_B32 ? 4 : 16);
+	constexpr int WIDTH = KIND == LDS_B64 ? 8 : ((KIND == LDS_B32 || KIND == LDS_BPERMUTE) ? 4 : 16);
 	for (int wps : {1, 2, 4, 8}) {
 		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
 		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
@@ -349,6 +356,8 @@ int main(int argc, char **argv)
 	lds_case<LDS_B64, PAT_RANDOM>(first);
 	lds_case<LDS_B32, PAT_DAS>(first);
 	lds_case<LDS_B32, PAT_RANDOM>(first);
+	lds_case<LDS_BPERMUTE, PAT_DAS>(first);
+	lds_case<LDS_BPERMUTE, PAT_RANDOM>(first);
 	emit("]}\n");
 	fputs(json.c_str(), stdout);
 	return 0;
