@@ -139,6 +139,7 @@ struct Server {
 	uint64_t   rf_ring_bytes = 0, rf_active_size = 0;
 	uint64_t   insertion_index = 0, compute_index = 0;
 	uint32_t   rf_block = 0;
+	bool       multi_device = false;                             /* --devices: frames spread over several GPUs */
 
 	ShmBlock *block(uint32_t i) { return reinterpret_cast<ShmBlock *>(reinterpret_cast<uint8_t *>(sm + 1) + (size_t)i * sizeof(ShmBlock)); }
 	/* beamformer_shared_memory_data_pointer (beamformer_shared_memory.c:280-297): the client
@@ -225,6 +226,7 @@ void handle_upload(Server &s, uint64_t rf_block_rf_size)
 	/* the slot about to be overwritten was read in place by the frame three uploads ago, which the
 	 * library runs asynchronously: wait for exactly that frame */
 	if (s.read_pending[slot]) { (void)hipEventSynchronize(s.read_done[slot]); s.read_pending[slot] = false; }
+	if (s.multi_device) beamformer_hip_synchronize();       /* no per-slot events without a stream of ours */
 	if (ok) ok = hipMemcpy(s.rf_ring[slot], s.payload(), size, hipMemcpyHostToDevice) == hipSuccess;
 	s.rf_active_size = size;
 	s.rf_block = block;
@@ -302,11 +304,22 @@ int main(int argc, char **argv)
 	const char *name = "/ogl_beamformer_shared_memory";          /* base_linux.c:5 */
 	uint64_t size = 2ull << 30;                                    /* main_linux.c:19 */
 	long once = -1;
+	bool multi_device = false;
 	for (int i = 1; i < argc; i++) {
 		if (!std::strcmp(argv[i], "--name") && i + 1 < argc) name = argv[++i];
 		else if (!std::strcmp(argv[i], "--size") && i + 1 < argc) size = std::strtoull(argv[++i], nullptr, 0);
 		else if (!std::strcmp(argv[i], "--once") && i + 1 < argc) once = std::strtol(argv[++i], nullptr, 0);
-		else { std::fprintf(stderr, "usage: %s [--name /shm] [--size bytes] [--once work_items]\n", argv[0]); return 2; }
+		else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {
+			/* every frame spread over several GPUs, invisible to the client (beamformer_hip_set_devices) */
+			int32_t ids[8]; uint32_t n = 0;
+			for (const char *c = argv[++i]; *c && n < 8; ) {
+				ids[n++] = (int32_t)std::strtol(c, const_cast<char **>(&c), 10);
+				if (*c == ',') c++;
+			}
+			if (!n || !beamformer_hip_set_devices(ids, n)) { std::fprintf(stderr, "bad --devices list\n"); return 2; }
+			multi_device = n > 1;
+		}
+		else { std::fprintf(stderr, "usage: %s [--name /shm] [--size bytes] [--once work_items] [--devices a,b,...]\n", argv[0]); return 2; }
 	}
 	std::signal(SIGINT, on_signal);
 	std::signal(SIGTERM, on_signal);
@@ -324,7 +337,12 @@ int main(int argc, char **argv)
 	s.size = size;
 	/* run the library on a stream of ours so that per-slot completion events can be recorded behind
 	 * its frames (no device: the calls fail and every compute request is answered with an error) */
-	if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess) {
+	s.multi_device = multi_device;
+	if (multi_device) {
+		/* a stream belongs to one device: the library keeps its own streams, and an RF slot is reused only
+		 * after beamformer_hip_synchronize (handle_upload) */
+		s.stream = nullptr;
+	} else if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess) {
 		beamformer_hip_set_stream(s.stream);
 		for (auto &e : s.read_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
 	} else {
