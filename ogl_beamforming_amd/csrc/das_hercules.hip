@@ -7,8 +7,9 @@
  *     index = T0(voxel) + sqrt(z^2 + e^2) fs / c          pass: e^2 < 0.25 / (F# / z)^2
  *     out  += w_t cos^2(pi F#/z sqrt(e^2)) * rotate_iq(interpolate(rf[c][t], index), index).
  *
- * The general kernel is VALU bound at ~44 issue slots per pair (tools/microbench.hip: a wave64
- * VALU instruction holds its SIMD for 4 clocks, a transcendental for twice that).  This kernel
+ * The general kernel is VALU bound at ~130 VALU clocks per pair (tools/microbench.hip: a wave64 f32
+ * instruction holds its SIMD for 2.5 clocks, a packed one 4.3, v_fract / v_cvt 4.1, a transcendental
+ * 8.15; the texture-address path takes 16.3 clocks per CU for the pair's one gather).  This kernel
  * applies when the volume's lateral axes are aligned with the array's (exact-zero matrix
  * coefficients, host check plan_hercules): the 64 lanes of a wave lie along the output's x axis and
  * share y and z, so one of the two lateral terms of e^2 is per lane and constant over the inner
@@ -21,7 +22,9 @@
  *     floor / fraction / address, ONE 16-byte gather, the interpolation as two packed ops;
  *     v_fract + v_sin + v_cos of the demodulation phase, the phasor scaled by the apodization in
  *       one packed multiply, two packed FMAs of rotate-accumulate;
- *     |sample| for coherency weighting (packed square, add, v_sqrt, fma).
+ *     |sample| for coherency weighting (multiply, fma, v_sqrt, fma).
+ * That is ~95 VALU clocks per pair, four of its instructions transcendental (the distance and |sample|
+ * square roots, sin, cos): the kernel runs with the vector ALU 99 % busy.
  * The f-number test and the row range test are decided per wave and outer element from the
  * table row's extremes: when every lane passes both for the whole inner loop (the common case)
  * the loop runs without compares, selects or branches; otherwise a checked instantiation runs.
@@ -34,7 +37,6 @@
 #include "das_common.h"
 
 #define BF_HERC_BATCH 4
-
 /* cos^2(sqrt(w)) on [0, (pi/2)^2]: degree-5 fit at the Chebyshev nodes, |error| < 4.0e-7 (6.7e-7 as an
  * f32 Horner chain) -- next to 1e-4 of parity tolerance and the ~1e-6 of the hardware's v_cos */
 #define BF_APOD_C0  0.9999996f
@@ -237,18 +239,9 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				index[k] = dist[k] * kp + T0p;
 				if constexpr (CPLX) turns[k] = index[k] * tpsp;
 			}
-			/* floor and fraction of two indices with packed adds (unchecked linear path only: every index is
-			 * known to lie in [0.5, S - 1.5)): adding 2^23 - 0.5 rounds index - 0.5 to an integer in the low
-			 * mantissa bits, i.e. floor(index) -- or, for an exactly integral index, possibly index - 1 with
-			 * fraction 1, which interpolates to the same sample */
-			f32x2 magic[P], fracp[P];
-			if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
-				#pragma unroll
-				for (int k = 0; k < P; k++) {
-					magic[k] = index[k] + splat(8388607.5f);
-					fracp[k] = index[k] - (magic[k] - splat(8388608.0f));
-				}
-			}
+			/* (floor / fraction of two indices by packed adds -- index + 2^23 - 1/2 leaves floor(index) in the low
+			 * mantissa bits -- measured the same as v_cvt_flr + v_fract per index, 179.1 against 178.7 ms on 32 planes of
+			 * config 5, and needs margins at the row ends: not used) */
 			float   frac[B], ap[B];
 			Tap<INTERP> tap[B];
 			uint32_t off[B];
@@ -260,18 +253,15 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				ap[k]     = (k & 1) ? apod[k >> 1].y : apod[k >> 1].x;
 				if (k == 0) ap[k] *= first_weight;
 				uint32_t row = row0 + (uint32_t)(n + k) * inner_stride;
-				if constexpr (INTERP == BF_INTERP_LINEAR && !CHECK) {
-					frac[k] = (k & 1) ? fracp[k >> 1].y : fracp[k >> 1].x;
-					float mg = (k & 1) ? magic[k >> 1].y : magic[k >> 1].x;
-					/* bits(magic) = 0x4B000000 + floor(index); the constant leaves through the wave-uniform row offset */
-					off[k] = (__builtin_bit_cast(uint32_t, mg) * ES) + (row - 0x4B000000u * ES);
-				} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+				if constexpr (INTERP == BF_INTERP_LINEAR) {
 					frac[k] = hw_fract(idx);
 					uint32_t ki = (uint32_t)cvt_floor_i32(idx);
 					off[k] = row + ki * ES;
-					bool ok = (ki < ulast) && (e < apodization_test);
-					off[k] = ok ? off[k] : q.zero_offset;
-					ap[k]  = ok ? ap[k] : 0.f;
+					if constexpr (CHECK) {
+						bool ok = (ki < ulast) && (e < apodization_test);
+						off[k] = ok ? off[k] : q.zero_offset;
+						ap[k]  = ok ? ap[k] : 0.f;
+					}
 				} else {
 					tap[k] = tap_setup<INTERP, CPLX>(idx, (float)S, S - 1);
 					off[k] = row + tap[k].off;
