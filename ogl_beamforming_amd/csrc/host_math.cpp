@@ -37,6 +37,7 @@ static std::vector<float> residue_hadamard(int q, bool shift_right)
 std::vector<float> hadamard_transpose(int order)
 {
 	int dim = order, base = 0;
+	if (order <= 0 || order > 4096) return {};            /* callers pass transmit / group counts (<= 256) */
 	if (is_pow2(order))                                base = 1;
 	else if (order % 20 == 0 && is_pow2(order / 20)) { base = 20; dim = order / 20; }
 	else if (order % 12 == 0 && is_pow2(order / 12)) { base = 12; dim = order / 12; }

@@ -53,8 +53,12 @@ bool validate_parameters(const BeamformerParameters *bp)
 		return false;
 
 	uint64_t buffer_size = frame_ring_bytes();
-	uint64_t frame_size  = (uint64_t)max_of(1, bp->output_points[0]) * (uint64_t)max_of(1, bp->output_points[1])
-	                       * (uint64_t)max_of(1, bp->output_points[2]) * 8u /* Float32Complex */;
+	/* three 31-bit extents times 8 can wrap 64 bits (the reference's u64 product does): a wrapped size would
+	 * pass the check below and launch over a grid the frame ring cannot hold, so saturate instead */
+	const uint64_t px = (uint64_t)max_of(1, bp->output_points[0]), py = (uint64_t)max_of(1, bp->output_points[1]),
+	               pz = (uint64_t)max_of(1, bp->output_points[2]);
+	uint64_t frame_size = UINT64_MAX;
+	if (px * py <= (UINT64_MAX >> 3) / pz) frame_size = px * py * pz * 8u /* Float32Complex */;
 	uint64_t incoherent_size = frame_size / 2;
 	if (bp->coherency_weighting) buffer_size -= incoherent_size;
 	return check(frame_size <= buffer_size, BeamformerLibErrorKind_FrameSizeOverflow);

@@ -58,6 +58,8 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error, bool a
 		return false;
 	}
 	uint32_t D = bp.decimation_rate > 1 ? bp.decimation_rate : 1;
+	/* a decimation beyond the row leaves no sample (and 2 * D must not wrap: found by tests/plan_fuzz.cpp) */
+	if (D > S) { error = "decimation rate exceeds the sample count"; return false; }
 
 	float    fs      = bp.sampling_frequency;
 	uint32_t samples = S;
@@ -66,8 +68,8 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error, bool a
 		if (in_kind == BeamformerDataKind_Int16)   in_kind = BeamformerDataKind_Int16Complex;
 		if (in_kind == BeamformerDataKind_Float16) in_kind = BeamformerDataKind_Float16Complex;
 		if (in_kind == BeamformerDataKind_Float32) in_kind = BeamformerDataKind_Float32Complex;
-		samples /= 2 * D;
-		fs      /= (float)(2 * D);
+		samples  = (uint32_t)(S / (2ull * D));                         /* 64-bit: 2 * D must not wrap */
+		fs      /= 2.0f * (float)D;
 	}
 	/* The DAS kernels test sample indices with unsigned compares against S-1 / S-3 and clamp tap
 	 * addresses into the row: a row shorter than the interpolation's support (1 sample nearest,
@@ -249,6 +251,13 @@ bool build_plan(const ParameterBlock &pb, Plan &plan, std::string &error, bool a
 			plan.das_sparse = id == BeamformerAcquisitionKind_UFORCES || id == BeamformerAcquisitionKind_UHERCULES;
 			plan.das_time_offset = time_offset;                          /* :888 */
 			if (bp.readi_group_count > 1) {                              /* :932-939 */
+				/* The kernel reads row readi_group of a readi_group_count^2 matrix and walks
+				 * readi_group_count x acquisition_count transmit elements: bound both before anything is sized
+				 * by them (an unchecked 65536 asked for a 17 GB matrix: tests/plan_fuzz.cpp) */
+				if (bp.readi_group_count > BeamformerMaxEmissionsCount || bp.readi_group >= bp.readi_group_count) {
+					error = "readi_group / readi_group_count out of range";
+					return false;
+				}
 				plan.readi_hadamard = hadamard_transpose((int)bp.readi_group_count);
 				if (plan.readi_hadamard.empty()) { error = "no Hadamard construction for readi_group_count"; return false; }
 			}

@@ -278,3 +278,40 @@ def test_planner_refuses_rows_shorter_than_the_interpolation_support(demodulate,
     assert L.beamformer_create_filter(C.byref(acq.filters[0]), 0, 0)
     assert L.beamformer_push_simple_parameters(C.byref(acq.bp))
     assert not L.beamformer_hip_describe_plan(0, C.byref(P.HipPlan()))
+
+
+def test_planner_refuses_wild_decimation_and_readi_groups(L):
+    """found by tests/plan_fuzz.cpp: a decimation rate whose doubling wraps to 0 divided by zero, and an
+    unchecked readi_group_count sized a 17 GB Hadamard matrix (and readi_group indexed past it on the device)"""
+    acq = cfg.rca("wild", 16, 2, 256, (8, 8, 1), (-1e-3, 0, 5e-3), (1e-3, 0, 9e-3), seed=1)
+    assert L.beamformer_create_filter(C.byref(acq.filters[0]), 0, 0)
+    for rate, ok in ((0x80000000, False), (257, False), (4, True)):
+        acq.bp.decimation_rate = rate
+        assert L.beamformer_push_simple_parameters(C.byref(acq.bp))
+        assert bool(L.beamformer_hip_describe_plan(0, C.byref(P.HipPlan()))) == ok, rate
+    f = cfg.forces("wild_readi", 16, 4, 512, (8, 1, 8), (-1e-3, 0, 5e-3), (1e-3, 0, 9e-3), seed=2, decode=0, readi_groups=4, readi_group=2)
+    for groups, group, ok in ((4, 2, True), (4, 4, False), (65536, 0, False), (0x80000000, 0, False), (300, 1, False)):
+        f.bp.readi_group_count, f.bp.readi_group = groups, group
+        assert L.beamformer_push_simple_parameters(C.byref(f.bp))
+        assert bool(L.beamformer_hip_describe_plan(0, C.byref(P.HipPlan()))) == ok, (groups, group)
+
+
+def test_planner_survives_fuzzing(tmp_path):
+    """csrc/planner.cpp + csrc/host_math.cpp under AddressSanitizer + UBSan (CPU build; the GPU pool has no
+    sanitizers): 300 000 parameter blocks with boundary and wild values in every field a client can write.
+    Every block is planned or refused without a sanitizer report, and accepted plans keep the invariants the
+    kernels rely on (tests/plan_fuzz.cpp)."""
+    import os, shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = tmp_path / "plan_fuzz"
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=enum",
+                            "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                            os.path.join(here, "plan_fuzz.cpp"), "-o", str(exe)], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    for seed in ("11", "12", "13"):
+        run = subprocess.run([str(exe), "100000", seed], capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+        accepted, refused = (int(v) for v in run.stdout.split()[1::2])
+        assert accepted > 5000 and refused > 5000                        # both outcomes were exercised
