@@ -159,6 +159,15 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
  * split over channels (frames under ~4096 waves of voxels: K waves share 64 voxels, each
  * sums C/K channels, partial sums meet in LDS); adding 0x20 keeps Decode on the O(T^2) kernel
  * where it would run as a fast Walsh-Hadamard transform.  For parity testing of every path. */
+typedef enum {
+	BeamformerHipDasPath_Automatic        = 0,
+	BeamformerHipDasPath_General          = 1,    /* das.hip for every frame */
+	BeamformerHipDasPath_PreferLdsStaged  = 3,    /* das_staged.hip where its window bound holds */
+	BeamformerHipDasPath_PreferFactored   = 4,    /* das_factored.hip wherever the index factorises */
+	BeamformerHipDasPath_HerculesAnyWidth = 6,    /* das_hercules.hip also on grids narrower than 32 voxels */
+	BeamformerHipDasPath_NoChannelSplit   = 0x10, /* flag: general kernel at one thread per voxel for small frames too */
+	BeamformerHipDasPath_DenseDecode      = 0x20, /* flag: Decode on the O(T^2) kernel, not the Walsh-Hadamard form */
+} BeamformerHipDasPath;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 
 /* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----
