@@ -64,6 +64,9 @@ def parse():
                     help="N devices inside this one process (beamformer_hip_set_devices) instead of one process per GPU")
     ap.add_argument("--devices", type=str, default="",
                     help="--in-process: comma separated HIP ordinals (default 0..N-1; an ordinal may repeat, e.g. 0,0 on a one-GPU box: then NOT the metric)")
+    ap.add_argument("--frame-graph", action="store_true",
+                    help="replay every frame from a captured hipGraph (beamformer_hip_enable_frame_graphs; BASELINE configs[4] names a "
+                         "hipGraph-captured frame).  Off by default: never faster (profiles/r02_graph_probe.json), and a graph frame times as one segment")
     ap.add_argument("--planes", type=int, default=0, help="profiling aid: beamform only this many centre z-planes (value is then NOT the metric)")
     return ap.parse_args()
 
@@ -102,6 +105,9 @@ def main():
     else:
         assert L.beamformer_hip_set_device(device.index), lib.last_error()
     L.beamformer_hip_set_das_path(args.das_path)
+    if args.frame_graph:
+        assert not in_process or n_gpus == 1, "frame graphs are a one-device feature"
+        L.beamformer_hip_enable_frame_graphs(1)
 
     # every rank builds the parameter block (cheap, deterministic); only rank 0 owns the RF
     acq = configs.config(args.config, args.scale)
@@ -329,8 +335,11 @@ def main():
                             f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "
                             f"{'complex' if voxel_bytes == 8 else 'real'} voxels",
                 "notes": ((acq.notes + "; ") if acq.notes else "") +
-                         "every stage is launched directly on a HIP stream, not replayed from a captured hipGraph: a frame is <= 5 launches and "
-                         "replay measured slower than direct launches (profiles/r02_graph_probe.json, DESIGN.md section 8)",
+                         ("every frame replayed from a captured hipGraph (--frame-graph): the whole frame times as one segment, reported as the DAS kernel"
+                          if args.frame_graph else
+                          "every stage is launched directly on a HIP stream, not replayed from a captured hipGraph (available: --frame-graph / "
+                          "beamformer_hip_enable_frame_graphs): a frame is <= 6 launches and replay measured no faster (profiles/r02_graph_probe.json, "
+                          "profiles/r02_other_configs.json, DESIGN.md section 8)"),
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": how,
                 "das_path": PATH_NAMES[das_path], "slab_verified": verified, "rf_checksum_equal_on_all_ranks": rf_checksum_ok,

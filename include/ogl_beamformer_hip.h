@@ -110,6 +110,18 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerH
  * times with the voxel and pair counts of the whole frame and the slowest device's frame time.) */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out);
 
+/* Frame graphs (BASELINE.json configs[4] names a "hipGraph-captured frame"; the reference records one command
+ * list per frame, beamformer_core.c:1570-1620).  When enabled, the stage launches of a frame are captured into a
+ * hipGraph, the parameter block's instantiated graph is updated in place from the capture (the frame-ring slot and
+ * the RF slot move every frame, so kernel arguments do) and launched as one unit.  Frames are bit-identical either
+ * way.  Off by default: measured, a replayed frame is never faster than the <= 6 direct launches it replaces and
+ * 4 us slower on 15-us frames (profiles/r02_graph_probe.json), and a graph frame times as ONE segment (reported
+ * under DAS) because events cannot be recorded inside it.  One device only; pair counting falls back to direct
+ * launches.  beamformer_hip_frame_graph_counts reports how many frames were replayed from a graph and how many
+ * graphs had to be instantiated (one per plan unless the stage topology changes). */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_frame_graphs(uint32_t enable);
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_frame_graph_counts(uint64_t *frames_replayed, uint64_t *graphs_instantiated);
+
 /* When enabled, every frame also runs a geometry-only kernel that counts the triples that
  * pass the apodization test (G in BASELINE.md section 4).  Off by default. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_pair_counting(uint32_t enable);

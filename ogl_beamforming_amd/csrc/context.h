@@ -64,6 +64,7 @@ struct PlanState {
 	DeviceBuffer hadamard_t, hadamard_base, readi_hadamard, transmits, sparse, mapping;
 	std::vector<DeviceBuffer> taps;     /* per stage: filter taps (+ demodulation phasors) */
 	std::list<std::vector<float>> tap_tables;   /* host copies the async uploads read from */
+	uint64_t     generation = 0;          /* bumped by every successful commit (replan) of this block on this device */
 	std::vector<BfTransmit>   transmit_table;
 	std::vector<uint16_t>     readi_bits;
 	std::string  error;
@@ -104,6 +105,10 @@ struct Device {
 	hipEvent_t   rf_landed[BeamformerMaxRawDataFramesInFlight]{}, rf_consumed[BeamformerMaxRawDataFramesInFlight]{};
 	bool         consumed_pending[BeamformerMaxRawDataFramesInFlight]{};
 	uint32_t     slab_first = 0, slab_count = 0;               /* planes of the current multi-device frame */
+	/* frame graphs (beamformer_hip_enable_frame_graphs): one instantiated hipGraph per parameter block, updated
+	 * in place from each frame's capture; graph_generation = the plan generation it was warmed up for */
+	hipGraphExec_t frame_exec[BeamformerMaxParameterBlocks]{};
+	uint64_t       graph_generation[BeamformerMaxParameterBlocks]{};
 };
 
 struct Context {
@@ -118,6 +123,8 @@ struct Context {
 	uint32_t       das_path_mode = 0;
 	bool           count_pairs = false;
 	bool           hilbert_enabled = false;                    /* beamformer_hip_enable_hilbert */
+	bool           frame_graphs = false;                       /* beamformer_hip_enable_frame_graphs */
+	uint64_t       graph_frames = 0, graph_instantiations = 0; /* frames replayed from a graph / graphs instantiated */
 
 	/* device state */
 	int          requested_devices[kMaxDevices]{-1, -1, -1, -1, -1, -1, -1, -1};

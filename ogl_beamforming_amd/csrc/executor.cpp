@@ -165,6 +165,8 @@ static void release_one_device(Device &d)
 	for (auto &b : d.scratch) b.release();
 	d.ring.release(); d.pair_counter.release(); d.minmax_scratch.release(); d.sum_scratch.release();
 	d.hercules_table.release();
+	for (auto &g : d.frame_exec) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
+	for (auto &g : d.graph_generation) g = 0;
 	for (auto &t : d.timing) {
 		if (t.created) for (auto &e : t.events) if (e) (void)hipEventDestroy(e);
 		t = TimingSlot{};
@@ -286,6 +288,7 @@ static PlanState *commit_block(uint32_t block)
 	if (!ok) { ps.valid = false; ps.error = "device allocation or upload failed"; return nullptr; }
 	if (clears_dirty) pb.dirty = 0;
 	ps.valid = true;
+	ps.generation++;
 	return &ps;
 }
 
@@ -590,7 +593,68 @@ static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
 	return HIP_OK(hipEventRecord(t.events[index], s));
 }
 
+static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, bool ingest_timed);
+
+/* One frame.  With frame graphs on (beamformer_hip_enable_frame_graphs; BASELINE.json configs[4]: "hipGraph-
+ * captured frame"; the reference's analogue is the one command list it records per frame,
+ * beamformer_core.c:1570-1620) the stage launches are captured into a hipGraph instead of being enqueued:
+ * every frame is captured (the frame-ring slot and the RF slot move from frame to frame, so kernel arguments
+ * change), the block's instantiated graph is updated in place from the capture (hipGraphExecUpdate: same
+ * topology, new arguments; re-instantiated when the topology changed) and launched.  The first frame of a
+ * plan runs uncaptured so that every allocation a stage needs exists before anything is captured.  Per-stage
+ * events cannot be recorded inside a graph: a graph frame times as one segment, reported under DAS. */
 static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ingest_timed)
+{
+	Context &c = g_context;
+	Device  &d = *c.cur;
+	if (!c.frame_graphs || c.device_count != 1 || c.count_pairs) return run_frame_stages(block, rf, rf_bytes, ingest_timed);
+	PlanState *ps = commit_block(block);                   /* a replan drains the stream: never inside a capture */
+	if (!ps) return set_error(BeamformerLibErrorKind_InvalidComputeStage);
+	if (d.graph_generation[block] != ps->generation) {
+		d.graph_generation[block] = ps->generation;
+		if (d.frame_exec[block]) { (void)hipGraphExecDestroy(d.frame_exec[block]); d.frame_exec[block] = nullptr; }
+		return run_frame_stages(block, rf, rf_bytes, ingest_timed);
+	}
+	hipStream_t s = d.stream;
+	TimingSlot &t = d.timing[d.frame_counter % kTimingSlots];
+	if (!t.created) {
+		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
+		t.created = true;
+	}
+	const bool sampled = t.sampled;
+	const uint32_t first = ingest_timed ? 1u : 0u;          /* events[0] -> events[1] is the caller's ingest segment */
+	if (sampled && !HIP_OK(hipEventRecord(t.events[first], s))) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	t.sampled = false;                                      /* no event records inside the capture */
+	bool ok = HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+	if (!ok) { t.sampled = sampled; return set_error(BeamformerLibErrorKind_InvalidAccess); }
+	ok = run_frame_stages(block, rf, rf_bytes, ingest_timed);
+	hipGraph_t graph = nullptr;
+	bool ended = HIP_OK(hipStreamEndCapture(s, &graph));
+	t.sampled = sampled;
+	if (!ok || !ended || !graph) { if (graph) (void)hipGraphDestroy(graph); return ok ? set_error(BeamformerLibErrorKind_InvalidAccess) : false; }
+	if (d.frame_exec[block]) {
+		hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult why;
+		if (!HIP_OK(hipGraphExecUpdate(d.frame_exec[block], graph, &bad, &why))) {
+			(void)hipGetLastError();
+			(void)hipGraphExecDestroy(d.frame_exec[block]); d.frame_exec[block] = nullptr;
+		}
+	}
+	if (!d.frame_exec[block]) {
+		ok = HIP_OK(hipGraphInstantiate(&d.frame_exec[block], graph, nullptr, nullptr, 0));
+		c.graph_instantiations++;
+	}
+	(void)hipGraphDestroy(graph);
+	ok = ok && HIP_OK(hipGraphLaunch(d.frame_exec[block], s));
+	c.graph_frames += ok;
+	/* the frame as one timed segment */
+	t.count = 0;
+	if (ingest_timed) t.kinds[t.count++] = kStageIngest;
+	t.kinds[t.count++] = (uint32_t)BeamformerShaderKind_DAS;
+	if (sampled) ok = ok && HIP_OK(hipEventRecord(t.events[t.count], s));
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
+}
+
+static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, bool ingest_timed)
 {
 	Context &c = g_context;
 	Device  &d = *c.cur;

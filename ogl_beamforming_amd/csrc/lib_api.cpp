@@ -465,6 +465,15 @@ uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out)
 	return last_frame_timings(out);
 }
 
+uint32_t beamformer_hip_enable_frame_graphs(uint32_t enable) { ctx().frame_graphs = enable != 0; return 1; }
+
+uint32_t beamformer_hip_frame_graph_counts(uint64_t *frames_replayed, uint64_t *graphs_instantiated)
+{
+	if (frames_replayed)     *frames_replayed     = ctx().graph_frames;
+	if (graphs_instantiated) *graphs_instantiated = ctx().graph_instantiations;
+	return 1;
+}
+
 uint32_t beamformer_hip_enable_pair_counting(uint32_t enable) { ctx().count_pairs = enable != 0; return 1; }
 
 uint32_t beamformer_hip_frame_min_max(float out_min_max[2])

@@ -104,6 +104,8 @@ def _load():
         "beamformer_hip_synchronize": (u32, []),
         "beamformer_hip_get_last_frame_info": (u32, [C.POINTER(P.HipFrameInfo)]),
         "beamformer_hip_get_last_frame_timings": (u32, [C.POINTER(P.HipFrameTimings)]),
+        "beamformer_hip_enable_frame_graphs": (u32, [u32]),
+        "beamformer_hip_frame_graph_counts": (u32, [C.POINTER(u64), C.POINTER(u64)]),
         "beamformer_hip_enable_pair_counting": (u32, [u32]),
         "beamformer_hip_frame_min_max": (u32, [C.POINTER(C.c_float)]),
         "beamformer_hip_sum_last_frames": (u32, [u32, vp, u64]),

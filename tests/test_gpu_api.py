@@ -231,3 +231,52 @@ def test_decode_benchmark_harness_runs(tmp_path):
         assert float(l.split("Decode kernel")[1].split()[0]) > 0            # the stage ran and was timed
     table = np.fromfile(tmp_path / "stats" / "decode_256.bin", dtype=np.uint8)
     assert table.size == 2248                                              # sizeof(BeamformerComputeStatsTable)
+
+
+@pytest.mark.parametrize("name", ["config4_small", "config5_small", "config2_small", "config1_small", "forces"])
+def test_frame_graphs_replay_bit_identical_frames(name, bflib):
+    """beamformer_hip_enable_frame_graphs (BASELINE configs[4]: hipGraph-captured frame): eight pipelined host
+    pushes with changing RF -- the frame-ring slot and the RF slot move every frame -- replayed from ONE
+    instantiated graph updated in place, bit-identical to direct launches; a parameter change in between
+    (replan) is picked up; the stats table still reports the frame."""
+    L = bflib.library()
+    acq = cases.make(name)
+    rng = np.random.default_rng(5)
+    rfs = [np.ascontiguousarray(acq.rf)]
+    for _ in range(3):
+        noise = rng.normal(0, 1, acq.rf.shape)
+        rfs.append(np.ascontiguousarray((acq.rf + (50 * noise if acq.rf.dtype == np.int16 else 0.05 * noise)).astype(acq.rf.dtype)))
+
+    def run(graphs, f_number):
+        bp = P.SimpleParameters.from_buffer_copy(bytes(acq.bp))
+        bp.f_number = f_number
+        L.beamformer_hip_enable_frame_graphs(1 if graphs else 0)
+        try:
+            for slot, fp in enumerate(acq.filters):
+                assert L.beamformer_create_filter(C.byref(fp), slot, 0)
+            assert L.beamformer_push_simple_parameters(C.byref(bp))
+            out = []
+            for k in range(8):
+                rf = rfs[k % len(rfs)]
+                assert L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0), bflib.last_error()
+                if k in (2, 5, 7):
+                    out.append(bflib.get_last_frame(bp).copy())
+            stats = P.ComputeStatsTable()
+            assert L.beamformer_compute_timings(C.byref(stats), -1)
+            return out, stats
+        finally:
+            L.beamformer_hip_enable_frame_graphs(0)
+
+    replayed0, built0 = C.c_uint64(), C.c_uint64()
+    L.beamformer_hip_frame_graph_counts(C.byref(replayed0), C.byref(built0))
+    for f_number in (acq.bp.f_number, acq.bp.f_number * 1.5):            # the second value forces a replan
+        direct, _ = run(False, f_number)
+        graphed, stats = run(True, f_number)
+        for a, b in zip(direct, graphed):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        ids = [int(stats.shader_ids[i]) for i in range(int(stats.shader_count))]
+        assert int(P.ShaderKind.DAS) in ids
+    replayed, built = C.c_uint64(), C.c_uint64()
+    L.beamformer_hip_frame_graph_counts(C.byref(replayed), C.byref(built))
+    assert replayed.value - replayed0.value >= 2 * 6                    # all but each plan's first frame(s)
+    assert 1 <= built.value - built0.value <= 4                         # one graph per plan, updated in place

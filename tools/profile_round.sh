@@ -25,6 +25,8 @@ cut -c1-600 $OUT/profiles/r02_bench.json
 for c in 1 2 3 5; do
   timeout -k 10 300 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
 done
+timeout -k 10 300 python bench.py --config 5 --frame-graph --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_graph.json 2> $OUT/bench_cfg5_graph.err
+timeout -k 10 300 python bench.py --config 1 --frame-graph --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg1_graph.json 2> $OUT/bench_cfg1_graph.err
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
 python3 - <<'PY'
 import json
@@ -33,6 +35,9 @@ for c in (1, 2, 3, 5):
     d = json.loads(open(f"gpurun_out/r02/bench_cfg{c}.json").read())
     out[f"config{c}"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "das_path": d["config"]["das_path"], "stage_ms": d["config"]["stage_ms"],
                          "workload": d["config"]["workload"], "roofline": {k: d["roofline"][k] for k in ("achieved", "frac", "kernel", "kernel_ms", "pairs_per_launch", "binding")}}
+for c in (1, 5):
+    d = json.loads(open(f"gpurun_out/r02/bench_cfg{c}_graph.json").read())
+    out[f"config{c}_frame_graph"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "notes": d["config"]["notes"]}
 d = json.loads(open("gpurun_out/r02/bench_inprocess_0_0.json").read())
 out["config4_in_process_two_contexts_on_one_gpu"] = {"ms_per_step": d["ms_per_step"], "sharding": d["config"]["sharding"], "device_das_ms": d["config"].get("device_das_ms"),
                                                       "note": "orchestration check only: both device contexts share one GPU"}
