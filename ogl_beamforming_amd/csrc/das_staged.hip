@@ -4,37 +4,49 @@
  * (idx = T(a; v_tx, z) + R(c; v_rx, z), shaders/das.glsl:204-231 of the reference), for
  * linear interpolation of complex samples -- the configuration the headline metric runs.
  *
- * das_separable.hip gathers 16 bytes per (voxel, channel, transmit) term straight from
- * global memory and saturates the CU's vector L1 (one 64-byte access per four lanes,
- * ~17 accesses per wave-gather, measured 1.04 accesses/clk/CU).  But the 1024 voxels of a
- * 32 x 32 tile touch only a short window of every RF row: the receive delay moves by at most
- * pitch*fs/c (0.6 sample at config 4) per voxel along the receive axis and less along the
- * transmit axis.  So per channel the block copies, for every transmit, one W-sample window
- * (W = 32 or 64, 256 or 512 bytes) of the RF row into LDS -- 19 KB per channel instead of
- * 1.2 MB of gathers through L1 -- and every lane then interpolates out of LDS:
- *   two ds_read_b64 (conflict free: a window is at most one 256-B bank row and the lanes of a
- *   half-wave sit on one voxel row) + the broadcast table read = 8 LDS cycles per 64 terms
- * against 17 L1 cycles before.
+ * das_separable.hip gathers 16 bytes per (voxel, channel, transmit) term straight from global
+ * memory and sits on the CU's vector-memory path: 16.3 clk per wave64 gather instruction
+ * (tools/microbench.hip).  But the 1024 voxels of a 32 x 32 tile touch only a short window of
+ * every RF row: the receive delay moves by at most pitch*fs/c (0.6 sample at config 4) per voxel
+ * along the receive axis and less along the transmit axis.  So per channel the block copies,
+ * for every transmit, one W-sample window (W = 32 or 64: 256 or 512 bytes) of the RF row into
+ * LDS -- 19 KB per channel instead of 1.2 MB of gathers through L1 -- and every lane then
+ * interpolates out of LDS (two ds_read_b64 per term; a window is at most one 256-B bank row, so
+ * distinct addresses of a wave fall in distinct banks).
  *
- * Pipeline per channel: the global loads of the NEXT channel's windows are issued into
- * registers before the current channel is consumed, and written to LDS after it
- * (barrier - ds_write - barrier); two 1024-thread blocks share a CU so one block's barriers
- * hide under the other's arithmetic.
+ * Round 2 rewrite.  The first version of this kernel lost to the gather kernel (1327 against
+ * 1165 ms) because it paid ~20 VALU instructions per term against the gather kernel's 14: integer
+ * window bookkeeping, an always-on range test, address arithmetic per tap.  VALU issue is what
+ * both kernels wait for, so this version removes every per-term instruction the window made
+ * necessary:
+ *   * the window position is folded into the FLOAT tables: element j of window (c, a) holds sample
+ *     floor(rmin_c) + floor(tmin_a) + j (rmin / tmin: the delay minima over the tile), the receive
+ *     table hands the lane R' = R - floor(rmin_c) once per channel and the transmit table holds
+ *     T' = T - floor(tmin_a) -- both differences are exact in f32 -- so ONE add gives the position
+ *     inside the window, whose floor and fraction are the tap and the interpolation weight.  (The
+ *     sum R' + T' of two small numbers is rounded at 2^-19 of a sample instead of the 2^-13 of the
+ *     absolute index: the staged kernel is closer to exact arithmetic than the shader it restates.)
+ *   * the row of the window inside the staging area is an immediate offset of the LDS read (the
+ *     transmit loop is unrolled by 4; the batch's base is a scalar operand of the one v_lshl_add);
+ *   * the transmit table is padded to a multiple of 4 with zero phasors over a zero window row, so
+ *     the last batch needs no select;
+ *   * the range test of sample_rf (0 <= index < S - 1) is decided per wave and channel from the
+ *     tile-wide extremes of T exactly as in das_separable.hip; only waves that can leave the row
+ *     run the checked loop (absolute tap = window tap + the two floors; invalid taps read a zero pair).
  *
- * Window bookkeeping is integer only: element e of window a holds sample
- * floor(rmin_c) + floor(tmin_a) + e, where rmin_c / tmin_a are the minima of the receive /
- * transmit delays over the tile (kept with the tables).  Since floor(x + y) >= floor(x) +
- * floor(y), a lane's tap k = floor(R + T) is never left of the window; the host only launches
- * this kernel when its bound on the delay spread fits the window (plan_staged, executor.cpp).
- * Out-of-range sample indices read a zero pair kept behind the windows, so there is no
- * weight arithmetic (das_common.h explains why no branch either).  No MFMA: gather-accumulate.
+ * Pipeline per channel: the global loads of the NEXT channel's windows are issued into registers
+ * before the current channel is consumed and written to LDS after it (barrier - ds_write -
+ * barrier); two 1024-thread blocks share a CU, so one block's barriers hide under the other's
+ * arithmetic.  The host only launches this kernel when its bound on the delay spread of a tile fits
+ * the window (plan_staged, executor.cpp).  No MFMA: gather-accumulate.
  */
 #include "das_common.h"
 
-#define BF_STAGE_MAX_LOADS 4      /* window elements a thread stages per channel (A*W <= 4096) */
-#ifndef BF_STAGED_BATCH
-#define BF_STAGED_BATCH 4         /* terms whose LDS reads are in flight together per lane */
-#endif
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef __attribute__((address_space(3))) f32x3 lds_f32x3;
 
 __device__ __forceinline__ float staged_phase_turns(float k, float index)
 {
@@ -43,34 +55,42 @@ __device__ __forceinline__ float staged_phase_turns(float k, float index)
 	return hw_fract(p) + e;
 }
 
-/* LDS (16-byte units first):
- *   T[a*V + v]   = { cos(phi_t), sin(phi_t), t_index, bits(a*W - floor(tmin_a)) }
- *   R[cl*U + u]  = { apod*cos(phi_r), apod*sin(phi_r), r_index, apod }       cl: channel in chunk
- *   stage[a*W + e], e < W, then 2 zero elements                              f32x2
- *   tfloor[a], rfloor[cl]                                                     int
+/* LDS (16-byte units first; A4 = transmits rounded up to a multiple of 4):
+ *   T[a*V + v]   = { cos(phi_t), sin(phi_t), T' = t_index - floor(tmin_a), bits(floor(tmin_a)) }   a < A4
+ *   R[cl*U + u]  = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }       cl: channel in chunk
+ *   stage[a*W + e], e < W, a < A4, then 2 zero elements                       f32x2
+ *   rfloor[cl]                                                                 int
  */
-template <bool CW, int VS, int WS>
+/* NL: window elements a thread stages per channel, ceil(A4 * W / threads) */
+template <bool CW, int VS, int WS, int NL>
 __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs p, const BfSeparableArgs q)
 {
 	extern __shared__ __attribute__((aligned(16))) f32x4 staged_lds[];
 	constexpr uint32_t V = 1u << VS, W = 1u << WS;
 	const uint32_t U = 1u << q.u_shift;
 	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
+	const int A4 = (A + 3) & ~3;
 	const int chunk = (int)q.channel_chunk;
 	f32x4 *T      = staged_lds;
-	f32x4 *R      = T + (size_t)A * V;
+	f32x4 *R      = T + (size_t)A4 * V;
 	f32x2 *stage  = reinterpret_cast<f32x2 *>(R + (size_t)chunk * U);
-	int   *tfloor = reinterpret_cast<int *>(stage + (size_t)A * W + 2);
-	int   *rfloor = tfloor + A;
-	const uint32_t zero_element = (uint32_t)A * W;
+	int   *rfloor = reinterpret_cast<int *>(stage + (size_t)A4 * W + 2);
+	const uint32_t zero_element = (uint32_t)A4 * W;
 
 	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
 	const uint32_t per   = (total + 7u) / 8u;
 	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 	if (tile >= total) return;                               /* whole block */
-	const uint32_t tu = tile % q.tiles[0];
-	const uint32_t tv = (tile / q.tiles[0]) % q.tiles[1];
-	const uint32_t zl = tile / (q.tiles[0] * q.tiles[1]);
+	uint32_t tu, tv, zl;                                     /* walk order: das_separable.hip */
+	if (q.depth_major) {
+		zl = tile % q.tiles[2];
+		tu = (tile / q.tiles[2]) % q.tiles[0];
+		tv = tile / (q.tiles[2] * q.tiles[0]);
+	} else {
+		tu = tile % q.tiles[0];
+		tv = (tile / q.tiles[0]) % q.tiles[1];
+		zl = tile / (q.tiles[0] * q.tiles[1]);
+	}
 	const uint32_t z  = p.z_first + zl;
 
 	const uint32_t u_axis = q.u_axis, v_axis = 1u - q.u_axis;
@@ -83,38 +103,65 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
 
-	/* ---- transmit table */
-	for (uint32_t e = tid; e < (uint32_t)A * V; e += nthreads) {
+	/* ---- transmit table (absolute delays first) */
+	for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
 		uint32_t a = e >> VS, iv = e & (V - 1);
-		float coord[3] = {0.f, 0.f, pz};
-		coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
-		float wx, wy, wz;
-		m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
-		const BfTransmit t = p.transmits[a];
-		float dist = 0.f;
-		if (!(t.flags & BF_TX_NONE)) {
-			float px = (t.flags & BF_TX_ROWS) ? wy : wx;
-			if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
-			else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
+		f32x4 entry = {0.f, 0.f, 0.f, 0.f};                  /* padding transmits: zero phasor, window position 0 */
+		if (a < (uint32_t)A) {
+			float coord[3] = {0.f, 0.f, pz};
+			coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
+			float wx, wy, wz;
+			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			const BfTransmit t = p.transmits[a];
+			float dist = 0.f;
+			if (!(t.flags & BF_TX_NONE)) {
+				float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+				if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
+				else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
+			}
+			float t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+			float turns = staged_phase_turns(phase_k, t_idx);
+			entry = f32x4{hw_cos_turns(turns), hw_sin_turns(turns), t_idx, 0.f};
 		}
-		float t_idx = (dist * p.inv_speed_of_sound + p.time_offset) * p.sampling_frequency;
-		float turns = staged_phase_turns(phase_k, t_idx);
-		T[e] = f32x4{hw_cos_turns(turns), hw_sin_turns(turns), t_idx, 0.f};
+		T[e] = entry;
 	}
 	if (tid < 2) stage[zero_element + tid] = f32x2{0.f, 0.f};
+	/* tile-wide extremes of the absolute transmit delay (range-test shortcut, as das_separable.hip) */
+	__shared__ f32x2 wave_range[16];
 	__syncthreads();
-	/* floor of the smallest transmit delay of each window, folded with the window's position */
+	{
+		float lo = __builtin_inff(), hi = -__builtin_inff();
+		for (uint32_t e = tid; e < (uint32_t)A * V; e += nthreads) {
+			float v = T[e].z;
+			lo = fminf(lo, v); hi = fmaxf(hi, v);
+		}
+		for (int off = 32; off > 0; off >>= 1) {
+			lo = fminf(lo, __shfl_xor(lo, off, 64));
+			hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+		}
+		if ((tid & 63u) == 0) wave_range[tid >> 6] = f32x2{lo, hi};
+	}
+	__syncthreads();
+	f32x2 range = wave_range[0];
+	for (uint32_t w = 1; w < (nthreads >> 6); w++) {
+		range.x = fminf(range.x, wave_range[w].x);
+		range.y = fmaxf(range.y, wave_range[w].y);
+	}
+	/* the same for every lane: keep it in scalar registers */
+	range.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, range.x)));
+	range.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, range.y)));
+	/* per transmit: floor of the smallest delay of its table row; the row becomes window-relative */
 	for (uint32_t a = tid; a < (uint32_t)A; a += nthreads) {
 		float *row = reinterpret_cast<float *>(T + (size_t)a * V);
 		float  m   = row[2];
 		#pragma unroll 4
 		for (uint32_t iv = 1; iv < V; iv++) m = fminf(m, row[4 * iv + 2]);
-		int f = (int)__builtin_floorf(m);
-		tfloor[a] = f;
-		float bits = __builtin_bit_cast(float, (int)(a * W) - f);
+		float fl = __builtin_floorf(m);
+		float bits = __builtin_bit_cast(float, (int)fl);
 		#pragma unroll 4
-		for (uint32_t iv = 0; iv < V; iv++) row[4 * iv + 3] = bits;
+		for (uint32_t iv = 0; iv < V; iv++) { row[4 * iv + 2] -= fl; row[4 * iv + 3] = bits; }
 	}
+	__syncthreads();                                         /* the floors are read below */
 
 	uint32_t lu, lv;
 	if (u_axis == 0) { lu = tid & (U - 1); lv = tid >> q.u_shift; }
@@ -125,28 +172,46 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 
 	f32x2 coherent   = {0.f, 0.f};
 	float incoherent = 0.f;
-	const char    *rf_bytes = (const char *)p.rf;
-	const f32x4   *Rl = R + lu, *Tl = T + lv;
+	const f32x4   *Rl = R + lu;
 	const uint32_t ulast = (uint32_t)(S - 1);
-	const uint32_t stage_elements = (uint32_t)A * W;
+	const uint32_t stage_elements = (uint32_t)A4 * W;
+	/* LDS byte addresses: the lane's column of the transmit table, the staging area */
+	const uint32_t t_base  = (uint32_t)(uintptr_t)(lds_f32x4 *)T;
+	const uint32_t stage_b = (uint32_t)(uintptr_t)(lds_f32x2 *)stage;
 
-	/* the window elements this thread stages: e = tid + n*nthreads -> (a, j) */
-	auto stage_load = [&](int channel, int rfl, f32x2 (&regs)[BF_STAGE_MAX_LOADS]) {
+	/* Staging.  Thread tid copies element j = tid % W of windows a_n = tid / W + n * (threads / W), n < NL:
+	 * sample rfl + floor(tmin_a) + j of row (channel, a).  The loads are buffer loads over the whole DAS
+	 * input: an offset outside it (a window that starts before the first row or ends behind the last)
+	 * returns zero instead of faulting, and samples a window holds from a NEIGHBOURING row are never
+	 * consumed -- a term is only evaluated (unchecked loop) or only kept (checked loop) when both of
+	 * its taps lie inside its own row.  Per thread and n one loop-invariant byte offset; per channel one add. */
+	const __amdgpu_buffer_rsrc_t rf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<void *>(p.rf), 0, (int)((uint32_t)C * (uint32_t)A * (uint32_t)S * 8u), 0x00020000);
+	const uint32_t windows_per_pass = nthreads >> WS;
+	uint32_t stage_inv[NL];
+	#pragma unroll
+	for (int n = 0; n < NL; n++) {
+		uint32_t a = (tid >> WS) + (uint32_t)n * windows_per_pass;
+		int tfl = 0;
+		if (a < (uint32_t)A) {
+			const float fbits = reinterpret_cast<const float *>(T + (size_t)a * V)[3];
+			tfl = __builtin_bit_cast(int, fbits);
+		}
+		/* transmits of the padding (a >= A) point far outside the buffer: they stage zeros */
+		stage_inv[n] = a < (uint32_t)A ? (a * (uint32_t)S + (uint32_t)(tfl + (int)(tid & (W - 1)))) * 8u : 0x80000000u;
+	}
+	auto stage_load = [&](int channel, int rfl, f32x2 (&regs)[NL]) {
+		const uint32_t at = ((uint32_t)channel * (uint32_t)A * (uint32_t)S + (uint32_t)rfl) * 8u;
 		#pragma unroll
-		for (int n = 0; n < BF_STAGE_MAX_LOADS; n++) {
-			uint32_t e = tid + (uint32_t)n * nthreads;
-			regs[n] = f32x2{0.f, 0.f};
-			if (e < stage_elements) {
-				uint32_t a = e >> WS, j = e & (W - 1);
-				int s = rfl + tfloor[a] + (int)j;
-				if ((uint32_t)s < (uint32_t)S)
-					regs[n] = gather<f32x2>(rf_bytes, (((uint32_t)channel * (uint32_t)A + a) * (uint32_t)S + (uint32_t)s) * 8u);
-			}
+		for (int n = 0; n < NL; n++) {
+			/* (the padding's 0x80000000 + at stays out of range: the host refuses inputs of 2 GiB and more here) */
+			i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rf_rsrc, (int)(stage_inv[n] + at), 0, 0);
+			regs[n] = __builtin_bit_cast(f32x2, v);
 		}
 	};
-	auto stage_store = [&](const f32x2 (&regs)[BF_STAGE_MAX_LOADS]) {
+	auto stage_store = [&](const f32x2 (&regs)[NL]) {
 		#pragma unroll
-		for (int n = 0; n < BF_STAGE_MAX_LOADS; n++) {
+		for (int n = 0; n < NL; n++) {
 			uint32_t e = tid + (uint32_t)n * nthreads;
 			if (e < stage_elements) stage[e] = regs[n];
 		}
@@ -167,14 +232,14 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			float a_arg   = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(xz))));
 			/* the delay is kept for lanes outside the aperture too: it keeps their (discarded)
 			 * LDS reads inside the window */
-			float r_idx = hw_sqrt(dx * dx + xz * xz) * p.inv_speed_of_sound * p.sampling_frequency;
-			f32x4 entry = {0.f, 0.f, r_idx, 0.f};
+			float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), p) * p.sampling_frequency;
+			f32x4 entry = {r_idx, 0.f, 0.f, 0.f};
 			if (a_arg < 0.5f) {
 				float cs    = hw_cos_turns(0.5f * a_arg);
 				float apod  = cs * cs;
 				float turns = staged_phase_turns(phase_k, r_idx);
-				entry.x = apod * hw_cos_turns(turns);
-				entry.y = apod * hw_sin_turns(turns);
+				entry.y = apod * hw_cos_turns(turns);
+				entry.z = apod * hw_sin_turns(turns);
 				entry.w = apod;
 			}
 			R[e] = entry;
@@ -182,14 +247,14 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 		__syncthreads();
 		for (uint32_t cl = tid; cl < (uint32_t)cn; cl += nthreads) {
 			const float *row = reinterpret_cast<const float *>(R + (size_t)cl * U);
-			float m = row[2];
+			float m = row[0];
 			#pragma unroll 4
-			for (uint32_t iu = 1; iu < U; iu++) m = fminf(m, row[4 * iu + 2]);
+			for (uint32_t iu = 1; iu < U; iu++) m = fminf(m, row[4 * iu]);
 			rfloor[cl] = (int)__builtin_floorf(m);
 		}
 		__syncthreads();
 
-		f32x2 regs[BF_STAGE_MAX_LOADS];
+		f32x2 regs[NL];
 		stage_load(c0, rfloor[0], regs);
 		for (int cl = 0; cl < cn; cl++) {
 			__syncthreads();                   /* everyone is done with the previous channel's windows */
@@ -198,48 +263,67 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			if (cl + 1 < cn) stage_load(c0 + cl + 1, rfloor[cl + 1], regs);   /* in flight during the arithmetic */
 			if (!inside) continue;
 
-			const f32x4 r = Rl[(size_t)cl * U];
-			if (__builtin_amdgcn_ballot_w64(r.w != 0.f) == 0) continue;    /* F# culling per wave */
-			const int rbase = -rfloor[cl];
+			/* (register budget: 64 per lane at 8 waves per SIMD with the next channel's windows in flight.  The
+			 * receive entry is read twice -- delay and aperture test here, phasor and weight after the loop -- and the
+			 * lane's table address is rebuilt per channel rather than kept) */
+			float r_x, r_w;
+			{
+				const f32x4 r = Rl[(size_t)cl * U];
+				r_x = r.x; r_w = r.w;
+			}
+			if (__builtin_amdgcn_ballot_w64(r_w != 0.f) == 0) continue;    /* F# culling per wave */
+			const int   rfl   = rfloor[cl];
+			const float r_rel = r_x - (float)rfl;                          /* exact: position of the lane's receive delay in the window */
 			f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 			float mag = 0.f;
-			constexpr int B = BF_STAGED_BATCH;
-			for (int a = 0; a < A; a += B) {
-				f32x4 t[B]; float frac[B]; uint32_t el[B]; f32x2 s0[B], s1[B];
-				#pragma unroll
-				for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k < A ? a + k : A - 1) * V];
-				#pragma unroll
-				for (int k = 0; k < B; k++) {
-					float index = r.z + t[k].z;
-					frac[k] = hw_fract(index);
-					uint32_t ki = (uint32_t)cvt_floor_i32(index);
-					/* (through a scalar temporary: __builtin_bit_cast applied directly to a vector
-					 * component reads the vector's first component with this hipcc) */
-					const float wbits = t[k].w;
-					uint32_t e  = ki + (uint32_t)(__builtin_bit_cast(int, wbits) + rbase);
-					el[k] = (ki < ulast && a + k < A) ? e : zero_element;
+			auto term = [&](f32x2 cs, float frac, f32x2 s0, f32x2 s1) {
+				f32x2 sv = s0 + frac * (s1 - s0);
+				acc1 += sv.x * cs;
+				acc2 += sv.y * cs;
+				if constexpr (CW) mag += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+			};
+			const bool lane_safe = (r_x + range.x >= 0.f) && (r_x + range.y < (float)(S - 1));
+			const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
+			auto batches = [&](auto checked) {
+				constexpr bool CHECK = decltype(checked)::value;
+				uint32_t lane_id = tid;
+				asm volatile("" : "+v"(lane_id));                          /* not hoisted: see the register budget above */
+				uint32_t t_at = t_base + ((u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1)) << 4), row_at = stage_b;
+				for (int a = 0; a < A4; a += 4, t_at += 4u * V * 16u, row_at += 4u * W * 8u) {
+					/* the unchecked loop reads 12 of an entry's 16 bytes (ds_read_b96): 4 registers fewer in flight */
+					using TE = typename std::conditional<CHECK, f32x4, f32x3>::type;
+					using LTE = typename std::conditional<CHECK, lds_f32x4, lds_f32x3>::type;
+					TE t[4]; float frac[4]; uint32_t at[4]; f32x2 s0[4], s1[4];
+					#pragma unroll
+					for (int k = 0; k < 4; k++) t[k] = *(LTE *)(uintptr_t)(t_at + (uint32_t)k * V * 16u);
+					#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						float rel = r_rel + t[k].z;
+						frac[k] = hw_fract(rel);
+						int ki  = cvt_floor_i32(rel);
+						at[k]   = ((uint32_t)ki << 3) + row_at;
+						if constexpr (CHECK) {
+							const float tb = t[k][3];
+							uint32_t k_abs = (uint32_t)(ki + rfl + __builtin_bit_cast(int, tb));
+							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 8u : stage_b + zero_element * 8u;
+						}
+					}
+					#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const uint32_t row_k = CHECK ? 0u : (uint32_t)k * W * 8u;      /* immediate offset of the LDS read */
+						s0[k] = *(volatile lds_f32x2 *)(uintptr_t)(at[k] + row_k);
+						s1[k] = *(volatile lds_f32x2 *)(uintptr_t)(at[k] + row_k + 8u);
+					}
+					#pragma unroll
+					for (int k = 0; k < 4; k++) term(f32x2{t[k].x, t[k].y}, frac[k], s0[k], s1[k]);
 				}
-				#pragma unroll
-				for (int k = 0; k < B; k++) {
-					/* two independent 8-byte reads (2 LDS cycles each); the empty asm keeps hipcc from
-					 * fusing them into one ds_read2_b64 (8 cycles) */
-					uint32_t e1 = el[k] + 1;
-					asm("" : "+v"(e1));
-					s0[k] = stage[el[k]];
-					s1[k] = stage[e1];
-				}
-				#pragma unroll
-				for (int k = 0; k < B; k++) {
-					f32x2 sv = (1.f - frac[k]) * s0[k] + frac[k] * s1[k];
-					f32x2 cs = {t[k].x, t[k].y};
-					acc1 += sv.x * cs;
-					acc2 += sv.y * cs;
-					if constexpr (CW) { f32x2 sq = sv * sv; mag += hw_sqrt(sq.x + sq.y); }
-				}
-			}
+			};
+			if (wave_safe) batches(std::false_type{});
+			else           batches(std::true_type{});
 			f32x2 sum = {acc1.x - acc2.y, acc1.y + acc2.x};
-			coherent.x += sum.x * r.x - sum.y * r.y;
-			coherent.y += sum.x * r.y + sum.y * r.x;
+			const f32x4 r = *(volatile lds_f32x4 *)(uintptr_t)((uint32_t)(uintptr_t)(lds_f32x4 *)Rl + (uint32_t)cl * U * 16u);
+			coherent.x += sum.x * r.y - sum.y * r.z;
+			coherent.y += sum.x * r.z + sum.y * r.y;
 			if constexpr (CW) incoherent += r.w * mag;
 		}
 	}
@@ -250,28 +334,41 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	reinterpret_cast<f32x2 *>(p.out)[out_index] = coherent;
 }
 
-template <bool CW, int VS, int WS>
+template <bool CW, int VS, int WS, int NL>
 static hipError_t launch_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
-	auto kernel = das_rca_staged_kernel<CW, VS, WS>;
+	auto kernel = das_rca_staged_kernel<CW, VS, WS, NL>;
 	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(q->threads), q->lds_bytes, s, *a, *q);
 	return hipGetLastError();
 }
 
+template <bool CW, int VS, int WS>
+static hipError_t launch_staged_loads(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
+{
+	const uint32_t A4 = ((uint32_t)a->acquisition_count + 3u) & ~3u;
+	switch (((A4 << WS) + q->threads - 1) / q->threads) {
+	case 1: return launch_staged<CW, VS, WS, 1>(a, q, s);
+	case 2: return launch_staged<CW, VS, WS, 2>(a, q, s);
+	case 3: return launch_staged<CW, VS, WS, 3>(a, q, s);
+	case 4: return launch_staged<CW, VS, WS, 4>(a, q, s);
+	}
+	return hipErrorInvalidValue;
+}
+
 template <bool CW>
 static hipError_t launch_staged_shape(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	switch ((q->v_shift << 4) | q->window_shift) {
-	case (4 << 4) | 5: return launch_staged<CW, 4, 5>(a, q, s);
-	case (5 << 4) | 5: return launch_staged<CW, 5, 5>(a, q, s);
-	case (6 << 4) | 5: return launch_staged<CW, 6, 5>(a, q, s);
-	case (4 << 4) | 6: return launch_staged<CW, 4, 6>(a, q, s);
-	case (5 << 4) | 6: return launch_staged<CW, 5, 6>(a, q, s);
-	case (6 << 4) | 6: return launch_staged<CW, 6, 6>(a, q, s);
+	case (4 << 4) | 5: return launch_staged_loads<CW, 4, 5>(a, q, s);
+	case (5 << 4) | 5: return launch_staged_loads<CW, 5, 5>(a, q, s);
+	case (6 << 4) | 5: return launch_staged_loads<CW, 6, 5>(a, q, s);
+	case (4 << 4) | 6: return launch_staged_loads<CW, 4, 6>(a, q, s);
+	case (5 << 4) | 6: return launch_staged_loads<CW, 5, 6>(a, q, s);
+	case (6 << 4) | 6: return launch_staged_loads<CW, 6, 6>(a, q, s);
 	}
 	return hipErrorInvalidValue;
 }
@@ -280,5 +377,7 @@ static hipError_t launch_staged_shape(const BfDasArgs *a, const BfSeparableArgs 
 extern "C" hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	if (!a->complex_data || a->interpolation != BF_INTERP_LINEAR) return hipErrorInvalidValue;
+	/* the staging loads address the DAS input through 32-bit buffer offsets with out-of-range padding at 2^31 */
+	if ((uint64_t)a->channel_count * (uint64_t)a->acquisition_count * (uint64_t)a->sample_count * 8u >= (1ull << 31)) return hipErrorInvalidValue;
 	return a->coherency_weighting ? launch_staged_shape<true>(a, q, s) : launch_staged_shape<false>(a, q, s);
 }

@@ -439,6 +439,9 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 {
 	if (!a.complex_data || a.interpolation != 1) return false;
 	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
+	/* the kernel stages through 32-bit buffer offsets and parks its padding loads at 2^31 */
+	if ((uint64_t)C * A * (uint64_t)a.sample_count * 8u >= (1ull << 31)) return false;
+	const uint32_t A4 = (A + 3u) & ~3u;                          /* the kernel pads the transmit table to whole batches of 4 */
 	const int u_axis = (int)q.u_axis, v_axis = 1 - u_axis;
 	const int r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0, w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;
 	float m[16];
@@ -467,10 +470,10 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + 4;       /* + taps, floors, rounding slack */
 			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
 			if (!ws) continue;
-			if (((uint64_t)A << ws) > ((uint64_t)4 << threads_shift)) continue;   /* BF_STAGE_MAX_LOADS */
+			if (((uint64_t)A4 << ws) > ((uint64_t)4 << threads_shift)) continue;  /* BF_STAGE_MAX_LOADS */
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
-				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A << vs)) + 8ull * (((uint64_t)A << ws) + 2) + 4ull * (A + cc);
+				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A4 << vs)) + 8ull * (((uint64_t)A4 << ws) + 2) + 4ull * cc;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
 				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = 2048u >> threads_shift;
