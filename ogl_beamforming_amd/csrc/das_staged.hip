@@ -55,12 +55,14 @@ __device__ __forceinline__ float staged_phase_turns(float k, float index)
 	return hw_fract(p) + e;
 }
 
-/* LDS (16-byte units first; A4 = transmits rounded up to a multiple of 4):
- *   T[a*V + v]   = { cos(phi_t), sin(phi_t), T' = t_index - floor(tmin_a), bits(floor(tmin_a)) }   a < A4
- *   R[cl*U + u]  = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }       cl: channel in chunk
- *   stage[a*W + e], e < W, a < A4, then 2 zero elements                       f32x2
- *   rfloor[cl]                                                                 int
- */
+/* LDS (A4 = transmits rounded up to a multiple of 4; transmits are kept in PAIRS so that one read serves two terms):
+ *   Tcs[(a/2)*V + v] = { cos(phi_t), sin(phi_t) of transmit a & ~1, then of transmit a | 1 }          f32x4
+ *   R[cl*U + u]      = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }     cl: channel in chunk   f32x4
+ *   stage[a*W + j]   = { s, s' - s }: sample floor(rmin_c) + floor(tmin_a) + j of row (c, a) and its
+ *                      difference to the next sample; j < W, a < A4; then one zero element               f32x4
+ *   Tz[(a/2)*V + v]  = { T' = t_index - floor(tmin_a) of transmit a & ~1, of transmit a | 1 }            f32x2
+ *   tfl[a]           = floor(tmin_a)  (checked loop and staging only),  rfloor[cl] = floor(rmin_c)       int
+ * Keeping {s, s' - s} makes the two taps ONE 16-byte aligned read and the interpolation one packed fma. */
 /* NL: window elements a thread stages per channel, ceil(A4 * W / threads) */
 template <bool CW, int VS, int WS, int NL>
 __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs p, const BfSeparableArgs q)
@@ -71,11 +73,13 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
 	const int A4 = (A + 3) & ~3;
 	const int chunk = (int)q.channel_chunk;
-	f32x4 *T      = staged_lds;
-	f32x4 *R      = T + (size_t)A4 * V;
-	f32x2 *stage  = reinterpret_cast<f32x2 *>(R + (size_t)chunk * U);
-	int   *rfloor = reinterpret_cast<int *>(stage + (size_t)A4 * W + 2);
-	const uint32_t zero_element = (uint32_t)A4 * W;
+	f32x4 *Tcs    = staged_lds;
+	f32x4 *R      = Tcs + (size_t)(A4 / 2) * V;
+	f32x4 *stage  = R + (size_t)chunk * U;
+	f32x2 *Tz     = reinterpret_cast<f32x2 *>(stage + (size_t)A4 * W + 1);
+	int   *tfl    = reinterpret_cast<int *>(Tz + (size_t)(A4 / 2) * V);
+	int   *rfloor = tfl + A4;
+	const uint32_t stage_elements = (uint32_t)A4 * W;
 
 	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
 	const uint32_t per   = (total + 7u) / 8u;
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
 
-	/* ---- transmit table (absolute delays first) */
+	/* ---- transmit tables (absolute delays first) */
 	for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
 		uint32_t a = e >> VS, iv = e & (V - 1);
-		f32x4 entry = {0.f, 0.f, 0.f, 0.f};                  /* padding transmits: zero phasor, window position 0 */
+		float cs_c = 0.f, cs_s = 0.f, t_idx = 0.f;           /* padding transmits: zero phasor, window position 0 */
 		if (a < (uint32_t)A) {
 			float coord[3] = {0.f, 0.f, pz};
 			coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
@@ -119,20 +123,23 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
 				else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
 			}
-			float t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+			t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
 			float turns = staged_phase_turns(phase_k, t_idx);
-			entry = f32x4{hw_cos_turns(turns), hw_sin_turns(turns), t_idx, 0.f};
+			cs_c = hw_cos_turns(turns); cs_s = hw_sin_turns(turns);
 		}
-		T[e] = entry;
+		const uint32_t pair = (a >> 1) * V + iv, half = a & 1u;
+		reinterpret_cast<f32x2 *>(Tcs + pair)[half] = f32x2{cs_c, cs_s};
+		reinterpret_cast<float *>(Tz + pair)[half]  = t_idx;
 	}
-	if (tid < 2) stage[zero_element + tid] = f32x2{0.f, 0.f};
+	if (tid == 0) stage[stage_elements] = f32x4{0.f, 0.f, 0.f, 0.f};
 	/* tile-wide extremes of the absolute transmit delay (range-test shortcut, as das_separable.hip) */
 	__shared__ f32x2 wave_range[16];
 	__syncthreads();
 	{
 		float lo = __builtin_inff(), hi = -__builtin_inff();
 		for (uint32_t e = tid; e < (uint32_t)A * V; e += nthreads) {
-			float v = T[e].z;
+			uint32_t a = e >> VS, iv = e & (V - 1);
+			float v = reinterpret_cast<const float *>(Tz + (a >> 1) * V + iv)[a & 1u];
 			lo = fminf(lo, v); hi = fmaxf(hi, v);
 		}
 		for (int off = 32; off > 0; off >>= 1) {
@@ -151,15 +158,15 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	range.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, range.x)));
 	range.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, range.y)));
 	/* per transmit: floor of the smallest delay of its table row; the row becomes window-relative */
-	for (uint32_t a = tid; a < (uint32_t)A; a += nthreads) {
-		float *row = reinterpret_cast<float *>(T + (size_t)a * V);
-		float  m   = row[2];
+	for (uint32_t a = tid; a < (uint32_t)A4; a += nthreads) {
+		float *row = reinterpret_cast<float *>(Tz + (size_t)(a >> 1) * V) + (a & 1u);
+		float  m   = row[0];
 		#pragma unroll 4
-		for (uint32_t iv = 1; iv < V; iv++) m = fminf(m, row[4 * iv + 2]);
+		for (uint32_t iv = 1; iv < V; iv++) m = fminf(m, row[2 * iv]);
 		float fl = __builtin_floorf(m);
-		float bits = __builtin_bit_cast(float, (int)fl);
 		#pragma unroll 4
-		for (uint32_t iv = 0; iv < V; iv++) { row[4 * iv + 2] -= fl; row[4 * iv + 3] = bits; }
+		for (uint32_t iv = 0; iv < V; iv++) row[2 * iv] -= fl;
+		tfl[a] = (int)fl;
 	}
 	__syncthreads();                                         /* the floors are read below */
 
@@ -174,10 +181,13 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	float incoherent = 0.f;
 	const f32x4   *Rl = R + lu;
 	const uint32_t ulast = (uint32_t)(S - 1);
-	const uint32_t stage_elements = (uint32_t)A4 * W;
-	/* LDS byte addresses: the lane's column of the transmit table, the staging area */
-	const uint32_t t_base  = (uint32_t)(uintptr_t)(lds_f32x4 *)T;
-	const uint32_t stage_b = (uint32_t)(uintptr_t)(lds_f32x2 *)stage;
+	/* LDS byte addresses */
+	uint32_t tcs_base = (uint32_t)(uintptr_t)(lds_f32x4 *)Tcs;
+	uint32_t tz_base  = (uint32_t)(uintptr_t)(lds_f32x2 *)Tz;
+	uint32_t stage_b  = (uint32_t)(uintptr_t)(lds_f32x4 *)stage;
+	/* opaque to the compiler: otherwise the static LDS in front of the dynamic block is re-added as a constant
+	 * to every address of the inner loop instead of once here */
+	asm("" : "+s"(tcs_base), "+s"(tz_base), "+s"(stage_b));
 
 	/* Staging.  Thread tid copies element j = tid % W of windows a_n = tid / W + n * (threads / W), n < NL:
 	 * sample rfl + floor(tmin_a) + j of row (channel, a).  The loads are buffer loads over the whole DAS
@@ -192,13 +202,8 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	#pragma unroll
 	for (int n = 0; n < NL; n++) {
 		uint32_t a = (tid >> WS) + (uint32_t)n * windows_per_pass;
-		int tfl = 0;
-		if (a < (uint32_t)A) {
-			const float fbits = reinterpret_cast<const float *>(T + (size_t)a * V)[3];
-			tfl = __builtin_bit_cast(int, fbits);
-		}
 		/* transmits of the padding (a >= A) point far outside the buffer: they stage zeros */
-		stage_inv[n] = a < (uint32_t)A ? (a * (uint32_t)S + (uint32_t)(tfl + (int)(tid & (W - 1)))) * 8u : 0x80000000u;
+		stage_inv[n] = a < (uint32_t)A ? (a * (uint32_t)S + (uint32_t)(tfl[a] + (int)(tid & (W - 1)))) * 8u : 0x80000000u;
 	}
 	auto stage_load = [&](int channel, int rfl, f32x2 (&regs)[NL]) {
 		const uint32_t at = ((uint32_t)channel * (uint32_t)A * (uint32_t)S + (uint32_t)rfl) * 8u;
@@ -209,17 +214,23 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			regs[n] = __builtin_bit_cast(f32x2, v);
 		}
 	};
+	/* element j keeps {s_j, s_(j+1) - s_j}: the next sample sits in the next lane (a wave stages whole windows,
+	 * consecutive lanes consecutive samples), fetched with a one-lane wave shift.  The last element of a window gets
+	 * a meaningless difference and is never a term's FIRST tap (the host's window bound, plan_staged). */
 	auto stage_store = [&](const f32x2 (&regs)[NL]) {
 		#pragma unroll
 		for (int n = 0; n < NL; n++) {
+			const float sx = regs[n].x, sy = regs[n].y;
+			const float nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x130, 0xf, 0xf, false));
+			const float ny = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x130, 0xf, 0xf, false));
 			uint32_t e = tid + (uint32_t)n * nthreads;
-			if (e < stage_elements) stage[e] = regs[n];
+			if (e < stage_elements) stage[e] = f32x4{sx, sy, nx - sx, ny - sy};
 		}
 	};
 
 	for (int c0 = 0; c0 < C; c0 += chunk) {
 		const int cn = (C - c0) < chunk ? (C - c0) : chunk;
-		__syncthreads();        /* readers of the previous chunk's R / stage are done; T is complete */
+		__syncthreads();        /* readers of the previous chunk's R / stage are done; the transmit tables are complete */
 		for (uint32_t e = tid; e < (uint32_t)cn * U; e += nthreads) {
 			uint32_t c = (uint32_t)c0 + (e >> q.u_shift), iu = e & (U - 1);
 			float coord[3] = {0.f, 0.f, pz};
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 
 			/* (register budget: 64 per lane at 8 waves per SIMD with the next channel's windows in flight.  The
 			 * receive entry is read twice -- delay and aperture test here, phasor and weight after the loop -- and the
-			 * lane's table address is rebuilt per channel rather than kept) */
+			 * lane's table addresses are rebuilt per channel rather than kept) */
 			float r_x, r_w;
 			{
 				const f32x4 r = Rl[(size_t)cl * U];
@@ -276,8 +287,8 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			const float r_rel = r_x - (float)rfl;                          /* exact: position of the lane's receive delay in the window */
 			f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 			float mag = 0.f;
-			auto term = [&](f32x2 cs, float frac, f32x2 s0, f32x2 s1) {
-				f32x2 sv = s0 + frac * (s1 - s0);
+			auto term = [&](f32x2 cs, float frac, f32x4 tap) {
+				f32x2 sv = f32x2{tap.x, tap.y} + frac * f32x2{tap.z, tap.w};
 				acc1 += sv.x * cs;
 				acc2 += sv.y * cs;
 				if constexpr (CW) mag += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
@@ -288,34 +299,35 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				constexpr bool CHECK = decltype(checked)::value;
 				uint32_t lane_id = tid;
 				asm volatile("" : "+v"(lane_id));                          /* not hoisted: see the register budget above */
-				uint32_t t_at = t_base + ((u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1)) << 4), row_at = stage_b;
-				for (int a = 0; a < A4; a += 4, t_at += 4u * V * 16u, row_at += 4u * W * 8u) {
-					/* the unchecked loop reads 12 of an entry's 16 bytes (ds_read_b96): 4 registers fewer in flight */
-					using TE = typename std::conditional<CHECK, f32x4, f32x3>::type;
-					using LTE = typename std::conditional<CHECK, lds_f32x4, lds_f32x3>::type;
-					TE t[4]; float frac[4]; uint32_t at[4]; f32x2 s0[4], s1[4];
-					#pragma unroll
-					for (int k = 0; k < 4; k++) t[k] = *(LTE *)(uintptr_t)(t_at + (uint32_t)k * V * 16u);
+				const uint32_t lane_v = u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1);
+				uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3), row_at = stage_b;
+				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, row_at += 4u * W * 16u) {
+					float frac[4]; uint32_t at[4]; f32x4 tap[4];
+					const f32x4 cs01 = *(lds_f32x4 *)(uintptr_t)tcs_at;
+					const f32x4 cs23 = *(lds_f32x4 *)(uintptr_t)(tcs_at + V * 16u);
+					const f32x2 tz01 = *(lds_f32x2 *)(uintptr_t)tz_at;
+					const f32x2 tz23 = *(lds_f32x2 *)(uintptr_t)(tz_at + V * 8u);
+					const float tz[4] = {tz01.x, tz01.y, tz23.x, tz23.y};
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
-						float rel = r_rel + t[k].z;
+						float rel = r_rel + tz[k];
 						frac[k] = hw_fract(rel);
 						int ki  = cvt_floor_i32(rel);
-						at[k]   = ((uint32_t)ki << 3) + row_at;
+						at[k]   = ((uint32_t)ki << 4) + row_at;
 						if constexpr (CHECK) {
-							const float tb = t[k][3];
-							uint32_t k_abs = (uint32_t)(ki + rfl + __builtin_bit_cast(int, tb));
-							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 8u : stage_b + zero_element * 8u;
+							uint32_t k_abs = (uint32_t)(ki + rfl + tfl[a + k]);
+							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : stage_b + stage_elements * 16u;
 						}
 					}
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
-						const uint32_t row_k = CHECK ? 0u : (uint32_t)k * W * 8u;      /* immediate offset of the LDS read */
-						s0[k] = *(volatile lds_f32x2 *)(uintptr_t)(at[k] + row_k);
-						s1[k] = *(volatile lds_f32x2 *)(uintptr_t)(at[k] + row_k + 8u);
+						const uint32_t row_k = CHECK ? 0u : (uint32_t)k * W * 16u;     /* immediate offset of the LDS read */
+						tap[k] = *(lds_f32x4 *)(uintptr_t)(at[k] + row_k);
 					}
-					#pragma unroll
-					for (int k = 0; k < 4; k++) term(f32x2{t[k].x, t[k].y}, frac[k], s0[k], s1[k]);
+					term(f32x2{cs01.x, cs01.y}, frac[0], tap[0]);
+					term(f32x2{cs01.z, cs01.w}, frac[1], tap[1]);
+					term(f32x2{cs23.x, cs23.y}, frac[2], tap[2]);
+					term(f32x2{cs23.z, cs23.w}, frac[3], tap[3]);
 				}
 			};
 			if (wave_safe) batches(std::false_type{});

@@ -473,7 +473,8 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			if (((uint64_t)A4 << ws) > ((uint64_t)4 << threads_shift)) continue;  /* BF_STAGE_MAX_LOADS */
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
-				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A4 << vs)) + 8ull * (((uint64_t)A4 << ws) + 2) + 4ull * cc;
+				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
+				uint64_t lds = 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 1) + 4ull * (A4 + cc) + 128;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
 				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = 2048u >> threads_shift;
