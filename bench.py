@@ -42,7 +42,7 @@ PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-dela
 KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
                 "das_hercules_kernel"]
 # the sources whose hash ties a committed PMC figure to the code that produced it (tools/pmc_das.py)
-KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_hercules.hip", "bf_kernels.h"]
+KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_hercules.hip", "bf_kernels.h"]
 
 
 def parse():
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU-baseline budget (DAS time summed over its three legs)")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 3 prefer the LDS-staged kernel, 4 factored kernel wherever it applies, 6 HERCULES aligned-grid kernel also on narrow grids")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 2 auto without the LDS-staged kernel (the gather kernel instead), 3 LDS-staged kernel wherever its window bound holds, 4 factored kernel wherever it applies, 6 HERCULES aligned-grid kernel also on narrow grids")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="multi-GPU: broadcast and compute back to back on one stream instead of pipelined")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -358,7 +358,7 @@ def main():
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
                          "compulsory HBM traffic is ~1e4x smaller (BASELINE.md section 4)",
-                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s),
+                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s, pairs_local),
             },
         }
         if not args.no_cpu_baseline and n_gpus == 1:
@@ -397,39 +397,55 @@ def measured_traffic(config, kernel):
                                           f"`{entry.get('command', 'bench.py')}`, kernel sources {entry.get('kernel_source_sha16')}")
 
 
-def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s):
-    """The physical resource that limits the DAS launch, priced against measured ceilings:
-      * the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up to
-        16 bytes per lane takes 16 clocks per CU whatever its width (tools/microbench.hip, pattern
-        "das_like", window resident in L1) -- achieved is measured live in this run;
-      * VALU issue: busy fraction of the SIMDs from the committed PMC pass of this kernel (not live)."""
+def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, terms):
+    """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
+      * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
+        to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
+      * the LDS-staged kernel -- VALU issue: the 11-instruction stream of one (voxel, channel, transmit) term, measured
+        as a stream with no memory instruction in it ("valu_stream");
+    achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
     try:
         with open(os.path.join(ROOT, "profiles", "r02_microbench.json")) as f:
             micro = json.load(f)
-        inst = "global_load_dwordx4" if bytes_per_gather >= 16 else "global_load_dwordx2" if bytes_per_gather == 8 else "global_load_dword"
-        rows = [g for g in micro["gather"] if g["inst"] == inst and g["level"] == "L1" and g["pattern"] == "das_like"]
-        best = max(rows, key=lambda g: g["bytes_per_clk_per_cu_wall"])
         cus = int(micro["compute_units"])
-        # a gather of 2 x 16 bytes per lane (cubic IQ) is two such instructions: same bytes per clock
-        peak = best["bytes_per_clk_per_cu_wall"] * cus * best["clock_ghz"] * 1e9
-        out = {
-            "resource": f"per-CU vector-memory (texture-address) path: {inst} per-lane gathers, {64 * min(bytes_per_gather, 16) / best['bytes_per_clk_per_cu_wall']:.1f} clk per wave64 instruction",
-            "achieved": gather_bytes / das_s / 1e9, "unit": "GB/s",
-            "peak": peak / 1e9,
-            "peak_model": f"{best['bytes_per_clk_per_cu_wall']:.1f} B/clk/CU (measured, L1-resident window, DAS-like addresses, {best['waves_per_simd']} waves/SIMD) x {cus} CUs x {best['clock_ghz']:.3f} GHz (clock sustained in that probe)",
-            "frac": gather_bytes / das_s / peak,
-            "peak_bytes_per_clk_per_cu": best["bytes_per_clk_per_cu_wall"], "probe_clock_ghz": best["clock_ghz"],
-            "source": "profiles/r02_microbench.json (tools/microbench.hip); achieved measured in this run",
-        }
+        if kernel == "das_rca_staged_kernel":
+            best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8), key=lambda v: v["cycles_per_term_per_simd_wall"])
+            per_term = best["cycles_per_term_per_simd_wall"]
+            peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / per_term          # terms per second with every SIMD issuing nothing else
+            out = {
+                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the term's 11-instruction stream (no memory instructions)",
+                "achieved": terms / das_s / 1e12, "unit": "T terms/s (terms that pass the f-number test)",
+                "peak": peak / 1e12,
+                "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_term:.2f} clk",
+                "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_term_per_simd": per_term,
+                "source": "profiles/r02_microbench.json valu_stream (tools/microbench.hip term_probe); achieved measured in this run",
+            }
+        else:
+            inst = "global_load_dwordx4" if bytes_per_gather >= 16 else "global_load_dwordx2" if bytes_per_gather == 8 else "global_load_dword"
+            rows = [g for g in micro["gather"] if g["inst"] == inst and g["level"] == "L1" and g["pattern"] == "das_like"]
+            best = max(rows, key=lambda g: g["bytes_per_clk_per_cu_wall"])
+            # a gather of 2 x 16 bytes per lane (cubic IQ) is two such instructions: same bytes per clock
+            peak = best["bytes_per_clk_per_cu_wall"] * cus * best["clock_ghz"] * 1e9
+            out = {
+                "resource": f"per-CU vector-memory (texture-address) path: {inst} per-lane gathers, {64 * min(bytes_per_gather, 16) / best['bytes_per_clk_per_cu_wall']:.1f} clk per wave64 instruction",
+                "achieved": gather_bytes / das_s / 1e9, "unit": "GB/s",
+                "peak": peak / 1e9,
+                "peak_model": f"{best['bytes_per_clk_per_cu_wall']:.1f} B/clk/CU (measured, L1-resident window, DAS-like addresses, {best['waves_per_simd']} waves/SIMD) x {cus} CUs x {best['clock_ghz']:.3f} GHz (clock sustained in that probe)",
+                "frac": gather_bytes / das_s / peak,
+                "peak_bytes_per_clk_per_cu": best["bytes_per_clk_per_cu_wall"], "probe_clock_ghz": best["clock_ghz"],
+                "source": "profiles/r02_microbench.json (tools/microbench.hip); achieved measured in this run",
+            }
     except (OSError, KeyError, ValueError):
-        out = {"resource": "unpriced: profiles/r02_microbench.json missing"}
+        out = {"resource": "unpriced: profiles/r02_microbench.json missing or without the probe this kernel needs"}
     try:
         with open(os.path.join(ROOT, "profiles", "r02_das_bound.json")) as f:
             bound = json.load(f)
         entry = bound[f"config{config}"][kernel]
         out["valu_busy_frac"] = entry["valu_busy_frac"]
         out["ta_busy_frac"] = entry.get("ta_busy_frac")
+        if entry.get("lds_idx_active_frac") is not None:
+            out["lds_idx_active_frac"] = entry["lds_idx_active_frac"]
         # The chip lowers its clock under this kernel (the probe's loop sustains more): cycles the launch was
         # resident (GRBM_GUI_ACTIVE / 8 of the committed whole-frame PMC pass) over this run's kernel time
         # estimate the clock it actually held; against the ceiling at THAT clock the kernel sits higher.
@@ -439,7 +455,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s):
             out["frac_at_sustained_clock"] = out["frac"] * out["probe_clock_ghz"] / clock
         out["valu_source"] = (f"profiles/r02_das_bound.json: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
                               f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash() else " (STALE: sources changed since)"))
-        if entry["valu_busy_frac"] > out.get("frac", 0):
+        if kernel != "das_rca_staged_kernel" and entry["valu_busy_frac"] > out.get("frac", 0):
             out["resource_note"] = "VALU issue is the tighter bound for this kernel (valu_busy_frac)"
     except (OSError, KeyError, ValueError):
         pass

@@ -157,13 +157,14 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold
  * the pipeline also demodulates (beamformer_core.c:567) and makes the pipeline IQ (:589). */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
 
-/* Select the DAS implementation: 0 = automatic (the separable-delay gather kernel when the
- * geometry allows and the interpolation is linear, else the per-voxel factored kernel for
- * RCA-family and FORCES frames with three or more transmits, else the gather kernel where the
- * geometry allows, else the general kernel), 1 = always the general kernel, 4 = the
- * factored kernel wherever it applies (also ahead of the gather kernel), 3 = prefer the
- * LDS-staged variant of the separable kernel where its window bound holds (measured slower
- * than the gather kernel on MI355X -- the path is VALU bound -- and kept as an experiment).
+/* Select the DAS implementation: 0 = automatic.  Row-column frames whose receive aperture and transmit
+ * steering lie along different array axes (separable delays) and that use linear interpolation run the
+ * LDS-staged kernel (das_staged.hip: complex samples, a tile's delay spread inside its LDS window, at least
+ * 12 transmits per channel) or else the gather kernel (das_separable.hip); otherwise the per-voxel factored
+ * kernel takes RCA-family and FORCES frames with three or more transmits, the gather kernel the remaining
+ * separable ones, the general kernel everything else.  1 = always the general kernel, 2 = as automatic but
+ * never the LDS-staged kernel, 3 = the LDS-staged kernel wherever its window bound holds (also below 12
+ * transmits), 4 = the factored kernel wherever it applies (also ahead of the gather kernel).
  * HERCULES-family frames whose grid is aligned with the array (one lateral transducer coordinate a
  * function of the output row alone) and at least 32 voxels wide run the aligned-grid kernel
  * (das_hercules.hip) in every mode but 1; 6 = that kernel also on narrow grids (idle lanes).
@@ -174,7 +175,8 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
 typedef enum {
 	BeamformerHipDasPath_Automatic        = 0,
 	BeamformerHipDasPath_General          = 1,    /* das.hip for every frame */
-	BeamformerHipDasPath_PreferLdsStaged  = 3,    /* das_staged.hip where its window bound holds */
+	BeamformerHipDasPath_NoLdsStaging     = 2,    /* automatic, but das_separable.hip where das_staged.hip would run */
+	BeamformerHipDasPath_PreferLdsStaged  = 3,    /* das_staged.hip wherever its window bound holds */
 	BeamformerHipDasPath_PreferFactored   = 4,    /* das_factored.hip wherever the index factorises */
 	BeamformerHipDasPath_HerculesAnyWidth = 6,    /* das_hercules.hip also on grids narrower than 32 voxels */
 	BeamformerHipDasPath_NoChannelSplit   = 0x10, /* flag: general kernel at one thread per voxel for small frames too */

@@ -589,6 +589,7 @@ static bool factored_applies(const BfDasArgs &a, const std::vector<BfTransmit> &
  * per-stage events on one frame in kTimingSamplePeriod; the frames in between run with no event
  * at all and report the newest sampled timings in the stats table. */
 constexpr uint64_t kTimingSamplePeriod = 8;
+constexpr uint32_t kStagedMinTransmits = 12;     /* das_staged.hip by default from this many transmits per channel (tools/staged_threshold.py: 0.94 of the gather kernel's time at 12, 0.83 at 16, 0.73-0.76 at 32-75) */
 constexpr uint64_t kSmallFrameBytes    = 8ull << 20;
 
 static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
@@ -847,7 +848,10 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					sep.zero_offset = (uint32_t)used;
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					if ((c.das_path_mode & 0xF) == 3 && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+					/* the LDS-staged kernel pays two block barriers and a window copy per channel: it wins once a channel
+					 * carries enough transmits to amortise them (kStagedMinTransmits, measured: tools/staged_threshold.py) */
+					const bool want_staged = das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits);
+					if (want_staged && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 						ok &= HIP_OK(bf_launch_das_staged(&a, &sep, s));
 						das_path = 2;
 					} else {

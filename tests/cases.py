@@ -46,6 +46,10 @@ def _cases():
                                                angles=np.linspace(-10, 10, 3))
     c["rca_staged_ragged"] = lambda: cfg.rca("rca_staged_ragged", 48, 7, 512, (45, 70, 2), LO3, HI3, seed=45,
                                              orientation=0x21, cw=True, f_number=0.6, angles=np.linspace(-12, 12, 7))
+    # 13 transmits: at or above executor.cpp's kStagedMinTransmits the staged kernel is the automatic choice (and 13 is not
+    # a multiple of 4: the zero-padded transmit batch)
+    c["rca_staged_auto"] = lambda: cfg.rca("rca_staged_auto", 32, 13, 512, (40, 36, 3), LO3, HI3, seed=46, orientation=0x12,
+                                           cw=True, f_number=0.6, angles=np.linspace(-12, 12, 13))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

@@ -82,6 +82,15 @@ def test_full_size_frame_properties(bflib, oracle, config4):
     assert np.array_equal(np.isnan(fast), np.isnan(general))
     assert np.abs(fast[ok] - general[ok]).max() / np.abs(fast[ok]).max() < 1e-4
 
+    # (6) the automatic choice is the LDS-staged kernel; the gather kernel it replaced agrees on the same slab
+    t = P.HipFrameTimings()
+    run(bflib, acq, shard=(250, 4))
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 2
+    gathered = run(bflib, acq, shard=(250, 4), path=2)
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 1
+    assert np.array_equal(np.isnan(fast), np.isnan(gathered))
+    assert np.abs(fast[ok] - gathered[ok]).max() / np.abs(fast[ok]).max() < 1e-4
+
 
 def test_full_size_linearity(bflib, config4):
     """B(a x + b y) = a B(x) + b B(y) for the whole pipeline without coherency weighting
@@ -158,7 +167,8 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
                                                 (P.InterpolationMode.Nearest, True, (257, 96, 19))])
 def test_odd_shapes_at_medium_size(interp, cw, points, bflib, oracle):
     """200 channels x 33 transmits into grids that are no multiple of any tile, on the automatic
-    path, the factored kernel and the general kernel: oracle rows of the middle plane."""
+    path (linear: the LDS-staged kernel), the gather kernel, the factored kernel and the general kernel: oracle
+    rows of the middle plane."""
     path = 0.40 * 3072 / 25e6 * 1540.0
     acq = cfg.rca("odd", 200, 33, 3072, points, (-14e-3, -9e-3, 0.15 * path), (14e-3, 9e-3, 0.40 * path), seed=5,
                   orientation=0x12, interp=interp, cw=cw, f_number=0.7, angles=np.linspace(-14, 14, 33))
@@ -167,7 +177,7 @@ def test_odd_shapes_at_medium_size(interp, cw, points, bflib, oracle):
     ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters, z=(z, 1), y=(y0, 4), threads=16, flags=flags)
     ok = ~np.isnan(ref)
     seen = set()
-    for mode in (0, 4, 1):
+    for mode in (0, 2, 4, 1):
         gpu = run(bflib, acq, path=mode)
         t = P.HipFrameTimings()
         assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
@@ -190,7 +200,7 @@ def test_odd_shapes_at_medium_size(interp, cw, points, bflib, oracle):
             assert np.median(err) < 1e-4
         else:
             assert err.max() <= 2e-3                                          # Int16 -> f16-staged Demodulate
-    assert seen == ({1, 3, 0} if interp == P.InterpolationMode.Linear else {3, 0})
+    assert seen == ({2, 1, 3, 0} if interp == P.InterpolationMode.Linear else {3, 0})
 
 
 def _f32c_rca(name, C, A, points, lo, hi, *, seed, interp, cw, pitch, f_number, orientation, angles, scatterer):
@@ -241,8 +251,10 @@ def _rows_against_oracle(frame, acq, oracle, selections, peak, local_tol=5e-4):
     return worst
 
 
-def test_config4_f32_complex_rows_at_the_edges_of_the_volume(bflib, oracle):
-    """Config 4's geometry (256 ch x 75 tx -> 512^3, coherency weighting, headline kernel) on
+@pytest.mark.parametrize("das_mode, kernel", [(0, 2), (2, 1)], ids=["staged", "gather"])
+def test_config4_f32_complex_rows_at_the_edges_of_the_volume(das_mode, kernel, bflib, oracle):
+    """Config 4's geometry (256 ch x 75 tx -> 512^3, coherency weighting; the headline kernel -- LDS-staged,
+    the automatic choice -- and the gather kernel it replaced) on
     Float32Complex RF: three rows at each of z, y in {first, middle, last}, plus the scatterer's rows,
     against the float oracle -- first and last planes, tile corners, the range-checked inner loop (rows
     whose index leaves the RF at the volume's edges) and the tail of the XCD tile walk."""
@@ -253,9 +265,9 @@ def test_config4_f32_complex_rows_at_the_edges_of_the_volume(bflib, oracle):
     acq = _f32c_rca("config4_f32c", 256, 75, (512, 512, 512), (-half, -half, z0), (half, half, z1), seed=4,
                     interp=P.InterpolationMode.Linear, cw=True, pitch=0.15e-3, f_number=0.5, orientation=0x12,
                     angles=np.linspace(-18.5, 18.5, 75), scatterer=scatterer)
-    frame = run(bflib, acq)
+    frame = run(bflib, acq, path=das_mode)
     t = P.HipFrameTimings()
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 1
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == kernel
     mag = np.abs(np.nan_to_num(frame))
     pz, py, px = np.unravel_index(np.argmax(mag), mag.shape)
     want = (np.array(scatterer) - np.array([-half, -half, z0])) / np.array([2 * half, 2 * half, z1 - z0]) * 511

@@ -59,10 +59,12 @@ def last_das_path(bflib):
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
 # them up on its own (das_separable.hip)
 SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest",
-             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged"}
+             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto"}
 # ... and of those, the linear-interpolation complex ones whose delay spread fits an LDS window
-# can run the LDS-staged variant (das_staged.hip, opt-in: it is slower on MI355X)
-STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged"}
+# can run the LDS-staged kernel (das_staged.hip): automatically from STAGED_MIN_TRANSMITS transmits per
+# channel (executor.cpp kStagedMinTransmits), on request (path 3) below that
+STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto"}
+STAGED_MIN_TRANSMITS = 12
 
 
 def factored_applies(bp):
@@ -100,7 +102,7 @@ def expected_path(name, bp):
     # factored kernel does where it applies (executor.cpp), the table kernel otherwise
     if name in SEPARABLE and (bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp)
                               or bp.acquisition_count < 3):
-        return 1
+        return 2 if name in STAGED and bp.acquisition_count >= STAGED_MIN_TRANSMITS else 1
     transmits = bp.acquisition_count - (1 if P.AcquisitionKind(bp.acquisition_kind) == P.AcquisitionKind.UFORCES else 0)
     return 3 if factored_applies(bp) and transmits >= 3 else 0
 
@@ -131,10 +133,25 @@ def test_general_kernel_on_separable_geometry(name, bflib, oracle):
     compare(gpu, ref, acq, flags)
 
 
+@pytest.mark.parametrize("name", sorted(STAGED))
+def test_gather_kernel_where_the_staged_kernel_applies(name, bflib, oracle):
+    """path 2: the separable-delay gather kernel, never staged"""
+    acq = cases.make(name)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    lib.beamformer_hip_set_das_path(2)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == 1
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq, flags)
+
+
 @pytest.mark.parametrize("name", sorted(SEPARABLE))
 def test_lds_staged_kernel(name, bflib, oracle):
-    """the opt-in LDS-staged variant; geometries outside its window bound fall back to the
-    gather kernel"""
+    """the LDS-staged kernel on request (these acquisitions have fewer transmits than its automatic
+    threshold); geometries outside its window bound fall back to the gather kernel"""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()

@@ -36,9 +36,9 @@ __device__ __forceinline__ uint64_t memtime()     { return __builtin_amdgcn_s_me
 __device__ __forceinline__ uint64_t memrealtime() { return __builtin_amdgcn_s_memrealtime(); }
 
 /* ------------------------------------------------------------------ VALU issue */
-enum { OP_FMA, OP_PK_FMA, OP_SQRT, OP_SIN, OP_RCP, OP_CVT_FLR, OP_FRACT, OP_MUL, OP_COUNT };
+enum { OP_FMA, OP_PK_FMA, OP_SQRT, OP_SIN, OP_RCP, OP_CVT_FLR, OP_FRACT, OP_MUL, OP_ADD, OP_LSHL_ADD, OP_PK_ADD, OP_COUNT };
 static const char *op_name[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_sqrt_f32", "v_sin_f32", "v_rcp_f32",
-                                        "v_cvt_flr_i32_f32", "v_fract_f32", "v_mul_f32"};
+                                        "v_cvt_flr_i32_f32", "v_fract_f32", "v_mul_f32", "v_add_f32", "v_lshl_add_u32", "v_pk_add_f32"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, int iters)
@@ -57,6 +57,9 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 			for (int k = 0; k < 8; k++) {
 				if constexpr (OP == OP_FMA)     asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
 				if constexpr (OP == OP_MUL)     asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+				if constexpr (OP == OP_ADD)     asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+				if constexpr (OP == OP_LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[k]) : "v"(b));
+				if constexpr (OP == OP_PK_ADD)  asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pc));
 				if constexpr (OP == OP_PK_FMA)  asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pb), "v"(pc));
 				if constexpr (OP == OP_SQRT)    asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
 				if constexpr (OP == OP_SIN)     asm volatile("v_sin_f32 %0, %0" : "+v"(a[k]));
@@ -70,6 +73,48 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 	float s = 0.f;
 	for (int k = 0; k < 8; k++) s += a[k] + p[k].x + p[k].y;
 	if (s == 12345.678f) sink[0] = s;
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		stamps[wave] = Stamp{t1 - t0, r1 - r0};
+	}
+}
+
+/* ------------------------------------------------------------------ the VALU stream of one DAS term
+ * What das_staged.hip's unchecked inner loop issues per (voxel, channel, transmit) term once the taps and
+ * the table entries are in registers -- window position, tap address, interpolation, rotate-accumulate,
+ * |s| for coherency weighting: 11 VALU instructions, here with four independent terms per iteration and
+ * no memory instruction at all.  Its rate is the ceiling of a kernel that is bound by VALU issue. */
+__global__ __launch_bounds__(1024) void term_probe(Stamp *stamps, float *sink, int iters)
+{
+	float r = 3.25f + 0.01f * (float)(threadIdx.x & 63), tz[4], mag = 0.f;
+	f32x2 tap_s[4], tap_d[4], cs[4], acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+	for (int k = 0; k < 4; k++) {
+		tz[k] = 1.5f + (float)k; tap_s[k] = f32x2{0.5f + k, 0.25f}; tap_d[k] = f32x2{0.125f, -0.5f};
+		cs[k] = f32x2{0.6f, 0.8f};
+	}
+	uint32_t base = 4096;
+	asm volatile("" : "+s"(base));
+	__syncthreads();
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			/* plain C++ so that hipcc schedules the four terms of an iteration against each other exactly as it does in
+			 * the kernel; the empty asm statements make the inputs opaque (nothing is hoisted) without issuing anything */
+			asm volatile("" : "+v"(tz[k]), "+v"(tap_s[k]), "+v"(tap_d[k]), "+v"(cs[k]));
+			float rel  = r + tz[k];
+			float frac = __builtin_amdgcn_fractf(rel);
+			int ki; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ki) : "v"(rel));
+			uint32_t at = ((uint32_t)ki << 4) + base;
+			f32x2 sv = tap_s[k] + frac * tap_d[k];
+			acc1 += sv.x * cs[k];
+			acc2 += sv.y * cs[k];
+			mag += __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+			asm volatile("" :: "v"(at));
+		}
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (mag + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag;
 	if ((threadIdx.x & 63) == 0) {
 		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 		stamps[wave] = Stamp{t1 - t0, r1 - r0};
@@ -251,6 +296,24 @@ template <int OP> static void valu_case(bool first)
 	}
 }
 
+static void term_case()
+{
+	const int iters = 40000;                           /* 160k terms per wave */
+	bool first = true;
+	for (int wps : {4, 8}) {
+		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
+		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
+		Result r = run([&] { hipLaunchKernelGGL(term_probe, dim3(blocks), dim3(64 * waves_per_block), 0, 0, d_stamps, d_sink, iters); }, waves);
+		double terms = 4.0 * iters;
+		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+		emit("%s{\"stream\":\"das_staged term: v_add_f32, v_fract_f32, v_cvt_flr_i32_f32, v_lshl_add_u32, 3 x v_pk_fma_f32, v_mul_f32, v_fmac_f32, "
+		     "v_sqrt_f32, v_add_f32 (+ v_add_u32 of the loop counter per 4 terms)\",\"waves_per_simd\":%d,\"cycles_per_term_per_simd_wall\":%.3f,"
+		     "\"cycles_per_term_per_simd_stamps\":%.3f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", first ? "" : ",\n  ",
+		     wps, wall_cycles / (terms * wps), r.cycles_per_wave / (terms * wps), r.clock_ghz, r.wall_ms);
+		first = false;
+	}
+}
+
 static char *d_window;
 
 template <int WIDTH, int PAT> static void gather_case(const char *level, uint32_t window, bool per_block, bool &first)
@@ -320,6 +383,12 @@ int main(int argc, char **argv)
 	valu_case<OP_RCP>(false);
 	valu_case<OP_CVT_FLR>(false);
 	valu_case<OP_FRACT>(false);
+	valu_case<OP_ADD>(false);
+	valu_case<OP_LSHL_ADD>(false);
+	valu_case<OP_PK_ADD>(false);
+	emit("],\n");
+	emit(" \"valu_stream\":[\n  ");
+	term_case();
 	emit("],\n");
 
 	bool first = true;

@@ -51,6 +51,9 @@ def main():
                 e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * SIMDS)
             if "TA_BUSY_avr" in c:
                 e["ta_busy_frac"] = c["TA_BUSY_avr"] / cycles
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                e["lds_idx_active_frac"] = c["SQ_LDS_IDX_ACTIVE"] / (cycles * 256)          # cycles the LDS index unit was busy, per CU
+                e["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, c["SQ_LDS_IDX_ACTIVE"])
             if c.get("SQ_INSTS_VMEM_RD"):
                 g = c["SQ_INSTS_VMEM_RD"]
                 e["per_gather_instruction"] = {
@@ -71,7 +74,8 @@ def main():
             else:
                 # a second run of the same kernel (e.g. the TA/TCP groups taken on a slab): derived fractions the first
                 # run lacks are added, raw counters are kept apart under the run's own label
-                for k in ("valu_busy_frac", "ta_busy_frac", "l1_hit_rate", "l2_hit_rate", "per_gather_instruction", "mean_resident_waves_per_cu"):
+                for k in ("valu_busy_frac", "ta_busy_frac", "l1_hit_rate", "l2_hit_rate", "per_gather_instruction", "mean_resident_waves_per_cu",
+                          "lds_idx_active_frac", "lds_bank_conflict_frac"):
                     if k in e and k not in have:
                         have[k] = e[k]
                         have.setdefault("also_from", {})[k] = s["command"]
