@@ -401,8 +401,8 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
         to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
-      * the LDS-staged kernel -- VALU issue: the 11-instruction stream of one (voxel, channel, transmit) term, measured
-        as a stream with no memory instruction in it ("valu_stream");
+      * the LDS-staged kernel -- VALU issue: the inner loop's VALU stream (38 instructions per 4 (voxel, channel,
+        transmit) terms), measured as a stream with no memory instruction in it ("valu_stream", shipping form);
     achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
     try:
@@ -410,11 +410,12 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             micro = json.load(f)
         cus = int(micro["compute_units"])
         if kernel == "das_rca_staged_kernel":
-            best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8), key=lambda v: v["cycles_per_term_per_simd_wall"])
+            best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8 and "shipping form" in v["stream"]),
+                       key=lambda v: v["cycles_per_term_per_simd_wall"])
             per_term = best["cycles_per_term_per_simd_wall"]
             peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / per_term          # terms per second with every SIMD issuing nothing else
             out = {
-                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the term's 11-instruction stream (no memory instructions)",
+                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the inner loop's 38 VALU instructions per 4 terms, measured as a stream with no memory instruction in it",
                 "achieved": terms / das_s / 1e12, "unit": "T terms/s (terms that pass the f-number test)",
                 "peak": peak / 1e12,
                 "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_term:.2f} clk",

@@ -58,11 +58,12 @@ __device__ __forceinline__ float staged_phase_turns(float k, float index)
 /* LDS (A4 = transmits rounded up to a multiple of 4; transmits are kept in PAIRS so that one read serves two terms):
  *   Tcs[(a/2)*V + v] = { cos(phi_t), sin(phi_t) of transmit a & ~1, then of transmit a | 1 }          f32x4
  *   R[cl*U + u]      = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }     cl: channel in chunk   f32x4
- *   stage[a*W + j]   = { s, s' - s }: sample floor(rmin_c) + floor(tmin_a) + j of row (c, a) and its
- *                      difference to the next sample; j < W, a < A4; then one zero element               f32x4
- *   Tz[(a/2)*V + v]  = { T' = t_index - floor(tmin_a) of transmit a & ~1, of transmit a | 1 }            f32x2
+ *   stage[a*W + j]   = { (s + s') / 2, s' - s }: s = sample floor(rmin_c) + floor(tmin_a) + j of row (c, a), s' the
+ *                      next one -- midpoint and difference; j < W, a < A4; then one zero element         f32x4
+ *   Tz[(a/2)*V + v]  = { T'' = t_index - floor(tmin_a) - 1/2 of transmit a & ~1, of transmit a | 1 }     f32x2
  *   tfl[a]           = floor(tmin_a)  (checked loop and staging only),  rfloor[cl] = floor(rmin_c)       int
- * Keeping {s, s' - s} makes the two taps ONE 16-byte aligned read and the interpolation one packed fma. */
+ * Keeping {midpoint, difference} makes the two taps ONE 16-byte aligned read and the interpolation one packed fma
+ * of the position relative to the middle of the pair. */
 /* NL: window elements a thread stages per channel, ceil(A4 * W / threads) */
 template <bool CW, int VS, int WS, int NL>
 __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs p, const BfSeparableArgs q)
@@ -73,12 +74,15 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
 	const int A4 = (A + 3) & ~3;
 	const int chunk = (int)q.channel_chunk;
-	f32x4 *Tcs    = staged_lds;
+	/* the staging area comes first and the kernel has no static LDS: 16 x (a window element's index + 1) IS its LDS
+	 * address, which the inner loop forms with one 24-bit multiply */
+	f32x4 *stage  = staged_lds + 1;                          /* (one unused element in front: see the magic number of the inner loop) */
+	f32x4 *Tcs    = stage + (size_t)A4 * W + 1;
 	f32x4 *R      = Tcs + (size_t)(A4 / 2) * V;
-	f32x4 *stage  = R + (size_t)chunk * U;
-	f32x2 *Tz     = reinterpret_cast<f32x2 *>(stage + (size_t)A4 * W + 1);
+	f32x2 *Tz     = reinterpret_cast<f32x2 *>(R + (size_t)chunk * U);
 	int   *tfl    = reinterpret_cast<int *>(Tz + (size_t)(A4 / 2) * V);
 	int   *rfloor = tfl + A4;
+	f32x2 *wave_range = reinterpret_cast<f32x2 *>(rfloor + ((chunk + 1) & ~1));      /* 16 entries, 8-byte aligned */
 	const uint32_t stage_elements = (uint32_t)A4 * W;
 
 	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
@@ -133,7 +137,6 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	}
 	if (tid == 0) stage[stage_elements] = f32x4{0.f, 0.f, 0.f, 0.f};
 	/* tile-wide extremes of the absolute transmit delay (range-test shortcut, as das_separable.hip) */
-	__shared__ f32x2 wave_range[16];
 	__syncthreads();
 	{
 		float lo = __builtin_inff(), hi = -__builtin_inff();
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 		for (uint32_t iv = 1; iv < V; iv++) m = fminf(m, row[2 * iv]);
 		float fl = __builtin_floorf(m);
 		#pragma unroll 4
-		for (uint32_t iv = 0; iv < V; iv++) row[2 * iv] -= fl;
+		for (uint32_t iv = 0; iv < V; iv++) row[2 * iv] = (row[2 * iv] - fl) - 0.5f;      /* both steps exact */
 		tfl[a] = (int)fl;
 	}
 	__syncthreads();                                         /* the floors are read below */
@@ -184,10 +187,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	/* LDS byte addresses */
 	uint32_t tcs_base = (uint32_t)(uintptr_t)(lds_f32x4 *)Tcs;
 	uint32_t tz_base  = (uint32_t)(uintptr_t)(lds_f32x2 *)Tz;
-	uint32_t stage_b  = (uint32_t)(uintptr_t)(lds_f32x4 *)stage;
 	/* opaque to the compiler: otherwise the static LDS in front of the dynamic block is re-added as a constant
 	 * to every address of the inner loop instead of once here */
-	asm("" : "+s"(tcs_base), "+s"(tz_base), "+s"(stage_b));
+	asm("" : "+s"(tcs_base), "+s"(tz_base));
 
 	/* Staging.  Thread tid copies element j = tid % W of windows a_n = tid / W + n * (threads / W), n < NL:
 	 * sample rfl + floor(tmin_a) + j of row (channel, a).  The loads are buffer loads over the whole DAS
@@ -221,10 +223,11 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 		#pragma unroll
 		for (int n = 0; n < NL; n++) {
 			const float sx = regs[n].x, sy = regs[n].y;
-			const float nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x130, 0xf, 0xf, false));
-			const float ny = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x130, 0xf, 0xf, false));
+			const float nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x130, 0xf, 0xf, true));
+			const float ny = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x130, 0xf, 0xf, true));
 			uint32_t e = tid + (uint32_t)n * nthreads;
-			if (e < stage_elements) stage[e] = f32x4{sx, sy, nx - sx, ny - sy};
+			const float dx = nx - sx, dy = ny - sy;
+			if (e < stage_elements) stage[e] = f32x4{__builtin_fmaf(0.5f, dx, sx), __builtin_fmaf(0.5f, dy, sy), dx, dy};
 		}
 	};
 
@@ -286,12 +289,14 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			const int   rfl   = rfloor[cl];
 			const float r_rel = r_x - (float)rfl;                          /* exact: position of the lane's receive delay in the window */
 			f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
-			float mag = 0.f;
-			auto term = [&](f32x2 cs, float frac, f32x4 tap) {
-				f32x2 sv = f32x2{tap.x, tap.y} + frac * f32x2{tap.z, tap.w};
+			f32x2 mag2 = {0.f, 0.f};
+			/* one term: g in [-0.5, 0.5] is the position relative to the MIDDLE of the tap pair, tap = {midpoint, difference} */
+			auto term = [&](f32x2 cs, float g, f32x4 tap) -> float {
+				f32x2 sv = f32x2{tap.x, tap.y} + g * f32x2{tap.z, tap.w};
 				acc1 += sv.x * cs;
 				acc2 += sv.y * cs;
-				if constexpr (CW) mag += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+				if constexpr (CW) return hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+				else return 0.f;
 			};
 			const bool lane_safe = (r_x + range.x >= 0.f) && (r_x + range.y < (float)(S - 1));
 			const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
@@ -300,34 +305,48 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				uint32_t lane_id = tid;
 				asm volatile("" : "+v"(lane_id));                          /* not hoisted: see the register budget above */
 				const uint32_t lane_v = u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1);
-				uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3), row_at = stage_b;
-				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, row_at += 4u * W * 16u) {
-					float frac[4]; uint32_t at[4]; f32x4 tap[4];
+				uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3);
+				/* Position -> tap without v_fract / v_cvt: adding M = 2^23 + (first window element of the batch) rounds the
+				 * (midpoint-relative) position to the nearest integer n and leaves the ELEMENT INDEX a*W + n in the low
+				 * mantissa bits, so that
+				 *     y = p + M;  n = y - M;  g = p - n        (packed: two terms per instruction, all three exact)
+				 * and the tap's LDS byte offset is (bits(y) & 0xFFFFFF) * 16 -- one 24-bit multiply, no add: M's own bit
+				 * pattern (0x4B000000 + a*W) contributes exactly a*W below bit 24.  M is a scalar, stepped by 4*W per batch
+				 * as an integer (the mantissa of a float in [2^23, 2^24) counts integers); term k's row k*W and the
+				 * staging area's base are the read's immediate offset. */
+				/* M starts at 2^23 + 1, not 2^23: a position of -1/2 (the lane with the smallest delays of the tile) must round
+				 * inside [2^23, 2^24) -- just below 2^23 floats step by 1/2 and 2^23 - 1/2 would come back exact, with garbage in
+				 * the low mantissa bits.  The staging area starts one element into the LDS to match. */
+				uint32_t m_bits = 0x4B000001u;
+				const f32x2 rr = {r_rel, r_rel};
+				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
+					uint32_t at[4]; f32x4 tap[4];
+					const float M = __builtin_bit_cast(float, m_bits);
+					const f32x2 M2 = {M, M};
 					const f32x4 cs01 = *(lds_f32x4 *)(uintptr_t)tcs_at;
 					const f32x4 cs23 = *(lds_f32x4 *)(uintptr_t)(tcs_at + V * 16u);
 					const f32x2 tz01 = *(lds_f32x2 *)(uintptr_t)tz_at;
 					const f32x2 tz23 = *(lds_f32x2 *)(uintptr_t)(tz_at + V * 8u);
-					const float tz[4] = {tz01.x, tz01.y, tz23.x, tz23.y};
+					const f32x2 p01 = rr + tz01, p23 = rr + tz23;
+					const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
+					const f32x2 g01 = p01 - (y01 - M2), g23 = p23 - (y23 - M2);
+					const float ys[4] = {y01.x, y01.y, y23.x, y23.y};
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
-						float rel = r_rel + tz[k];
-						frac[k] = hw_fract(rel);
-						int ki  = cvt_floor_i32(rel);
-						at[k]   = ((uint32_t)ki << 4) + row_at;
+						const uint32_t yb = __builtin_bit_cast(uint32_t, ys[k]);
+						asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at[k]) : "v"(yb));   /* (hipcc turns the builtin into shift + and); LDS address 0 = the staging area */
 						if constexpr (CHECK) {
-							uint32_t k_abs = (uint32_t)(ki + rfl + tfl[a + k]);
-							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : stage_b + stage_elements * 16u;
+							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfl + tfl[a + k]);      /* yb - m_bits = n */
+							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : (stage_elements + 1u) * 16u;
 						}
 					}
 					#pragma unroll
-					for (int k = 0; k < 4; k++) {
-						const uint32_t row_k = CHECK ? 0u : (uint32_t)k * W * 16u;     /* immediate offset of the LDS read */
-						tap[k] = *(lds_f32x4 *)(uintptr_t)(at[k] + row_k);
-					}
-					term(f32x2{cs01.x, cs01.y}, frac[0], tap[0]);
-					term(f32x2{cs01.z, cs01.w}, frac[1], tap[1]);
-					term(f32x2{cs23.x, cs23.y}, frac[2], tap[2]);
-					term(f32x2{cs23.z, cs23.w}, frac[3], tap[3]);
+					for (int k = 0; k < 4; k++) tap[k] = *(lds_f32x4 *)(uintptr_t)(at[k] + (CHECK ? 0u : (uint32_t)k * W * 16u));   /* immediate */
+					const float q0 = term(f32x2{cs01.x, cs01.y}, g01.x, tap[0]);
+					const float q1 = term(f32x2{cs01.z, cs01.w}, g01.y, tap[1]);
+					const float q2 = term(f32x2{cs23.x, cs23.y}, g23.x, tap[2]);
+					const float q3 = term(f32x2{cs23.z, cs23.w}, g23.y, tap[3]);
+					if constexpr (CW) { mag2 += f32x2{q0, q1}; mag2 += f32x2{q2, q3}; }
 				}
 			};
 			if (wave_safe) batches(std::false_type{});
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			const f32x4 r = *(volatile lds_f32x4 *)(uintptr_t)((uint32_t)(uintptr_t)(lds_f32x4 *)Rl + (uint32_t)cl * U * 16u);
 			coherent.x += sum.x * r.y - sum.y * r.z;
 			coherent.y += sum.x * r.z + sum.y * r.y;
-			if constexpr (CW) incoherent += r.w * mag;
+			if constexpr (CW) incoherent += r.w * (mag2.x + mag2.y);
 		}
 	}
 	if (!inside) return;

@@ -36,9 +36,12 @@ __device__ __forceinline__ uint64_t memtime()     { return __builtin_amdgcn_s_me
 __device__ __forceinline__ uint64_t memrealtime() { return __builtin_amdgcn_s_memrealtime(); }
 
 /* ------------------------------------------------------------------ VALU issue */
-enum { OP_FMA, OP_PK_FMA, OP_SQRT, OP_SIN, OP_RCP, OP_CVT_FLR, OP_FRACT, OP_MUL, OP_ADD, OP_LSHL_ADD, OP_PK_ADD, OP_COUNT };
+enum { OP_FMA, OP_PK_FMA, OP_SQRT, OP_SIN, OP_RCP, OP_CVT_FLR, OP_FRACT, OP_MUL, OP_ADD, OP_LSHL_ADD, OP_PK_ADD, OP_PK_ADD_SGPR, OP_PK_ADD_NEG,
+       OP_PK_FMA_SEL, OP_MUL_U24, OP_COUNT };
 static const char *op_name[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_sqrt_f32", "v_sin_f32", "v_rcp_f32",
-                                        "v_cvt_flr_i32_f32", "v_fract_f32", "v_mul_f32", "v_add_f32", "v_lshl_add_u32", "v_pk_add_f32"};
+                                        "v_cvt_flr_i32_f32", "v_fract_f32", "v_mul_f32", "v_add_f32", "v_lshl_add_u32", "v_pk_add_f32",
+                                        "v_pk_add_f32 (scalar-pair operand, op_sel_hi:[1,0])", "v_pk_add_f32 (neg_lo neg_hi on one operand)",
+                                        "v_pk_fma_f32 (op_sel_hi:[0,1,1]: one half broadcast)", "v_mul_u32_u24"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, int iters)
@@ -48,6 +51,8 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 	for (int k = 0; k < 8; k++) { a[k] = 1.0f + 0.001f * (float)(threadIdx.x + k); p[k] = f32x2{a[k], a[k] + 0.5f}; }
 	float b = 0.999f, c = 0.0001f;
 	f32x2 pb = {0.999f, 0.998f}, pc = {0.0001f, 0.0002f};
+	uint64_t spair = 0x3a83126f3a83126full;                  /* two small floats in a scalar register pair */
+	asm volatile("" : "+s"(spair));
 	__syncthreads();
 	uint64_t t0 = memtime(), r0 = memrealtime();
 	for (int i = 0; i < iters; i++) {
@@ -60,6 +65,10 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 				if constexpr (OP == OP_ADD)     asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
 				if constexpr (OP == OP_LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[k]) : "v"(b));
 				if constexpr (OP == OP_PK_ADD)  asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pc));
+				if constexpr (OP == OP_PK_ADD_SGPR) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[k]) : "s"(spair));
+				if constexpr (OP == OP_PK_ADD_NEG)  asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[k]) : "v"(pc));
+				if constexpr (OP == OP_PK_FMA_SEL)  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[k]) : "v"(pb), "v"(pc));
+				if constexpr (OP == OP_MUL_U24) asm volatile("v_mul_u32_u24 %0, 3, %0" : "+v"(a[k]));
 				if constexpr (OP == OP_PK_FMA)  asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pb), "v"(pc));
 				if constexpr (OP == OP_SQRT)    asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
 				if constexpr (OP == OP_SIN)     asm volatile("v_sin_f32 %0, %0" : "+v"(a[k]));
@@ -115,6 +124,52 @@ __global__ __launch_bounds__(1024) void term_probe(Stamp *stamps, float *sink, i
 	}
 	uint64_t t1 = memtime(), r1 = memrealtime();
 	if (mag + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag;
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		stamps[wave] = Stamp{t1 - t0, r1 - r0};
+	}
+}
+
+/* The stream das_staged.hip ships (round 2, final form): per batch of four terms 6 packed adds (window position,
+ * round-by-magic-number, fraction), 4 v_mul_u32_u24 (tap address), 4 + 8 packed fmas (interpolation, rotate-
+ * accumulate), 4 x (v_mul, v_fmac, v_sqrt) and 2 packed adds for |s|: 38 VALU instructions per 4 terms. */
+__global__ __launch_bounds__(1024) void term_probe_packed(Stamp *stamps, float *sink, int iters)
+{
+	float r = 3.25f + 0.01f * (float)(threadIdx.x & 63);
+	f32x2 tz01 = {1.5f, 2.5f}, tz23 = {3.5f, 4.5f}, mag2 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+	f32x4 tap[4], cs01 = {0.6f, 0.8f, 0.8f, 0.6f}, cs23 = cs01;
+	for (int k = 0; k < 4; k++) tap[k] = f32x4{0.5f + k, 0.25f, 0.125f, -0.5f};
+	uint32_t m_bits = 0x4B000001u;
+	asm volatile("" : "+s"(m_bits));
+	__syncthreads();
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		asm volatile("" : "+v"(tz01), "+v"(tz23), "+v"(cs01), "+v"(cs23), "+v"(tap[0]), "+v"(tap[1]), "+v"(tap[2]), "+v"(tap[3]));
+		const float M = __builtin_bit_cast(float, m_bits);
+		const f32x2 M2 = {M, M}, rr = {r, r};
+		const f32x2 p01 = rr + tz01, p23 = rr + tz23;
+		const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
+		const f32x2 g01 = p01 - (y01 - M2), g23 = p23 - (y23 - M2);
+		const float ys[4] = {y01.x, y01.y, y23.x, y23.y}, gs[4] = {g01.x, g01.y, g23.x, g23.y};
+		const f32x2 cs[4] = {{cs01.x, cs01.y}, {cs01.z, cs01.w}, {cs23.x, cs23.y}, {cs23.z, cs23.w}};
+		float q[4];
+		#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			uint32_t at;
+			asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at) : "v"(__builtin_bit_cast(uint32_t, ys[k])));
+			asm volatile("" :: "v"(at));
+			f32x2 sv = f32x2{tap[k].x, tap[k].y} + gs[k] * f32x2{tap[k].z, tap[k].w};
+			acc1 += sv.x * cs[k];
+			acc2 += sv.y * cs[k];
+			q[k] = __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+		}
+		mag2 += f32x2{q[0], q[1]};
+		mag2 += f32x2{q[2], q[3]};
+		m_bits += 128;
+		if (m_bits > 0x4B000801u) m_bits = 0x4B000001u;
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (mag2.x + mag2.y + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag2.x;
 	if ((threadIdx.x & 63) == 0) {
 		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 		stamps[wave] = Stamp{t1 - t0, r1 - r0};
@@ -314,6 +369,22 @@ static void term_case()
 	}
 }
 
+static void term_packed_case()
+{
+	const int iters = 40000;                           /* 160k terms per wave */
+	for (int wps : {4, 8}) {
+		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
+		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
+		Result r = run([&] { hipLaunchKernelGGL(term_probe_packed, dim3(blocks), dim3(64 * waves_per_block), 0, 0, d_stamps, d_sink, iters); }, waves);
+		double terms = 4.0 * iters;
+		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+		emit(",\n  {\"stream\":\"das_staged term, shipping form: per 4 terms 6 x v_pk_add_f32 (position, magic-number rounding, fraction), 4 x v_mul_u32_u24, "
+		     "12 x v_pk_fma_f32, 4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32), 2 x v_pk_add_f32 = 38 VALU instructions\",\"waves_per_simd\":%d,"
+		     "\"cycles_per_term_per_simd_wall\":%.3f,\"cycles_per_term_per_simd_stamps\":%.3f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
+		     wps, wall_cycles / (terms * wps), r.cycles_per_wave / (terms * wps), r.clock_ghz, r.wall_ms);
+	}
+}
+
 static char *d_window;
 
 template <int WIDTH, int PAT> static void gather_case(const char *level, uint32_t window, bool per_block, bool &first)
@@ -386,9 +457,14 @@ int main(int argc, char **argv)
 	valu_case<OP_ADD>(false);
 	valu_case<OP_LSHL_ADD>(false);
 	valu_case<OP_PK_ADD>(false);
+	valu_case<OP_PK_ADD_SGPR>(false);
+	valu_case<OP_PK_ADD_NEG>(false);
+	valu_case<OP_PK_FMA_SEL>(false);
+	valu_case<OP_MUL_U24>(false);
 	emit("],\n");
 	emit(" \"valu_stream\":[\n  ");
 	term_case();
+	term_packed_case();
 	emit("],\n");
 
 	bool first = true;

@@ -11,14 +11,17 @@ timeout -k 10 300 tools/bin/microbench > $OUT/profiles/r02_microbench.json 2> $O
 cp $OUT/profiles/r02_microbench.json profiles/r02_microbench.json
 echo "microbench done"
 # PMC passes first (bench.py reads their summaries): whole frames for the traffic figure, slabs for the rest
-timeout -k 10 420 python3 tools/pmc_das.py --config 4 --groups 0,1,7,8,9 --timeout 120 --out $OUT/pmc_cfg4 > $OUT/pmc_cfg4.log 2>&1
+timeout -k 10 480 python3 tools/pmc_das.py --config 4 --groups 0,1,2,7,8,9 --timeout 120 --out $OUT/pmc_cfg4 > $OUT/pmc_cfg4.log 2>&1
 timeout -k 10 200 python3 tools/pmc_das.py --config 4 --planes 16 --groups 3,5 --timeout 90 --out $OUT/pmc_cfg4_ta > $OUT/pmc_cfg4_ta.log 2>&1
+# the gather kernel the LDS-staged kernel replaced as the default (das path 2), for the comparison DESIGN.md quotes
+timeout -k 10 420 python3 tools/pmc_das.py --config 4 --das-path 2 --groups 0,1,7,8,9 --timeout 120 --out $OUT/pmc_cfg4_gather > $OUT/pmc_cfg4_gather.log 2>&1
+timeout -k 10 200 python3 tools/pmc_das.py --config 4 --das-path 2 --planes 16 --groups 3,5 --timeout 90 --out $OUT/pmc_cfg4_gather_ta > $OUT/pmc_cfg4_gather_ta.log 2>&1
 timeout -k 10 300 python3 tools/pmc_das.py --config 2 --groups 0,1,3,5,7,8,9 --timeout 60 --out $OUT/pmc_cfg2 > $OUT/pmc_cfg2.log 2>&1
 timeout -k 10 300 python3 tools/pmc_das.py --config 3 --groups 0,1,3,5,7,8,9 --timeout 60 --out $OUT/pmc_cfg3 > $OUT/pmc_cfg3.log 2>&1
 timeout -k 10 420 python3 tools/pmc_das.py --config 5 --planes 32 --groups 0,1,3,5,9 --timeout 90 --out $OUT/pmc_cfg5 > $OUT/pmc_cfg5.log 2>&1
 echo "pmc done"
 # the TA/TCP groups of config 4 come from a 16-plane slab (those passes are slow on whole frames): merged into the whole-frame entry
-python3 tools/summarize_profiles.py --round r02 $OUT/pmc_cfg4/summary.json $OUT/pmc_cfg4_ta/summary.json $OUT/pmc_cfg2/summary.json $OUT/pmc_cfg3/summary.json $OUT/pmc_cfg5/summary.json
+python3 tools/summarize_profiles.py --round r02 $OUT/pmc_cfg4/summary.json $OUT/pmc_cfg4_ta/summary.json $OUT/pmc_cfg4_gather/summary.json $OUT/pmc_cfg4_gather_ta/summary.json $OUT/pmc_cfg2/summary.json $OUT/pmc_cfg3/summary.json $OUT/pmc_cfg5/summary.json
 cp profiles/das_traffic.json profiles/r02_das_bound.json $OUT/profiles/
 timeout -k 10 400 python bench.py > $OUT/profiles/r02_bench.json 2> $OUT/bench.err
 cut -c1-600 $OUT/profiles/r02_bench.json
@@ -27,6 +30,9 @@ for c in 1 2 3 5; do
 done
 timeout -k 10 300 python bench.py --config 5 --frame-graph --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_graph.json 2> $OUT/bench_cfg5_graph.err
 timeout -k 10 300 python bench.py --config 1 --frame-graph --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg1_graph.json 2> $OUT/bench_cfg1_graph.err
+timeout -k 10 300 python bench.py --das-path 2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4_gather.json 2> $OUT/bench_cfg4_gather.err
+PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --json $OUT/profiles/r02_staged_threshold.json > $OUT/staged_threshold.log 2>&1 || echo "staged threshold sweep failed"
+PYTHONPATH=$ROOT timeout -k 10 300 python tools/pull_rate.py --json $OUT/profiles/r02_pull_rate.json > $OUT/pull_rate.log 2>&1 || echo "pull rate failed"
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
 python3 - <<'PY'
 import json
@@ -38,6 +44,10 @@ for c in (1, 2, 3, 5):
 for c in (1, 5):
     d = json.loads(open(f"gpurun_out/r02/bench_cfg{c}_graph.json").read())
     out[f"config{c}_frame_graph"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "notes": d["config"]["notes"]}
+d = json.loads(open("gpurun_out/r02/bench_cfg4_gather.json").read())
+out["config4_gather_kernel_das_path_2"] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "das_path": d["config"]["das_path"],
+                                           "roofline": {k: d["roofline"][k] for k in ("achieved", "frac", "kernel", "kernel_ms", "pairs_per_launch", "binding")},
+                                           "note": "the kernel that was the default until the LDS-staged kernel replaced it (same box, same run as the other entries)"}
 d = json.loads(open("gpurun_out/r02/bench_inprocess_0_0.json").read())
 out["config4_in_process_two_contexts_on_one_gpu"] = {"ms_per_step": d["ms_per_step"], "sharding": d["config"]["sharding"], "device_das_ms": d["config"].get("device_das_ms"),
                                                       "note": "orchestration check only: both device contexts share one GPU"}
