@@ -467,6 +467,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			if (us > 6) continue;
 			if ((u_axis == 0 ? us : vs) < 4) continue;
 			float spread = step_u * (float)((1u << us) - 1) + step_v * (float)((1u << vs) - 1);
+			if (!(spread >= 0.f && spread <= 60.f)) continue;                /* also a NaN / infinite spread (wild parameters) */
 			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + 4;       /* + taps, floors, rounding slack */
 			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
 			if (!ws) continue;

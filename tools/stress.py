@@ -1,5 +1,5 @@
-"""Soak test on a GPU box: 30 000 small frames through both push entry points, alternating two
-parameter blocks and occasionally re-pushing parameters (replans), with periodic bit-exact
+"""Soak test on a GPU box: 30 000 small frames through both push entry points, alternating three
+parameter blocks (2-D single plane wave, 2-D compounding on the factored kernel, a row-column volume on the LDS-staged kernel) and occasionally re-pushing parameters (replans), with periodic bit-exact
 checks of the exported frame and a watch on host RSS and device memory.
     PYTHONPATH=. python tools/stress.py [frames [device,device,...]]"""
 import ctypes as C, os, sys, time
@@ -16,8 +16,10 @@ if len(sys.argv) > 2:            # stress.py N 0,0,0 : the same soak through the
     ids = [int(v) for v in sys.argv[2].split(",")]
     assert L.beamformer_hip_set_devices((C.c_int32 * len(ids))(*ids), len(ids))
 L.beamformer_set_global_timeout(0xFFFFFFFF)
-assert L.beamformer_reserve_parameter_blocks(2)
-acqs = [configs.config(1, 0.5), configs.config(2, 0.0625)]
+assert L.beamformer_reserve_parameter_blocks(3)
+acqs = [configs.config(1, 0.5), configs.config(2, 0.0625),
+        configs.rca("staged", 32, 13, 512, (40, 36, 3), (-3e-3, -3e-3, 6e-3), (3e-3, 3e-3, 18e-3), seed=46, orientation=0x12, cw=True,
+                    f_number=0.6, angles=np.linspace(-12, 12, 13))]
 golden = []
 for slot, acq in enumerate(acqs):
     for s, fp in enumerate(acq.filters):
@@ -31,7 +33,7 @@ torch.cuda.synchronize()
 free0 = torch.cuda.mem_get_info()[0]; rss0 = rss_mb(); t0 = time.time()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 for i in range(N):
-    slot = (i // 7) & 1
+    slot = (i // 7) % 3
     acq = acqs[slot]
     if i % 1013 == 0:
         assert L.beamformer_push_simple_parameters_at(C.byref(acq.bp), slot)          # replan
