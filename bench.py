@@ -401,7 +401,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
         to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
-      * the LDS-staged kernel -- VALU issue: the inner loop's VALU stream (38 instructions per 4 (voxel, channel,
+      * the LDS-staged kernel -- VALU issue: the inner loop's VALU stream (40 instructions per 4 (voxel, channel,
         transmit) terms), measured as a stream with no memory instruction in it ("valu_stream", shipping form);
     achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
@@ -415,7 +415,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             per_term = best["cycles_per_term_per_simd_wall"]
             peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / per_term          # terms per second with every SIMD issuing nothing else
             out = {
-                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the inner loop's 38 VALU instructions per 4 terms, measured as a stream with no memory instruction in it",
+                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the inner loop's 40 VALU instructions per 4 terms, measured as a stream with no memory instruction in it",
                 "achieved": terms / das_s / 1e12, "unit": "T terms/s (terms that pass the f-number test)",
                 "peak": peak / 1e12,
                 "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_term:.2f} clk",

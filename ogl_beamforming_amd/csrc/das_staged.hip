@@ -1,4 +1,4 @@
-/* das_staged.hip -- row-column DAS with the RF staged in LDS (gfx950 / MI355X).
+/* das_staged.hip -- row-column DAS with the RF staged in LDS (gfx950 / MI355X): the headline kernel.
  *
  * Same arithmetic contract and the same delay factorisation as das_separable.hip
  * (idx = T(a; v_tx, z) + R(c; v_rx, z), shaders/das.glsl:204-231 of the reference), for
@@ -9,36 +9,40 @@
  * (tools/microbench.hip).  But the 1024 voxels of a 32 x 32 tile touch only a short window of
  * every RF row: the receive delay moves by at most pitch*fs/c (0.6 sample at config 4) per voxel
  * along the receive axis and less along the transmit axis.  So per channel the block copies,
- * for every transmit, one W-sample window (W = 32 or 64: 256 or 512 bytes) of the RF row into
- * LDS -- 19 KB per channel instead of 1.2 MB of gathers through L1 -- and every lane then
- * interpolates out of LDS (two ds_read_b64 per term; a window is at most one 256-B bank row, so
- * distinct addresses of a wave fall in distinct banks).
+ * for every transmit, one W-sample window (W = 32 or 64) of the RF row into LDS -- 19 KB of
+ * coalesced loads per channel instead of 1.2 MB of gathers through L1 -- and every lane then
+ * interpolates out of LDS.
  *
- * Round 2 rewrite.  The first version of this kernel lost to the gather kernel (1327 against
- * 1165 ms) because it paid ~20 VALU instructions per term against the gather kernel's 14: integer
- * window bookkeeping, an always-on range test, address arithmetic per tap.  VALU issue is what
- * both kernels wait for, so this version removes every per-term instruction the window made
- * necessary:
+ * Round 1's version of this kernel lost to the gather kernel (1327 against 1165 ms) because it
+ * paid ~20 VALU instructions per term against the gather kernel's 14 (integer window bookkeeping,
+ * an always-on range test, address arithmetic per tap), and VALU issue is what both kernels wait
+ * for.  This version pays 10 (40 per batch of 4 terms):
  *   * the window position is folded into the FLOAT tables: element j of window (c, a) holds sample
- *     floor(rmin_c) + floor(tmin_a) + j (rmin / tmin: the delay minima over the tile), the receive
- *     table hands the lane R' = R - floor(rmin_c) once per channel and the transmit table holds
- *     T' = T - floor(tmin_a) -- both differences are exact in f32 -- so ONE add gives the position
- *     inside the window, whose floor and fraction are the tap and the interpolation weight.  (The
- *     sum R' + T' of two small numbers is rounded at 2^-19 of a sample instead of the 2^-13 of the
- *     absolute index: the staged kernel is closer to exact arithmetic than the shader it restates.)
- *   * the row of the window inside the staging area is an immediate offset of the LDS read (the
- *     transmit loop is unrolled by 4; the batch's base is a scalar operand of the one v_lshl_add);
- *   * the transmit table is padded to a multiple of 4 with zero phasors over a zero window row, so
- *     the last batch needs no select;
+ *     floor(rmin_c) + floor(tmin_a) + j (rmin / tmin: the delay minima over the tile); the receive
+ *     table hands the lane R' = R - floor(rmin_c) once per channel, the transmit table holds
+ *     T'' = T - floor(tmin_a) - 1/2 -- all exact in f32 -- so ONE add gives the position p relative
+ *     to the MIDDLE of the tap pair.  (A sum of two small numbers is rounded at 2^-19 of a sample
+ *     instead of the absolute index's 2^-12: closer to exact arithmetic than the shader it restates.)
+ *   * window elements are {midpoint, difference} of neighbouring samples, 16 bytes: the two taps are
+ *     ONE aligned ds_read_b128 and the interpolation ONE packed fma, midpoint + g * difference;
+ *   * no v_fract, no v_cvt: adding M = 2^23 + 1 + a*W rounds p to the nearest integer n and leaves the
+ *     window ELEMENT INDEX in the low mantissa bits (y = p + M; n = y - M; g = p - n: packed adds over
+ *     two terms, all exact); the tap's LDS address is (bits(y) & 0xFFFFFF) * 16, one v_mul_u32_u24,
+ *     because the staging area starts one element into an LDS that holds nothing static;
+ *   * transmits in pairs: one ds_read2_b64 serves four terms' delays, one ds_read_b128 two terms'
+ *     phasors; the transmit table is padded to a multiple of 4 with zero phasors over a zero window
+ *     row, so the last batch needs no select;
  *   * the range test of sample_rf (0 <= index < S - 1) is decided per wave and channel from the
  *     tile-wide extremes of T exactly as in das_separable.hip; only waves that can leave the row
- *     run the checked loop (absolute tap = window tap + the two floors; invalid taps read a zero pair).
+ *     run the checked loop (absolute tap = window tap + the two floors; invalid taps read a zero element).
  *
- * Pipeline per channel: the global loads of the NEXT channel's windows are issued into registers
+ * Pipeline per channel: the buffer loads of the NEXT channel's windows are issued into registers
  * before the current channel is consumed and written to LDS after it (barrier - ds_write -
  * barrier); two 1024-thread blocks share a CU, so one block's barriers hide under the other's
  * arithmetic.  The host only launches this kernel when its bound on the delay spread of a tile fits
- * the window (plan_staged, executor.cpp).  No MFMA: gather-accumulate.
+ * the window (plan_staged, executor.cpp).  No MFMA: gather-accumulate.  Measured (config 4, one
+ * MI355X): 854-883 ms per 512^3 frame against 1116-1158 ms for the gather kernel; VALU 97 % busy,
+ * 0.86-0.89 of the rate of its own VALU stream run without memory instructions.
  */
 #include "das_common.h"
 

@@ -130,41 +130,61 @@ __global__ __launch_bounds__(1024) void term_probe(Stamp *stamps, float *sink, i
 	}
 }
 
-/* The stream das_staged.hip ships (round 2, final form): per batch of four terms 6 packed adds (window position,
+/* The stream das_staged.hip ships (round 2, final form): per batch of four terms 8 packed adds (window position,
  * round-by-magic-number, fraction), 4 v_mul_u32_u24 (tap address), 4 + 8 packed fmas (interpolation, rotate-
- * accumulate), 4 x (v_mul, v_fmac, v_sqrt) and 2 packed adds for |s|: 38 VALU instructions per 4 terms. */
+ * accumulate), 4 x (v_mul, v_fmac, v_sqrt) and 2 packed adds for |s|: 40 VALU instructions per 4 terms. */
+/* PARTS: bit 0 = position / rounding / address (8 packed adds + 4 v_mul_u32_u24 per 4 terms), bit 1 = interpolation and
+ * rotate-accumulate (12 packed fmas), bit 2 = |s| (4 x v_mul, v_fmac, v_sqrt + 2 packed adds); 7 = the whole stream.  The
+ * parts run alone tell which of them the whole costs more than. */
+template <int PARTS>
 __global__ __launch_bounds__(1024) void term_probe_packed(Stamp *stamps, float *sink, int iters)
 {
 	float r = 3.25f + 0.01f * (float)(threadIdx.x & 63);
 	f32x2 tz01 = {1.5f, 2.5f}, tz23 = {3.5f, 4.5f}, mag2 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+	f32x2 g01 = {0.25f, -0.25f}, g23 = {0.125f, -0.125f}, svs[4];
 	f32x4 tap[4], cs01 = {0.6f, 0.8f, 0.8f, 0.6f}, cs23 = cs01;
-	for (int k = 0; k < 4; k++) tap[k] = f32x4{0.5f + k, 0.25f, 0.125f, -0.5f};
+	for (int k = 0; k < 4; k++) { tap[k] = f32x4{0.5f + k, 0.25f, 0.125f, -0.5f}; svs[k] = f32x2{0.5f + k, 0.25f}; }
 	uint32_t m_bits = 0x4B000001u;
 	asm volatile("" : "+s"(m_bits));
 	__syncthreads();
 	uint64_t t0 = memtime(), r0 = memrealtime();
 	for (int i = 0; i < iters; i++) {
 		asm volatile("" : "+v"(tz01), "+v"(tz23), "+v"(cs01), "+v"(cs23), "+v"(tap[0]), "+v"(tap[1]), "+v"(tap[2]), "+v"(tap[3]));
-		const float M = __builtin_bit_cast(float, m_bits);
-		const f32x2 M2 = {M, M}, rr = {r, r};
-		const f32x2 p01 = rr + tz01, p23 = rr + tz23;
-		const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
-		const f32x2 g01 = p01 - (y01 - M2), g23 = p23 - (y23 - M2);
-		const float ys[4] = {y01.x, y01.y, y23.x, y23.y}, gs[4] = {g01.x, g01.y, g23.x, g23.y};
+		if constexpr (PARTS & 1) {
+			const float M = __builtin_bit_cast(float, m_bits);
+			const f32x2 M2 = {M, M}, rr = {r, r};
+			const f32x2 p01 = rr + tz01, p23 = rr + tz23;
+			const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
+			g01 = p01 - (y01 - M2); g23 = p23 - (y23 - M2);
+			const float ys[4] = {y01.x, y01.y, y23.x, y23.y};
+			#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				uint32_t at;
+				asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at) : "v"(__builtin_bit_cast(uint32_t, ys[k])));
+				asm volatile("" :: "v"(at));
+			}
+			if constexpr (!(PARTS & 2)) asm volatile("" :: "v"(g01), "v"(g23));
+		} else {
+			asm volatile("" : "+v"(g01), "+v"(g23));
+		}
+		const float gs[4] = {g01.x, g01.y, g23.x, g23.y};
 		const f32x2 cs[4] = {{cs01.x, cs01.y}, {cs01.z, cs01.w}, {cs23.x, cs23.y}, {cs23.z, cs23.w}};
 		float q[4];
 		#pragma unroll
 		for (int k = 0; k < 4; k++) {
-			uint32_t at;
-			asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at) : "v"(__builtin_bit_cast(uint32_t, ys[k])));
-			asm volatile("" :: "v"(at));
-			f32x2 sv = f32x2{tap[k].x, tap[k].y} + gs[k] * f32x2{tap[k].z, tap[k].w};
-			acc1 += sv.x * cs[k];
-			acc2 += sv.y * cs[k];
-			q[k] = __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+			f32x2 sv;
+			if constexpr (PARTS & 2) {
+				sv = f32x2{tap[k].x, tap[k].y} + gs[k] * f32x2{tap[k].z, tap[k].w};
+				acc1 += sv.x * cs[k];
+				acc2 += sv.y * cs[k];
+				if constexpr (!(PARTS & 4)) asm volatile("" :: "v"(sv));
+			} else {
+				asm volatile("" : "+v"(svs[k]));
+				sv = svs[k];
+			}
+			if constexpr (PARTS & 4) q[k] = __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
 		}
-		mag2 += f32x2{q[0], q[1]};
-		mag2 += f32x2{q[2], q[3]};
+		if constexpr (PARTS & 4) { mag2 += f32x2{q[0], q[1]}; mag2 += f32x2{q[2], q[3]}; }
 		m_bits += 128;
 		if (m_bits > 0x4B000801u) m_bits = 0x4B000001u;
 	}
@@ -369,19 +389,18 @@ static void term_case()
 	}
 }
 
-static void term_packed_case()
+template <int PARTS> static void term_packed_case(const char *what)
 {
 	const int iters = 40000;                           /* 160k terms per wave */
 	for (int wps : {4, 8}) {
 		int waves_per_block = wps <= 4 ? 4 * wps : 16, blocks_per_cu = wps <= 4 ? 1 : 2;
 		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
-		Result r = run([&] { hipLaunchKernelGGL(term_probe_packed, dim3(blocks), dim3(64 * waves_per_block), 0, 0, d_stamps, d_sink, iters); }, waves);
+		Result r = run([&] { hipLaunchKernelGGL(term_probe_packed<PARTS>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, d_stamps, d_sink, iters); }, waves);
 		double terms = 4.0 * iters;
 		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
-		emit(",\n  {\"stream\":\"das_staged term, shipping form: per 4 terms 6 x v_pk_add_f32 (position, magic-number rounding, fraction), 4 x v_mul_u32_u24, "
-		     "12 x v_pk_fma_f32, 4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32), 2 x v_pk_add_f32 = 38 VALU instructions\",\"waves_per_simd\":%d,"
+		emit(",\n  {\"stream\":\"%s\",\"waves_per_simd\":%d,"
 		     "\"cycles_per_term_per_simd_wall\":%.3f,\"cycles_per_term_per_simd_stamps\":%.3f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
-		     wps, wall_cycles / (terms * wps), r.cycles_per_wave / (terms * wps), r.clock_ghz, r.wall_ms);
+		     what, wps, wall_cycles / (terms * wps), r.cycles_per_wave / (terms * wps), r.clock_ghz, r.wall_ms);
 	}
 }
 
@@ -464,7 +483,12 @@ int main(int argc, char **argv)
 	emit("],\n");
 	emit(" \"valu_stream\":[\n  ");
 	term_case();
-	term_packed_case();
+	term_packed_case<7>("das_staged term, shipping form: per 4 terms 8 x v_pk_add_f32 (position, magic-number rounding, fraction), 4 x v_mul_u32_u24, "
+	                    "12 x v_pk_fma_f32, 4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32), 2 x v_pk_add_f32 = 40 VALU instructions");
+	term_packed_case<1>("part of the shipping form alone: position / rounding / address (8 x v_pk_add_f32 + 4 x v_mul_u32_u24 per 4 terms)");
+	term_packed_case<2>("part of the shipping form alone: interpolation + rotate-accumulate (12 x v_pk_fma_f32 per 4 terms)");
+	term_packed_case<4>("part of the shipping form alone: |s| (4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32) + 2 x v_pk_add_f32 per 4 terms)");
+	term_packed_case<6>("parts of the shipping form: interpolation + rotate-accumulate + |s| (no position part)");
 	emit("],\n");
 
 	bool first = true;
