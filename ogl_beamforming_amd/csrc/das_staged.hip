@@ -220,9 +220,14 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			regs[n] = __builtin_bit_cast(f32x2, v);
 		}
 	};
-	/* element j keeps {s_j, s_(j+1) - s_j}: the next sample sits in the next lane (a wave stages whole windows,
-	 * consecutive lanes consecutive samples), fetched with a one-lane wave shift.  The last element of a window gets
-	 * a meaningless difference and is never a term's FIRST tap (the host's window bound, plan_staged). */
+	/* Element j keeps the LINE through samples j and j + 1 in window coordinates, {c_j, d_j} with d_j = s_(j+1) - s_j and
+	 * c_j = s_j + (1/2 - j) d_j, so that the interpolated sample at position p (measured from half a sample into the window,
+	 * as the tables hold it) is c_j + p d_j for j = round(p): one packed fma of the position itself, no fraction needed.
+	 * (At an integer position both neighbouring lines give the same value, so the tie of the rounding is harmless.)  The next
+	 * sample sits in the next lane (a wave stages whole windows, consecutive lanes consecutive samples), fetched with a
+	 * one-lane wave shift.  The last element of a window gets a meaningless line and is never selected (the host's window
+	 * bound, plan_staged). */
+	const float half_minus_j = 0.5f - (float)(tid & (W - 1));
 	auto stage_store = [&](const f32x2 (&regs)[NL]) {
 		#pragma unroll
 		for (int n = 0; n < NL; n++) {
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			const float ny = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x130, 0xf, 0xf, true));
 			uint32_t e = tid + (uint32_t)n * nthreads;
 			const float dx = nx - sx, dy = ny - sy;
-			if (e < stage_elements) stage[e] = f32x4{__builtin_fmaf(0.5f, dx, sx), __builtin_fmaf(0.5f, dy, sy), dx, dy};
+			if (e < stage_elements) stage[e] = f32x4{__builtin_fmaf(half_minus_j, dx, sx), __builtin_fmaf(half_minus_j, dy, sy), dx, dy};
 		}
 	};
 
@@ -294,9 +299,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			const float r_rel = r_x - (float)rfl;                          /* exact: position of the lane's receive delay in the window */
 			f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 			f32x2 mag2 = {0.f, 0.f};
-			/* one term: g in [-0.5, 0.5] is the position relative to the MIDDLE of the tap pair, tap = {midpoint, difference} */
-			auto term = [&](f32x2 cs, float g, f32x4 tap) -> float {
-				f32x2 sv = f32x2{tap.x, tap.y} + g * f32x2{tap.z, tap.w};
+			/* one term: pos = position in the window (minus 1/2), tap = the line {c, d} of the element round(pos) selects */
+			auto term = [&](f32x2 cs, float pos, f32x4 tap) -> float {
+				f32x2 sv = f32x2{tap.x, tap.y} + pos * f32x2{tap.z, tap.w};
 				acc1 += sv.x * cs;
 				acc2 += sv.y * cs;
 				if constexpr (CW) return hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
@@ -310,17 +315,16 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				asm volatile("" : "+v"(lane_id));                          /* not hoisted: see the register budget above */
 				const uint32_t lane_v = u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1);
 				uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3);
-				/* Position -> tap without v_fract / v_cvt: adding M = 2^23 + (first window element of the batch) rounds the
-				 * (midpoint-relative) position to the nearest integer n and leaves the ELEMENT INDEX a*W + n in the low
-				 * mantissa bits, so that
-				 *     y = p + M;  n = y - M;  g = p - n        (packed: two terms per instruction, all three exact)
-				 * and the tap's LDS byte offset is (bits(y) & 0xFFFFFF) * 16 -- one 24-bit multiply, no add: M's own bit
-				 * pattern (0x4B000000 + a*W) contributes exactly a*W below bit 24.  M is a scalar, stepped by 4*W per batch
-				 * as an integer (the mantissa of a float in [2^23, 2^24) counts integers); term k's row k*W and the
-				 * staging area's base are the read's immediate offset. */
+				/* Position -> tap without v_fract / v_cvt / a fraction: adding M = 2^23 + 1 + (first window element of the batch)
+				 * rounds the position to the nearest integer and leaves the ELEMENT INDEX a*W + round(p) in the low mantissa bits
+				 * of y = p + M (packed: two terms per instruction); the tap's LDS byte address is (bits(y) & 0xFFFFFF) * 16 -- one
+				 * 24-bit multiply, no add: M's own bit pattern (0x4B000001 + a*W) contributes exactly 1 + a*W below bit 24, and the
+				 * staging area starts one element into the LDS.  M is a scalar, stepped by 4*W per batch as an integer (the mantissa
+				 * of a float in [2^23, 2^24) counts integers); term k's row k*W is the read's immediate offset.  The element is a
+				 * line in window coordinates, so the interpolation uses p itself. */
 				/* M starts at 2^23 + 1, not 2^23: a position of -1/2 (the lane with the smallest delays of the tile) must round
 				 * inside [2^23, 2^24) -- just below 2^23 floats step by 1/2 and 2^23 - 1/2 would come back exact, with garbage in
-				 * the low mantissa bits.  The staging area starts one element into the LDS to match. */
+				 * the low mantissa bits. */
 				uint32_t m_bits = 0x4B000001u;
 				const f32x2 rr = {r_rel, r_rel};
 				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
@@ -333,7 +337,6 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 					const f32x2 tz23 = *(lds_f32x2 *)(uintptr_t)(tz_at + V * 8u);
 					const f32x2 p01 = rr + tz01, p23 = rr + tz23;
 					const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
-					const f32x2 g01 = p01 - (y01 - M2), g23 = p23 - (y23 - M2);
 					const float ys[4] = {y01.x, y01.y, y23.x, y23.y};
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
@@ -346,10 +349,10 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 					}
 					#pragma unroll
 					for (int k = 0; k < 4; k++) tap[k] = *(lds_f32x4 *)(uintptr_t)(at[k] + (CHECK ? 0u : (uint32_t)k * W * 16u));   /* immediate */
-					const float q0 = term(f32x2{cs01.x, cs01.y}, g01.x, tap[0]);
-					const float q1 = term(f32x2{cs01.z, cs01.w}, g01.y, tap[1]);
-					const float q2 = term(f32x2{cs23.x, cs23.y}, g23.x, tap[2]);
-					const float q3 = term(f32x2{cs23.z, cs23.w}, g23.y, tap[3]);
+					const float q0 = term(f32x2{cs01.x, cs01.y}, p01.x, tap[0]);
+					const float q1 = term(f32x2{cs01.z, cs01.w}, p01.y, tap[1]);
+					const float q2 = term(f32x2{cs23.x, cs23.y}, p23.x, tap[2]);
+					const float q3 = term(f32x2{cs23.z, cs23.w}, p23.y, tap[3]);
 					if constexpr (CW) { mag2 += f32x2{q0, q1}; mag2 += f32x2{q2, q3}; }
 				}
 			};
