@@ -78,9 +78,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
 	const int A4 = (A + 3) & ~3;
 	const int chunk = (int)q.channel_chunk;
-	/* the staging area comes first and the kernel has no static LDS: 16 x (a window element's index + 1) IS its LDS
-	 * address, which the inner loop forms with one 24-bit multiply */
-	f32x4 *stage  = staged_lds + 1;                          /* (one unused element in front: see the magic number of the inner loop) */
+	/* the staging area comes first and the kernel has no static LDS: 16 x (a window element's index + 2) IS its LDS
+	 * address, which the inner loop forms with one shift */
+	f32x4 *stage  = staged_lds + 2;                          /* (two unused elements in front: see the rounding of the inner loop) */
 	f32x4 *Tcs    = stage + (size_t)A4 * W + 1;
 	f32x4 *R      = Tcs + (size_t)(A4 / 2) * V;
 	f32x2 *Tz     = reinterpret_cast<f32x2 *>(R + (size_t)chunk * U);
@@ -315,17 +315,20 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				asm volatile("" : "+v"(lane_id));                          /* not hoisted: see the register budget above */
 				const uint32_t lane_v = u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1);
 				uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3);
-				/* Position -> tap without v_fract / v_cvt / a fraction: adding M = 2^23 + 1 + (first window element of the batch)
-				 * rounds the position to the nearest integer and leaves the ELEMENT INDEX a*W + round(p) in the low mantissa bits
-				 * of y = p + M (packed: two terms per instruction); the tap's LDS byte address is (bits(y) & 0xFFFFFF) * 16 -- one
-				 * 24-bit multiply, no add: M's own bit pattern (0x4B000001 + a*W) contributes exactly 1 + a*W below bit 24, and the
-				 * staging area starts one element into the LDS.  M is a scalar, stepped by 4*W per batch as an integer (the mantissa
-				 * of a float in [2^23, 2^24) counts integers); term k's row k*W is the read's immediate offset.  The element is a
-				 * line in window coordinates, so the interpolation uses p itself. */
-				/* M starts at 2^23 + 1, not 2^23: a position of -1/2 (the lane with the smallest delays of the tile) must round
-				 * inside [2^23, 2^24) -- just below 2^23 floats step by 1/2 and 2^23 - 1/2 would come back exact, with garbage in
-				 * the low mantissa bits. */
-				uint32_t m_bits = 0x4B000001u;
+				/* Position -> tap without v_fract / v_cvt / a fraction: adding M = 2^23 + 2 + (first window element of the batch)
+				 * rounds the position to the nearest integer and leaves the ELEMENT INDEX 2 + a*W + round(p) in the low mantissa
+				 * bits of y = p + M (packed: two terms per instruction); the tap's LDS byte address is (bits(y) & 0xFFFFFF) * 16 --
+				 * one 24-bit multiply, no add: M's own bit pattern (0x4B000002 + a*W) contributes exactly 2 + a*W below bit 24,
+				 * and the staging area starts two elements into an LDS that holds nothing static.  M is a scalar, stepped by 4*W
+				 * per batch as an integer (the mantissa of a float in [2^23, 2^24) counts integers); term k's row k*W is the read's
+				 * immediate offset.  The element is a line in window coordinates, so the interpolation uses p itself.
+				 * Why 2^23 + 2: (1) p = -1/2 (the lane with the smallest delays of the tile) must round inside [2^23, 2^24) --
+				 * just below 2^23 floats step by 1/2 and 2^23 - 1/2 would come back exact, with garbage in the low mantissa bits;
+				 * (2) that tie must not round DOWN to the element in front of the row: 2 + a*W is even, so round-to-even takes it
+				 * up to element 0.  At every other tie both neighbouring lines give the same value.
+				 * (Tried and measured no faster: y = fma(p, 2^-149, B) into a denormal whose bit pattern is the index, then a
+				 * full-rate shift instead of the half-rate 24-bit multiply -- 0.721 of the gather kernel's time against 0.710.) */
+				uint32_t m_bits = 0x4B000002u;
 				const f32x2 rr = {r_rel, r_rel};
 				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
 					uint32_t at[4]; f32x4 tap[4];
@@ -341,10 +344,10 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
 						const uint32_t yb = __builtin_bit_cast(uint32_t, ys[k]);
-						asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at[k]) : "v"(yb));   /* (hipcc turns the builtin into shift + and); LDS address 0 = the staging area */
+						asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at[k]) : "v"(yb));   /* (hipcc turns the builtin into shift + and) */
 						if constexpr (CHECK) {
-							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfl + tfl[a + k]);      /* yb - m_bits = n */
-							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : (stage_elements + 1u) * 16u;
+							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfl + tfl[a + k]);      /* yb - m_bits = round(p) */
+							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : (stage_elements + 2u) * 16u;
 						}
 					}
 					#pragma unroll

@@ -475,7 +475,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
-				uint64_t lds = 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 2) + 4ull * (A4 + cc + 1) + 128;
+				uint64_t lds = 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
 				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = 2048u >> threads_shift;
