@@ -61,7 +61,8 @@ __device__ __forceinline__ float staged_phase_turns(float k, float index)
 
 /* LDS (A4 = transmits rounded up to a multiple of 4; transmits are kept in PAIRS so that one read serves two terms):
  *   Tcs[(a/2)*V + v] = { cos(phi_t), sin(phi_t) of transmit a & ~1, then of transmit a | 1 }          f32x4
- *   R[cl*U + u]      = { r_index, apod*cos(phi_r), apod*sin(phi_r), apod }     cl: channel in chunk   f32x4
+ *   R[cl*U + u]      = { R' = r_index - floor(rmin_c), apod*cos(phi_r), apod*sin(phi_r), +-apod }   cl: channel in chunk;
+ *                      the weight's sign bit set = the lane may leave the RF row (checked loop)          f32x4
  *   stage[a*W + j]   = { (s + s') / 2, s' - s }: s = sample floor(rmin_c) + floor(tmin_a) + j of row (c, a), s' the
  *                      next one -- midpoint and difference; j < W, a < A4; then one zero element         f32x4
  *   Tz[(a/2)*V + v]  = { T'' = t_index - floor(tmin_a) - 1/2 of transmit a & ~1, of transmit a | 1 }     f32x2
@@ -276,6 +277,17 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			rfloor[cl] = (int)__builtin_floorf(m);
 		}
 		__syncthreads();
+		/* the entries become what the channel loop consumes with no arithmetic: the delay relative to the channel's window
+		 * (exact) and, in the SIGN of the weight, whether the lane can leave the RF row for some transmit of the tile
+		 * (r + min T < 0 or r + max T >= S - 1: such a wave runs the checked loop) */
+		for (uint32_t e = tid; e < (uint32_t)cn * U; e += nthreads) {
+			f32x4 entry = R[e];
+			const bool lane_safe = (entry.x + range.x >= 0.f) && (entry.x + range.y < (float)(S - 1));
+			entry.x -= (float)rfloor[e >> q.u_shift];
+			if (!lane_safe) entry.w = -entry.w;          /* -0.0f for a lane outside the aperture: still "unsafe" to the sign test */
+			R[e] = entry;
+		}
+		__syncthreads();
 
 		f32x2 regs[NL];
 		stage_load(c0, rfloor[0], regs);
@@ -289,14 +301,13 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			/* (register budget: 64 per lane at 8 waves per SIMD with the next channel's windows in flight.  The
 			 * receive entry is read twice -- delay and aperture test here, phasor and weight after the loop -- and the
 			 * lane's table addresses are rebuilt per channel rather than kept) */
-			float r_x, r_w;
+			float r_rel, r_w;
 			{
 				const f32x4 r = Rl[(size_t)cl * U];
-				r_x = r.x; r_w = r.w;
+				r_rel = r.x; r_w = r.w;
 			}
 			if (__builtin_amdgcn_ballot_w64(r_w != 0.f) == 0) continue;    /* F# culling per wave */
-			const int   rfl   = rfloor[cl];
-			const float r_rel = r_x - (float)rfl;                          /* exact: position of the lane's receive delay in the window */
+			const bool wave_safe = __builtin_amdgcn_ballot_w64(__builtin_signbitf(r_w)) == 0;
 			f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 			f32x2 mag2 = {0.f, 0.f};
 			/* one term: pos = position in the window (minus 1/2), tap = the line {c, d} of the element round(pos) selects */
@@ -307,8 +318,6 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				if constexpr (CW) return hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
 				else return 0.f;
 			};
-			const bool lane_safe = (r_x + range.x >= 0.f) && (r_x + range.y < (float)(S - 1));
-			const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
 			auto batches = [&](auto checked) {
 				constexpr bool CHECK = decltype(checked)::value;
 				uint32_t lane_id = tid;
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 						const uint32_t yb = __builtin_bit_cast(uint32_t, ys[k]);
 						asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at[k]) : "v"(yb));   /* (hipcc turns the builtin into shift + and) */
 						if constexpr (CHECK) {
-							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfl + tfl[a + k]);      /* yb - m_bits = round(p) */
+							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfloor[cl] + tfl[a + k]);      /* yb - m_bits = round(p) */
 							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : (stage_elements + 2u) * 16u;
 						}
 					}
@@ -361,11 +370,13 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			};
 			if (wave_safe) batches(std::false_type{});
 			else           batches(std::true_type{});
-			f32x2 sum = {acc1.x - acc2.y, acc1.y + acc2.x};
+			/* per-channel fold, written scalar (hipcc otherwise builds it from packed ops and six register moves) */
+			float sum_x = acc1.x - acc2.y, sum_y = acc1.y + acc2.x;
+			asm volatile("" : "+v"(sum_x), "+v"(sum_y));
 			const f32x4 r = *(volatile lds_f32x4 *)(uintptr_t)((uint32_t)(uintptr_t)(lds_f32x4 *)Rl + (uint32_t)cl * U * 16u);
-			coherent.x += sum.x * r.y - sum.y * r.z;
-			coherent.y += sum.x * r.z + sum.y * r.y;
-			if constexpr (CW) incoherent += r.w * (mag2.x + mag2.y);
+			coherent.x = __builtin_fmaf(sum_x, r.y, __builtin_fmaf(-sum_y, r.z, coherent.x));
+			coherent.y = __builtin_fmaf(sum_x, r.z, __builtin_fmaf(sum_y, r.y, coherent.y));
+			if constexpr (CW) incoherent = __builtin_fmaf(__builtin_fabsf(r.w), mag2.x + mag2.y, incoherent);
 		}
 	}
 	if (!inside) return;

@@ -130,10 +130,10 @@ __global__ __launch_bounds__(1024) void term_probe(Stamp *stamps, float *sink, i
 	}
 }
 
-/* The stream das_staged.hip ships (round 2, final form): per batch of four terms 8 packed adds (window position,
- * round-by-magic-number, fraction), 4 v_mul_u32_u24 (tap address), 4 + 8 packed fmas (interpolation, rotate-
- * accumulate), 4 x (v_mul, v_fmac, v_sqrt) and 2 packed adds for |s|: 40 VALU instructions per 4 terms. */
-/* PARTS: bit 0 = position / rounding / address (8 packed adds + 4 v_mul_u32_u24 per 4 terms), bit 1 = interpolation and
+/* The stream das_staged.hip ships (round 2, final form): per batch of four terms 4 packed adds (window position,
+ * round-by-magic-number), 4 v_mul_u32_u24 (tap address), 4 + 8 packed fmas (interpolation, rotate-accumulate),
+ * 4 x (v_mul, v_fmac, v_sqrt) and 2 packed adds for |s|: 36 VALU instructions per 4 terms. */
+/* PARTS: bit 0 = position / rounding / address (4 packed adds + 4 v_mul_u32_u24 per 4 terms), bit 1 = interpolation and
  * rotate-accumulate (12 packed fmas), bit 2 = |s| (4 x v_mul, v_fmac, v_sqrt + 2 packed adds); 7 = the whole stream.  The
  * parts run alone tell which of them the whole costs more than. */
 template <int PARTS>
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void term_probe_packed(Stamp *stamps, float *
 			const f32x2 M2 = {M, M}, rr = {r, r};
 			const f32x2 p01 = rr + tz01, p23 = rr + tz23;
 			const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
-			g01 = p01 - (y01 - M2); g23 = p23 - (y23 - M2);
+			g01 = p01; g23 = p23;                        /* the interpolation uses the position itself (line-form elements) */
 			const float ys[4] = {y01.x, y01.y, y23.x, y23.y};
 			#pragma unroll
 			for (int k = 0; k < 4; k++) {
@@ -483,9 +483,9 @@ int main(int argc, char **argv)
 	emit("],\n");
 	emit(" \"valu_stream\":[\n  ");
 	term_case();
-	term_packed_case<7>("das_staged term, shipping form: per 4 terms 8 x v_pk_add_f32 (position, magic-number rounding, fraction), 4 x v_mul_u32_u24, "
-	                    "12 x v_pk_fma_f32, 4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32), 2 x v_pk_add_f32 = 40 VALU instructions");
-	term_packed_case<1>("part of the shipping form alone: position / rounding / address (8 x v_pk_add_f32 + 4 x v_mul_u32_u24 per 4 terms)");
+	term_packed_case<7>("das_staged term, shipping form: per 4 terms 4 x v_pk_add_f32 (position, magic-number rounding), 4 x v_mul_u32_u24, "
+	                    "12 x v_pk_fma_f32, 4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32), 2 x v_pk_add_f32 = 36 VALU instructions");
+	term_packed_case<1>("part of the shipping form alone: position / rounding / address (4 x v_pk_add_f32 + 4 x v_mul_u32_u24 per 4 terms)");
 	term_packed_case<2>("part of the shipping form alone: interpolation + rotate-accumulate (12 x v_pk_fma_f32 per 4 terms)");
 	term_packed_case<4>("part of the shipping form alone: |s| (4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32) + 2 x v_pk_add_f32 per 4 terms)");
 	term_packed_case<6>("parts of the shipping form: interpolation + rotate-accumulate + |s| (no position part)");
