@@ -590,7 +590,7 @@ static bool factored_applies(const BfDasArgs &a, const std::vector<BfTransmit> &
  * per-stage events on one frame in kTimingSamplePeriod; the frames in between run with no event
  * at all and report the newest sampled timings in the stats table. */
 constexpr uint64_t kTimingSamplePeriod = 8;
-constexpr uint32_t kStagedMinTransmits = 12;     /* das_staged.hip by default from this many transmits per channel (tools/staged_threshold.py: 0.94 of the gather kernel's time at 12, 0.83 at 16, 0.73-0.76 at 32-75) */
+constexpr uint32_t kStagedMinTransmits = 6;      /* das_staged.hip by default from this many transmits per channel (tools/staged_threshold.py: 1.17 of the gather kernel's time at 4 transmits, 0.93 at 6-8, 0.85 at 10-12, 0.74 at 16, 0.68-0.71 at 32-75) */
 constexpr uint64_t kSmallFrameBytes    = 8ull << 20;
 
 static bool record(TimingSlot &t, uint32_t index, hipStream_t s)

@@ -64,7 +64,7 @@ SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_rea
 # can run the LDS-staged kernel (das_staged.hip): automatically from STAGED_MIN_TRANSMITS transmits per
 # channel (executor.cpp kStagedMinTransmits), on request (path 3) below that
 STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto"}
-STAGED_MIN_TRANSMITS = 12
+STAGED_MIN_TRANSMITS = 6
 
 
 def factored_applies(bp):
