@@ -25,6 +25,7 @@ import argparse
 import ctypes as C
 import hashlib
 import json
+import re
 import os
 import sys
 import time
@@ -371,12 +372,17 @@ def main():
 
 
 def kernel_source_hash():
+    """sha256 over the DAS kernel sources with comments and whitespace removed: a committed PMC figure stays valid
+    through edits that cannot change the code object, and is refused after any that can."""
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
         p = os.path.join(ROOT, "ogl_beamforming_amd", "csrc", name)
         if os.path.exists(p):
+            text = open(p, encoding="utf-8", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
             h.update(name.encode())
-            h.update(open(p, "rb").read())
+            h.update(re.sub(r"\s+", " ", text).strip().encode())
     return h.hexdigest()[:16]
 
 
@@ -401,7 +407,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
         to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
-      * the LDS-staged kernel -- VALU issue: the inner loop's VALU stream (40 instructions per 4 (voxel, channel,
+      * the LDS-staged kernel -- VALU issue: the inner loop's VALU stream (36 instructions per 4 (voxel, channel,
         transmit) terms), measured as a stream with no memory instruction in it ("valu_stream", shipping form);
     achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
@@ -410,12 +416,12 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             micro = json.load(f)
         cus = int(micro["compute_units"])
         if kernel == "das_rca_staged_kernel":
-            best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8 and "shipping form" in v["stream"]),
+            best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8 and v["stream"].startswith("das_staged term, shipping form")),
                        key=lambda v: v["cycles_per_term_per_simd_wall"])
             per_term = best["cycles_per_term_per_simd_wall"]
             peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / per_term          # terms per second with every SIMD issuing nothing else
             out = {
-                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the inner loop's 40 VALU instructions per 4 terms, measured as a stream with no memory instruction in it",
+                "resource": f"VALU issue: {per_term:.1f} clk per wave64 term per SIMD for the inner loop's 36 VALU instructions per 4 terms, measured as a stream with no memory instruction in it",
                 "achieved": terms / das_s / 1e12, "unit": "T terms/s (terms that pass the f-number test)",
                 "peak": peak / 1e12,
                 "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_term:.2f} clk",

@@ -16,33 +16,35 @@
  * Round 1's version of this kernel lost to the gather kernel (1327 against 1165 ms) because it
  * paid ~20 VALU instructions per term against the gather kernel's 14 (integer window bookkeeping,
  * an always-on range test, address arithmetic per tap), and VALU issue is what both kernels wait
- * for.  This version pays 10 (40 per batch of 4 terms):
+ * for.  This version pays 9 (36 per batch of 4 terms):
  *   * the window position is folded into the FLOAT tables: element j of window (c, a) holds sample
  *     floor(rmin_c) + floor(tmin_a) + j (rmin / tmin: the delay minima over the tile); the receive
- *     table hands the lane R' = R - floor(rmin_c) once per channel, the transmit table holds
- *     T'' = T - floor(tmin_a) - 1/2 -- all exact in f32 -- so ONE add gives the position p relative
- *     to the MIDDLE of the tap pair.  (A sum of two small numbers is rounded at 2^-19 of a sample
- *     instead of the absolute index's 2^-12: closer to exact arithmetic than the shader it restates.)
- *   * window elements are {midpoint, difference} of neighbouring samples, 16 bytes: the two taps are
- *     ONE aligned ds_read_b128 and the interpolation ONE packed fma, midpoint + g * difference;
- *   * no v_fract, no v_cvt: adding M = 2^23 + 1 + a*W rounds p to the nearest integer n and leaves the
- *     window ELEMENT INDEX in the low mantissa bits (y = p + M; n = y - M; g = p - n: packed adds over
- *     two terms, all exact); the tap's LDS address is (bits(y) & 0xFFFFFF) * 16, one v_mul_u32_u24,
- *     because the staging area starts one element into an LDS that holds nothing static;
+ *     table hands the lane R' = R - floor(rmin_c), the transmit table holds
+ *     T'' = T - floor(tmin_a) - 1/2 -- all exact in f32 -- so ONE add gives the position p in the
+ *     window, less 1/2.  (A sum of two small numbers is rounded at 2^-19 of a sample instead of the
+ *     absolute index's 2^-12: closer to exact arithmetic than the shader it restates.)
+ *   * window elements are LINES in window coordinates, {c_j, d_j} with d_j = s_(j+1) - s_j and
+ *     c_j = s_j + (1/2 - j) d_j, 16 bytes: the two taps are ONE aligned ds_read_b128 and the
+ *     interpolation ONE packed fma of the position itself, c_j + p d_j -- no fraction is formed;
+ *   * no v_fract, no v_cvt: adding M = 2^23 + 2 + a*W rounds p to the nearest integer and leaves the
+ *     window ELEMENT INDEX in the low mantissa bits of y = p + M (a packed add over two terms); the
+ *     tap's LDS address is (bits(y) & 0xFFFFFF) * 16, one v_mul_u32_u24, because the staging area
+ *     starts two elements into an LDS that holds nothing static;
  *   * transmits in pairs: one ds_read2_b64 serves four terms' delays, one ds_read_b128 two terms'
  *     phasors; the transmit table is padded to a multiple of 4 with zero phasors over a zero window
  *     row, so the last batch needs no select;
- *   * the range test of sample_rf (0 <= index < S - 1) is decided per wave and channel from the
- *     tile-wide extremes of T exactly as in das_separable.hip; only waves that can leave the row
- *     run the checked loop (absolute tap = window tap + the two floors; invalid taps read a zero element).
+ *   * the range test of sample_rf (0 <= index < S - 1) is decided per lane and channel when the
+ *     receive table is built (tile-wide extremes of T, as in das_separable.hip) and kept in the sign
+ *     of the entry's weight; only waves with such a lane run the checked loop (absolute tap = window
+ *     tap + the two floors; invalid taps read a zero element).
  *
  * Pipeline per channel: the buffer loads of the NEXT channel's windows are issued into registers
  * before the current channel is consumed and written to LDS after it (barrier - ds_write -
  * barrier); two 1024-thread blocks share a CU, so one block's barriers hide under the other's
  * arithmetic.  The host only launches this kernel when its bound on the delay spread of a tile fits
  * the window (plan_staged, executor.cpp).  No MFMA: gather-accumulate.  Measured (config 4, one
- * MI355X): 854-883 ms per 512^3 frame against 1116-1158 ms for the gather kernel; VALU 97 % busy,
- * 0.86-0.89 of the rate of its own VALU stream run without memory instructions.
+ * MI355X): 801-850 ms per 512^3 frame against 1128-1180 ms for the gather kernel; VALU 94 % busy,
+ * 0.81-0.85 of the rate of its own VALU stream run without memory instructions.
  */
 #include "das_common.h"
 
