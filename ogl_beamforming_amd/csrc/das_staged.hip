@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 	if (tile >= total) return;                               /* whole block */
 	uint32_t tu, tv, zl;                                     /* walk order: das_separable.hip */
-	if (q.depth_major) {
+	if (q.depth_major & 1u) {
 		zl = tile % q.tiles[2];
 		tu = (tile / q.tiles[2]) % q.tiles[0];
 		tv = tile / (q.tiles[2] * q.tiles[0]);
@@ -164,9 +164,15 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 		range.x = fminf(range.x, wave_range[w].x);
 		range.y = fmaxf(range.y, wave_range[w].y);
 	}
-	/* the same for every lane: keep it in scalar registers */
-	range.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, range.x)));
-	range.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, range.y)));
+	/* the same for every lane: keep it in scalar registers.  (Through scalar temporaries: __builtin_bit_cast applied
+	 * directly to a vector component reads the vector's FIRST component with this hipcc -- range.y silently became
+	 * range.x, and waves whose lanes reach the end of the RF row for the tile's largest transmit delay only took the
+	 * unchecked loop; found by the focused-transmit parity case, whose delays differ by hundreds of samples.) */
+	{
+		const float lo = range.x, hi = range.y;
+		range.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)));
+		range.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
+	}
 	/* per transmit: floor of the smallest delay of its table row; the row becomes window-relative */
 	for (uint32_t a = tid; a < (uint32_t)A4; a += nthreads) {
 		float *row = reinterpret_cast<float *>(Tz + (size_t)(a >> 1) * V) + (a & 1u);
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				r_rel = r.x; r_w = r.w;
 			}
 			if (__builtin_amdgcn_ballot_w64(r_w != 0.f) == 0) continue;    /* F# culling per wave */
-			const bool wave_safe = __builtin_amdgcn_ballot_w64(__builtin_signbitf(r_w)) == 0;
+			const bool wave_safe = !(q.depth_major & 2u) && __builtin_amdgcn_ballot_w64(__builtin_signbitf(r_w)) == 0;   /* bit 1: test hook, checked loop everywhere */
 			f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 			f32x2 mag2 = {0.f, 0.f};
 			/* one term: pos = position in the window (minus 1/2), tap = the line {c, d} of the element round(pos) selects */

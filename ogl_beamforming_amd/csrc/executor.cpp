@@ -471,6 +471,15 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + 4;       /* + taps, floors, rounding slack */
 			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
 			if (!ws) continue;
+			/* BEAMFORMER_HIP_STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
+			 * a window larger than needed is legal, a smaller one is not taken) */
+			if (const char *force = std::getenv("BEAMFORMER_HIP_STAGED_SHAPE")) {
+				unsigned fu = 0, fv = 0, fw = 0;
+				if (std::sscanf(force, "%u,%u,%u", &fu, &fv, &fw) == 3) {
+					if (fu != us || fv != vs || fw < ws || fw > 6) continue;
+					ws = fw;
+				}
+			}
 			if (((uint64_t)A4 << ws) > ((uint64_t)4 << threads_shift)) continue;  /* BF_STAGE_MAX_LOADS */
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
@@ -492,6 +501,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			}
 		}
 	}
+	if (std::getenv("BEAMFORMER_HIP_STAGED_CHECKED")) best.depth_major |= 2u;      /* test hook: the range-checked loop for every wave */
 	if (std::getenv("BEAMFORMER_HIP_DEBUG"))
 		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u\n",
 		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_shift, best.channel_chunk, best.lds_bytes);

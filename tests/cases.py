@@ -50,6 +50,15 @@ def _cases():
     # a multiple of 4: the zero-padded transmit batch)
     c["rca_staged_auto"] = lambda: cfg.rca("rca_staged_auto", 32, 13, 512, (40, 36, 3), LO3, HI3, seed=46, orientation=0x12,
                                            cw=True, f_number=0.6, angles=np.linspace(-12, 12, 13))
+    # focused / diverging transmits (distances instead of plane-wave projections in the transmit table) on the staged kernel
+    c["rca_vls_staged"] = lambda: cfg.rca("rca_vls_staged", 32, 8, 2048, (40, 36, 3), LO3, HI3, seed=47, orientation=0x12, cw=True,
+                                          kind=K.RCA_VLS, f_number=0.6, angles=np.linspace(-8, 8, 8),
+                                          depths=np.array([-12e-3, 30e-3, -20e-3, 45e-3, 25e-3, -15e-3, 60e-3, -30e-3]))
+    # the same focused transmits over RF rows too short for most of them: terms that fall off the end of a row in nearly every
+    # wave (the unchecked / checked loop decision of the staged kernel; 256 samples after demodulation)
+    c["rca_vls_staged_short_rows"] = lambda: cfg.rca("rca_vls_staged_short_rows", 32, 8, 512, (40, 36, 3), LO3, HI3, seed=48,
+                                                     orientation=0x12, cw=True, kind=K.RCA_VLS, f_number=0.6, angles=np.linspace(-8, 8, 8),
+                                                     depths=np.array([-12e-3, 30e-3, -20e-3, 45e-3, 25e-3, -15e-3, 60e-3, -30e-3]))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

@@ -59,11 +59,11 @@ def last_das_path(bflib):
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
 # them up on its own (das_separable.hip)
 SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest",
-             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto"}
+             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows"}
 # ... and of those, the linear-interpolation complex ones whose delay spread fits an LDS window
 # can run the LDS-staged kernel (das_staged.hip): automatically from STAGED_MIN_TRANSMITS transmits per
 # channel (executor.cpp kStagedMinTransmits), on request (path 3) below that
-STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto"}
+STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows"}
 STAGED_MIN_TRANSMITS = 6
 
 
@@ -159,6 +159,23 @@ def test_lds_staged_kernel(name, bflib, oracle):
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert last_das_path(bflib) == (2 if name in STAGED else 1)
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq, flags)
+
+
+@pytest.mark.parametrize("name", sorted(STAGED))
+def test_lds_staged_kernel_checked_loop_everywhere(name, bflib, oracle, monkeypatch):
+    """BEAMFORMER_HIP_STAGED_CHECKED: every wave of the staged kernel runs the range-checked loop (normally only the
+    waves that can leave the RF row do): the oracle's frame either way"""
+    acq = cases.make(name)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    monkeypatch.setenv("BEAMFORMER_HIP_STAGED_CHECKED", "1")
+    lib.beamformer_hip_set_das_path(3)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert last_das_path(bflib) == 2
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)
