@@ -164,6 +164,28 @@ def test_lds_staged_kernel(name, bflib, oracle):
     compare(gpu, ref, acq, flags)
 
 
+@pytest.mark.parametrize("shape", ["5,4,5", "4,5,5", "6,4,5", "5,5,5", "4,6,5", "5,4,6", "4,5,6", "6,4,6", "5,5,6", "4,6,6"])
+@pytest.mark.parametrize("name", ["rca_staged_auto", "rca_staged_ragged"])
+def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracle, monkeypatch):
+    """BEAMFORMER_HIP_STAGED_SHAPE = "log2 U, log2 V, log2 W": each instantiation of the staged kernel (tile extents along
+    the receive / transmit axes, 32- or 64-sample windows, 512- and 1024-thread blocks) instead of the shape the host would
+    pick; a shape whose window cannot hold the tile's delay spread is declined and the gather kernel runs"""
+    acq = cases.make(name)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    monkeypatch.setenv("BEAMFORMER_HIP_STAGED_SHAPE", shape)
+    lib.beamformer_hip_set_das_path(3)
+    try:
+        gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        path = last_das_path(bflib)
+        assert path in (1, 2)
+        if shape in ("5,4,6", "4,5,6", "5,5,6", "4,6,6") and name == "rca_staged_auto":
+            assert path == 2                     # a 64-sample window holds this case's spread for tiles up to 32 voxels along the receive axis
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(gpu, ref, acq, flags)
+
+
 @pytest.mark.parametrize("name", sorted(STAGED))
 def test_lds_staged_kernel_checked_loop_everywhere(name, bflib, oracle, monkeypatch):
     """BEAMFORMER_HIP_STAGED_CHECKED: every wave of the staged kernel runs the range-checked loop (normally only the
