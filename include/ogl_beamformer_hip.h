@@ -183,6 +183,13 @@ typedef enum {
 	BeamformerHipDasPath_DenseDecode      = 0x20, /* flag: Decode on the O(T^2) kernel, not the Walsh-Hadamard form */
 } BeamformerHipDasPath;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
+/* Environment variables the library reads (measurement and test aids; none is needed in production):
+ *   BEAMFORMER_HIP_DEVICE            HIP ordinal of the one-device mode (else LOCAL_RANK, else 0)
+ *   BEAMFORMER_HIP_FRAME_RING_BYTES  size of the beamformed-frame ring (default 4 GiB)
+ *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major
+ *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
+ *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernel's range-checked loop for every wave
+ *   BEAMFORMER_HIP_DEBUG             one line per staged-kernel plan on stderr */
 
 /* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----
  * Host only, no device needed.  The reference keeps this loader in its throughput harness;
