@@ -43,7 +43,7 @@ PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-dela
 KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
                 "das_hercules_kernel"]
 # the sources whose hash ties a committed PMC figure to the code that produced it (tools/pmc_das.py)
-KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_hercules.hip", "bf_kernels.h"]
+KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_hercules.hip", "bf_kernels.h"]
 
 
 def parse():

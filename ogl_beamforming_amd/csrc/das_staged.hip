@@ -62,15 +62,14 @@ __device__ __forceinline__ float staged_phase_turns(float k, float index)
 }
 
 /* LDS (A4 = transmits rounded up to a multiple of 4; transmits are kept in PAIRS so that one read serves two terms):
- *   Tcs[(a/2)*V + v] = { cos(phi_t), sin(phi_t) of transmit a & ~1, then of transmit a | 1 }          f32x4
+ *   stage[a*W + j]   = { c_j, d_j }: the line through samples j and j + 1 of window (c, a) in window coordinates
+ *                      (d_j = s' - s, c_j = s + (1/2 - j) d_j; s = sample floor(rmin_c) + floor(tmin_a) + j of row (c, a),
+ *                      s' the next one); j < W, a < A4; two unused elements in front, one zero element behind   f32x4
+ *   Tcs[(a/2)*V + v] = { cos(phi_t), sin(phi_t) of transmit a & ~1, then of transmit a | 1 }                   f32x4
  *   R[cl*U + u]      = { R' = r_index - floor(rmin_c), apod*cos(phi_r), apod*sin(phi_r), +-apod }   cl: channel in chunk;
- *                      the weight's sign bit set = the lane may leave the RF row (checked loop)          f32x4
- *   stage[a*W + j]   = { (s + s') / 2, s' - s }: s = sample floor(rmin_c) + floor(tmin_a) + j of row (c, a), s' the
- *                      next one -- midpoint and difference; j < W, a < A4; then one zero element         f32x4
- *   Tz[(a/2)*V + v]  = { T'' = t_index - floor(tmin_a) - 1/2 of transmit a & ~1, of transmit a | 1 }     f32x2
- *   tfl[a]           = floor(tmin_a)  (checked loop and staging only),  rfloor[cl] = floor(rmin_c)       int
- * Keeping {midpoint, difference} makes the two taps ONE 16-byte aligned read and the interpolation one packed fma
- * of the position relative to the middle of the pair. */
+ *                      the weight's sign bit set = the lane may leave the RF row (checked loop)                  f32x4
+ *   Tz[(a/2)*V + v]  = { T'' = t_index - floor(tmin_a) - 1/2 of transmit a & ~1, of transmit a | 1 }             f32x2
+ *   tfl[a]           = floor(tmin_a)  (checked loop and staging only),  rfloor[cl] = floor(rmin_c)               int */
 /* NL: window elements a thread stages per channel, ceil(A4 * W / threads) */
 template <bool CW, int VS, int WS, int NL>
 __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs p, const BfSeparableArgs q)

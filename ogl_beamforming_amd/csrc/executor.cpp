@@ -437,10 +437,11 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
 static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
                         uint32_t zcount, BfSeparableArgs &q)
 {
-	if (!a.complex_data || a.interpolation != 1) return false;
+	if (a.interpolation != 1) return false;
+	const bool cplx = a.complex_data != 0;                       /* das_staged.hip / das_staged_real.hip */
 	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
-	/* the kernel stages through 32-bit buffer offsets and parks its padding loads at 2^31 */
-	if ((uint64_t)C * A * (uint64_t)a.sample_count * 8u >= (1ull << 31)) return false;
+	/* the kernels stage through 32-bit buffer offsets and park their padding loads at 2^31 */
+	if ((uint64_t)C * A * (uint64_t)a.sample_count * (cplx ? 8u : 4u) >= (1ull << 31)) return false;
 	const uint32_t A4 = (A + 3u) & ~3u;                          /* the kernel pads the transmit table to whole batches of 4 */
 	const int u_axis = (int)q.u_axis, v_axis = 1 - u_axis;
 	const int r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0, w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;
@@ -484,7 +485,8 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
-				uint64_t lds = 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128;
+				uint64_t lds = cplx ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
+				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (((uint64_t)A4 << ws) + 4) + 4ull * (A4 + cc + 1) + 128;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
 				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = 2048u >> threads_shift;
@@ -863,7 +865,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					 * carries enough transmits to amortise them (kStagedMinTransmits, measured: tools/staged_threshold.py) */
 					const bool want_staged = das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits);
 					if (want_staged && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
-						ok &= HIP_OK(bf_launch_das_staged(&a, &sep, s));
+						ok &= HIP_OK(plan.iq_pipeline ? bf_launch_das_staged(&a, &sep, s) : bf_launch_das_staged_real(&a, &sep, s));
 						das_path = 2;
 					} else {
 						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));

@@ -59,6 +59,13 @@ def _cases():
     c["rca_vls_staged_short_rows"] = lambda: cfg.rca("rca_vls_staged_short_rows", 32, 8, 512, (40, 36, 3), LO3, HI3, seed=48,
                                                      orientation=0x12, cw=True, kind=K.RCA_VLS, f_number=0.6, angles=np.linspace(-8, 8, 8),
                                                      depths=np.array([-12e-3, 30e-3, -20e-3, 45e-3, 25e-3, -15e-3, 60e-3, -30e-3]))
+    # real samples (no Demodulate) on the staged kernel's real-data twin, with and without coherency weighting; 9 transmits
+    # (padded batch), short rows in the second one (checked loop)
+    c["rca_staged_real"] = lambda: cfg.rca("rca_staged_real", 32, 9, 1024, (40, 36, 3), LO3, HI3, seed=49, orientation=0x12, cw=True,
+                                           demodulate=False, data_kind=D.Int16, f_number=0.6, angles=np.linspace(-12, 12, 9))
+    c["rca_staged_real_short_rows"] = lambda: cfg.rca("rca_staged_real_short_rows", 24, 7, 256, (45, 70, 2), LO3, HI3, seed=50,
+                                                      orientation=0x21, cw=False, demodulate=False, data_kind=D.Float32, f_number=0.6,
+                                                      angles=np.linspace(-12, 12, 7))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

@@ -59,11 +59,11 @@ def last_das_path(bflib):
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
 # them up on its own (das_separable.hip)
 SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest",
-             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows"}
-# ... and of those, the linear-interpolation complex ones whose delay spread fits an LDS window
+             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows"}
+# ... and of those, the linear-interpolation ones (complex or real samples) whose delay spread fits an LDS window
 # can run the LDS-staged kernel (das_staged.hip): automatically from STAGED_MIN_TRANSMITS transmits per
 # channel (executor.cpp kStagedMinTransmits), on request (path 3) below that
-STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows"}
+STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows"}
 STAGED_MIN_TRANSMITS = 6
 
 
