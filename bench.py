@@ -42,9 +42,11 @@ PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-dela
               "(retired: LDS row-cache experiment)", "HERCULES aligned-grid kernel"]
 KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
                 "das_hercules_kernel"]
-# the sources whose hash ties a committed PMC figure to the code that produced it (tools/pmc_das.py)
-KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_hercules.hip", "bf_kernels.h"]
-
+# the sources whose hash ties a committed PMC figure to the code that produced it (tools/summarize_profiles.py): the
+# kernel's own file plus the headers every DAS kernel includes
+KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
+                "das_rca_staged_real_kernel": "das_staged_real.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
+COMMON_SOURCES = ["das_common.h", "bf_kernels.h"]
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -371,11 +373,12 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_source_hash():
-    """sha256 over the DAS kernel sources with comments and whitespace removed: a committed PMC figure stays valid
-    through edits that cannot change the code object, and is refused after any that can."""
+def kernel_source_hash(kernel):
+    """sha256 over the sources of one DAS kernel (its file + the common headers) with comments and whitespace removed: a
+    committed PMC figure stays valid through edits that cannot change that kernel's code object, and is refused after any
+    that can."""
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
+    for name in [KERNEL_FILES.get(kernel, "das.hip")] + COMMON_SOURCES:
         p = os.path.join(ROOT, "ogl_beamforming_amd", "csrc", name)
         if os.path.exists(p):
             text = open(p, encoding="utf-8", errors="replace").read()
@@ -397,8 +400,8 @@ def measured_traffic(config, kernel):
         entry = table[f"config{config}"][kernel]
     except (OSError, KeyError, ValueError):
         return None, "no committed PMC pass for this configuration and kernel"
-    if entry.get("kernel_source_sha16") != kernel_source_hash():
-        return None, f"profiles/das_traffic.json is stale: taken at kernel sources {entry.get('kernel_source_sha16')}, now {kernel_source_hash()}"
+    if entry.get("kernel_source_sha16") != kernel_source_hash(kernel):
+        return None, f"profiles/das_traffic.json is stale: taken at kernel sources {entry.get('kernel_source_sha16')}, now {kernel_source_hash(kernel)}"
     return entry["hbm_bytes_per_launch"], (f"profiles/das_traffic.json ({entry.get('round', '?')}): rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of "
                                           f"`{entry.get('command', 'bench.py')}`, kernel sources {entry.get('kernel_source_sha16')}")
 
@@ -461,7 +464,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             out["sustained_clock_ghz_est"] = clock
             out["frac_at_sustained_clock"] = out["frac"] * out["probe_clock_ghz"] / clock
         out["valu_source"] = (f"profiles/r02_das_bound.json: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
-                              f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash() else " (STALE: sources changed since)"))
+                              f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash(kernel) else " (STALE: sources changed since)"))
         if kernel != "das_rca_staged_kernel" and entry["valu_busy_frac"] > out.get("frac", 0):
             out["resource_note"] = "VALU issue is the tighter bound for this kernel (valu_busy_frac)"
     except (OSError, KeyError, ValueError):

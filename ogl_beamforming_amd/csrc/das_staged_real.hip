@@ -297,6 +297,8 @@ static hipError_t launch_staged_real_loads(const BfDasArgs *a, const BfSeparable
 	case 2: return launch_staged_real<CW, VS, WS, 2>(a, q, s);
 	case 3: return launch_staged_real<CW, VS, WS, 3>(a, q, s);
 	case 4: return launch_staged_real<CW, VS, WS, 4>(a, q, s);
+	case 5: case 6: return launch_staged_real<CW, VS, WS, 6>(a, q, s);       /* (a staging width larger than needed only loads zeros) */
+	case 7: case 8: return launch_staged_real<CW, VS, WS, 8>(a, q, s);
 	}
 	return hipErrorInvalidValue;
 }

@@ -481,7 +481,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 					ws = fw;
 				}
 			}
-			if (((uint64_t)A4 << ws) > ((uint64_t)4 << threads_shift)) continue;  /* BF_STAGE_MAX_LOADS */
+			if (((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;  /* window elements a thread stages per channel: 4 (complex: registers), 8 (real) */
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */

@@ -297,18 +297,20 @@ def test_config2_f32_complex_first_and_last_rows(bflib, oracle):
     print(f"config 2 geometry, f32 complex RF: max error {worst[0]:.2e} of the peak, {worst[1]:.2e} of the rows' own maximum")
 
 
-@pytest.mark.parametrize("transmits", [24, 48, 100, 128])
-def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits, bflib):
-    """The staged kernel's staging width per thread is a template parameter (1 to 4 window elements per thread and
-    channel, by the transmit count); the BASELINE configurations only reach two of them.  Config 4's geometry at
-    128 channels with 24 to 128 transmits, one slab: the staged kernel (automatic) against the gather kernel (path 2),
-    which the oracle-checked tests hold to the oracle."""
+@pytest.mark.parametrize("demodulate", [True, False], ids=["iq", "real"])
+@pytest.mark.parametrize("transmits", [24, 48, 75, 100, 128])
+def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits, demodulate, bflib):
+    """The staged kernels' staging width per thread is a template parameter (1 to 4 window elements per thread and
+    channel for IQ samples, up to 8 for real ones, by the transmit count and the window size); the BASELINE
+    configurations only reach two of them.  Config 4's geometry at 128 channels with 24 to 128 transmits, IQ
+    (Demodulate) and real (undecimated: 64-sample windows) samples, one slab: the staged kernel (automatic) against
+    the gather kernel (path 2), which the oracle-checked tests hold to the oracle."""
     Cn, S = 128, 2048
     half = (Cn - 1) / 2 * 0.15e-3
     path = S / 25e6 * cfg.SPEED_OF_SOUND
     z0, z1 = 0.12 * path, 0.30 * path
     acq = cfg.rca(f"tx{transmits}", Cn, transmits, S, (256, 256, 256), (-half, -half, z0), (half, half, z1), seed=9, cw=True,
-                  pitch=0.15e-3, orientation=0x12, f_number=0.5, angles=np.linspace(-18.5, 18.5, transmits))
+                  pitch=0.15e-3, orientation=0x12, f_number=0.5, angles=np.linspace(-18.5, 18.5, transmits), demodulate=demodulate)
     t = P.HipFrameTimings()
     staged = run(bflib, acq, shard=(120, 4))
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 2

@@ -11,11 +11,29 @@
 usage: summarize_profiles.py --round r02 <pmc summary.json> [...]     (run from the repository root)
 A summary whose command has no --planes is a whole frame and feeds das_traffic.json as well."""
 import argparse
+import hashlib
 import json
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# as bench.py: the kernel's own file plus the headers every DAS kernel includes, comments and whitespace removed
+KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
+                "das_rca_staged_real_kernel": "das_staged_real.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
+COMMON_SOURCES = ["das_common.h", "bf_kernels.h"]
+
+
+def kernel_source_hash(kernel):
+    h = hashlib.sha256()
+    for name in [KERNEL_FILES.get(kernel, "das.hip")] + COMMON_SOURCES:
+        p = os.path.join(ROOT, "ogl_beamforming_amd", "csrc", name)
+        if os.path.exists(p):
+            text = open(p, encoding="utf-8", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
+            h.update(name.encode())
+            h.update(re.sub(r"\s+", " ", text).strip().encode())
+    return h.hexdigest()[:16]
 SIMDS = 256 * 4
 # compulsory HBM traffic of the DAS launch: its input RF once + the volume once (SURVEY 8d shapes)
 COMPULSORY = {2: 128 * 31 * 2048 * 8 + 1024 * 1024 * 8, 3: 32 * 32 * 2048 * 4 + 256 ** 3 * 4,
@@ -45,7 +63,7 @@ def main():
         key = f"config{config}"
         if "GRBM_GUI_ACTIVE" in c:
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # shader-clock cycles the launches were resident, all dispatches
-            e = {"command": s["command"], "kernel_source_sha16": s["kernel_source_sha16"], "dispatches_summed": n,
+            e = {"command": s["command"], "kernel_source_sha16": kernel_source_hash(kernel), "tree_sha16_at_run": s["kernel_source_sha16"], "dispatches_summed": n,
                  "planes": int(planes.group(1)) if planes else "whole frame", "kernel_cycles_per_launch": cycles / n}
             if "SQ_ACTIVE_INST_VALU" in c:
                 e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * SIMDS)
@@ -86,7 +104,7 @@ def main():
                 "fetch_size_kib": c["FETCH_SIZE"] / n, "write_size_kib": c["WRITE_SIZE"] / n, "hbm_bytes_per_launch": hbm,
                 "compulsory_bytes": COMPULSORY.get(config), "ratio_to_compulsory": hbm / COMPULSORY[config] if config in COMPULSORY else None,
                 "l2_hit_rate": (c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])) if "TCC_HIT_sum" in c else None,
-                "launches_averaged": n, "round": args.round, "command": s["command"], "kernel_source_sha16": s["kernel_source_sha16"]}
+                "launches_averaged": n, "round": args.round, "command": s["command"], "kernel_source_sha16": kernel_source_hash(kernel), "tree_sha16_at_run": s["kernel_source_sha16"]}
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     json.dump(bound, open(bound_path, "w"), indent=1)
     print("wrote", traffic_path, bound_path)
