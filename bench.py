@@ -45,7 +45,7 @@ KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel
 # the sources whose hash ties a committed PMC figure to the code that produced it (tools/summarize_profiles.py): the
 # kernel's own file plus the headers every DAS kernel includes
 KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
-                "das_rca_staged_real_kernel": "das_staged_real.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
+                "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
 COMMON_SOURCES = ["das_common.h", "bf_kernels.h"]
 
 def parse():

@@ -158,9 +158,10 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_display_last_frame(float threshold
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_enable_hilbert(uint32_t enable);
 
 /* Select the DAS implementation: 0 = automatic.  Row-column frames whose receive aperture and transmit
- * steering lie along different array axes (separable delays) and that use linear interpolation run the
- * LDS-staged kernel (das_staged.hip / das_staged_real.hip: a tile's delay spread inside its LDS window, at least
- * 6 transmits per channel) or else the gather kernel (das_separable.hip); otherwise the per-voxel factored
+ * steering lie along different array axes (separable delays) run the LDS-staged kernels (das_staged.hip /
+ * das_staged_real.hip for linear interpolation of IQ / real samples, das_staged_cubic.hip for cubic interpolation of
+ * IQ samples: a tile's delay spread inside its LDS window, at least 6 transmits per channel) or else, for linear
+ * interpolation, the gather kernel (das_separable.hip); otherwise the per-voxel factored
  * kernel takes RCA-family and FORCES frames with three or more transmits, the gather kernel the remaining
  * separable ones, the general kernel everything else.  1 = always the general kernel, 2 = as automatic but
  * never the LDS-staged kernel, 3 = the LDS-staged kernel wherever its window bound holds (also below 6

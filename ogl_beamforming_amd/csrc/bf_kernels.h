@@ -150,6 +150,7 @@ hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 hipError_t bf_launch_das_staged_real(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
+hipError_t bf_launch_das_staged_cubic(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
  * 2*1024 floats */
 hipError_t bf_launch_das_factored(const BfDasArgs *a, hipStream_t s);

@@ -437,8 +437,9 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
 static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
                         uint32_t zcount, BfSeparableArgs &q)
 {
-	if (a.interpolation != 1) return false;
 	const bool cplx = a.complex_data != 0;                       /* das_staged.hip / das_staged_real.hip */
+	const bool cubic = a.interpolation == 2;                     /* das_staged_cubic.hip: complex samples only */
+	if (a.interpolation != 1 && !(cubic && cplx)) return false;
 	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
 	/* the kernels stage through 32-bit buffer offsets and park their padding loads at 2^31 */
 	if ((uint64_t)C * A * (uint64_t)a.sample_count * (cplx ? 8u : 4u) >= (1ull << 31)) return false;
@@ -469,7 +470,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			if ((u_axis == 0 ? us : vs) < 4) continue;
 			float spread = step_u * (float)((1u << us) - 1) + step_v * (float)((1u << vs) - 1);
 			if (!(spread >= 0.f && spread <= 60.f)) continue;                /* also a NaN / infinite spread (wild parameters) */
-			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + 4;       /* + taps, floors, rounding slack */
+			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + (cubic ? 6 : 4);   /* + taps (k - 1 .. k + 2 for cubic), floors, rounding slack */
 			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
 			if (!ws) continue;
 			/* BEAMFORMER_HIP_STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
@@ -485,11 +486,12 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
-				uint64_t lds = cplx ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
+				uint64_t lds = cubic ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 32ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
+				             : cplx ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
 				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (((uint64_t)A4 << ws) + 4) + 4ull * (A4 + cc + 1) + 128;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
-				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = 2048u >> threads_shift;
+				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = (cubic ? 1024u : 2048u) >> threads_shift;   /* (cubic: 128 VGPRs per lane) */
 				if (blocks > by_waves) blocks = by_waves;
 				uint32_t waves = blocks << (threads_shift - 6);
 				uint32_t balance = us > vs ? us - vs : vs - us;
@@ -852,8 +854,17 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				 * and nearest its generic loop loses to the factored kernel (200 ch x 33 tx -> 129 x 333 x 21,
 				 * cubic: 7.6 ms against 4.8 ms; nearest 2.6 against 2.1), which then goes first. */
 				const uint32_t das_mode = c.das_path_mode & 0xF;
-				const bool tables_first = a.interpolation == 1 || das_mode == 3 ||
-				                          !factored_applies(a, ps->transmit_table, das_mode);
+				/* (cubic IQ frames with enough transmits try the staged cubic kernel first: it declines -- and the factored
+				 * kernel runs -- when the geometry is not separable or the delay spread does not fit a window) */
+				const bool staged_cubic = a.interpolation == 2 && plan.iq_pipeline && (das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits));
+				bool tables_first = a.interpolation == 1 || das_mode == 3 || staged_cubic ||
+				                    !factored_applies(a, ps->transmit_table, das_mode);
+				if (staged_cubic && das_mode != 3 && tables_first && a.interpolation == 2) {
+					BfSeparableArgs probe{};
+					if (!(plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, probe) &&
+					      plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, probe)))
+						tables_first = !factored_applies(a, ps->transmit_table, das_mode);
+				}
 				if (das_mode != 1 && das_mode != 4 && tables_first &&
 				    plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
 					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
@@ -865,7 +876,8 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					 * carries enough transmits to amortise them (kStagedMinTransmits, measured: tools/staged_threshold.py) */
 					const bool want_staged = das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits);
 					if (want_staged && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
-						ok &= HIP_OK(plan.iq_pipeline ? bf_launch_das_staged(&a, &sep, s) : bf_launch_das_staged_real(&a, &sep, s));
+						ok &= HIP_OK(!plan.iq_pipeline ? bf_launch_das_staged_real(&a, &sep, s) :
+						             a.interpolation == 2 ? bf_launch_das_staged_cubic(&a, &sep, s) : bf_launch_das_staged(&a, &sep, s));
 						das_path = 2;
 					} else {
 						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));

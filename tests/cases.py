@@ -66,6 +66,13 @@ def _cases():
     c["rca_staged_real_short_rows"] = lambda: cfg.rca("rca_staged_real_short_rows", 24, 7, 256, (45, 70, 2), LO3, HI3, seed=50,
                                                       orientation=0x21, cw=False, demodulate=False, data_kind=D.Float32, f_number=0.6,
                                                       angles=np.linspace(-12, 12, 7))
+    # cubic interpolation of IQ samples on the staged kernel's cubic twin (9 transmits: padded batch), and with rows short enough
+    # that most waves run its checked loop
+    c["rca_staged_cubic"] = lambda: cfg.rca("rca_staged_cubic", 32, 9, 1024, (40, 36, 3), LO3, HI3, seed=51, orientation=0x12, cw=True,
+                                            interp=I.Cubic, f_number=0.6, angles=np.linspace(-12, 12, 9))
+    c["rca_staged_cubic_short_rows"] = lambda: cfg.rca("rca_staged_cubic_short_rows", 24, 7, 384, (45, 70, 2), LO3, HI3, seed=52,
+                                                       orientation=0x21, cw=False, interp=I.Cubic, f_number=0.6,
+                                                       angles=np.linspace(-12, 12, 7))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

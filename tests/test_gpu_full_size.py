@@ -167,7 +167,7 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
                                                 (P.InterpolationMode.Nearest, True, (257, 96, 19))])
 def test_odd_shapes_at_medium_size(interp, cw, points, bflib, oracle):
     """200 channels x 33 transmits into grids that are no multiple of any tile, on the automatic
-    path (linear: the LDS-staged kernel), the gather kernel, the factored kernel and the general kernel: oracle
+    path (linear and cubic: the LDS-staged kernels), the gather kernel, the factored kernel and the general kernel: oracle
     rows of the middle plane."""
     path = 0.40 * 3072 / 25e6 * 1540.0
     acq = cfg.rca("odd", 200, 33, 3072, points, (-14e-3, -9e-3, 0.15 * path), (14e-3, 9e-3, 0.40 * path), seed=5,
@@ -200,7 +200,7 @@ def test_odd_shapes_at_medium_size(interp, cw, points, bflib, oracle):
             assert np.median(err) < 1e-4
         else:
             assert err.max() <= 2e-3                                          # Int16 -> f16-staged Demodulate
-    assert seen == ({2, 1, 3, 0} if interp == P.InterpolationMode.Linear else {3, 0})
+    assert seen == ({2, 1, 3, 0} if interp == P.InterpolationMode.Linear else {2, 3, 0} if interp == P.InterpolationMode.Cubic else {3, 0})
 
 
 def _f32c_rca(name, C, A, points, lo, hi, *, seed, interp, cw, pitch, f_number, orientation, angles, scatterer):
@@ -297,25 +297,32 @@ def test_config2_f32_complex_first_and_last_rows(bflib, oracle):
     print(f"config 2 geometry, f32 complex RF: max error {worst[0]:.2e} of the peak, {worst[1]:.2e} of the rows' own maximum")
 
 
-@pytest.mark.parametrize("demodulate", [True, False], ids=["iq", "real"])
+@pytest.mark.parametrize("demodulate, interp", [(True, P.InterpolationMode.Linear), (False, P.InterpolationMode.Linear),
+                                                (True, P.InterpolationMode.Cubic)], ids=["iq", "real", "iq_cubic"])
 @pytest.mark.parametrize("transmits", [24, 48, 75, 100, 128])
-def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits, demodulate, bflib):
+def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits, demodulate, interp, bflib):
     """The staged kernels' staging width per thread is a template parameter (1 to 4 window elements per thread and
     channel for IQ samples, up to 8 for real ones, by the transmit count and the window size); the BASELINE
     configurations only reach two of them.  Config 4's geometry at 128 channels with 24 to 128 transmits, IQ
-    (Demodulate) and real (undecimated: 64-sample windows) samples, one slab: the staged kernel (automatic) against
-    the gather kernel (path 2), which the oracle-checked tests hold to the oracle."""
+    (Demodulate; linear and cubic) and real (undecimated: 64-sample windows) samples, one slab: the staged kernel
+    (automatic) against what path 2 runs -- the gather kernel, or the factored kernel for cubic --, which the
+    oracle-checked tests hold to the oracle."""
     Cn, S = 128, 2048
     half = (Cn - 1) / 2 * 0.15e-3
     path = S / 25e6 * cfg.SPEED_OF_SOUND
     z0, z1 = 0.12 * path, 0.30 * path
     acq = cfg.rca(f"tx{transmits}", Cn, transmits, S, (256, 256, 256), (-half, -half, z0), (half, half, z1), seed=9, cw=True,
-                  pitch=0.15e-3, orientation=0x12, f_number=0.5, angles=np.linspace(-18.5, 18.5, transmits), demodulate=demodulate)
+                  pitch=0.15e-3, orientation=0x12, f_number=0.5, angles=np.linspace(-18.5, 18.5, transmits), demodulate=demodulate, interp=interp)
     t = P.HipFrameTimings()
     staged = run(bflib, acq, shard=(120, 4))
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 2
-    gathered = run(bflib, acq, shard=(120, 4), path=2)
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 1
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
+    if interp == P.InterpolationMode.Cubic and transmits == 128:
+        # 128 transmits x 32-byte window elements do not fit the LDS: the staged cubic kernel declines, the factored kernel runs
+        assert int(t.das_path) == 3
+        return
+    assert int(t.das_path) == 2
+    gathered = run(bflib, acq, shard=(120, 4), path=2)          # cubic: the factored kernel
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == (3 if interp == P.InterpolationMode.Cubic else 1)
     assert np.array_equal(np.isnan(staged), np.isnan(gathered))
     ok = ~np.isnan(gathered)
     assert ok.any() and np.abs(staged[ok] - gathered[ok]).max() / np.abs(gathered[ok]).max() < 1e-4

@@ -59,11 +59,13 @@ def last_das_path(bflib):
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
 # them up on its own (das_separable.hip)
 SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest",
-             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows"}
-# ... and of those, the linear-interpolation ones (complex or real samples) whose delay spread fits an LDS window
+             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows", "rca_staged_cubic", "rca_staged_cubic_short_rows"}
+# ... and of those, the ones with linear interpolation (complex or real samples) or cubic interpolation of complex samples whose
+# delay spread fits an LDS window
 # can run the LDS-staged kernel (das_staged.hip): automatically from STAGED_MIN_TRANSMITS transmits per
 # channel (executor.cpp kStagedMinTransmits), on request (path 3) below that
-STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows"}
+STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows", "rca_staged_cubic", "rca_staged_cubic_short_rows",
+          "rca_sep_ragged_cubic"}
 STAGED_MIN_TRANSMITS = 6
 
 
@@ -100,9 +102,11 @@ def expected_path(name, bp):
         return 5
     # the LDS-table kernel goes first for linear interpolation; for cubic and nearest the
     # factored kernel does where it applies (executor.cpp), the table kernel otherwise
+    if name in STAGED and bp.acquisition_count >= STAGED_MIN_TRANSMITS:
+        return 2                                 # linear (IQ or real) and cubic IQ frames: the staged kernels go first
     if name in SEPARABLE and (bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp)
                               or bp.acquisition_count < 3):
-        return 2 if name in STAGED and bp.acquisition_count >= STAGED_MIN_TRANSMITS else 1
+        return 1
     transmits = bp.acquisition_count - (1 if P.AcquisitionKind(bp.acquisition_kind) == P.AcquisitionKind.UFORCES else 0)
     return 3 if factored_applies(bp) and transmits >= 3 else 0
 
@@ -135,14 +139,17 @@ def test_general_kernel_on_separable_geometry(name, bflib, oracle):
 
 @pytest.mark.parametrize("name", sorted(STAGED))
 def test_gather_kernel_where_the_staged_kernel_applies(name, bflib, oracle):
-    """path 2: the separable-delay gather kernel, never staged"""
+    """path 2: automatic, but never staged -- the separable-delay gather kernel for linear interpolation, the factored
+    kernel for cubic (as before the staged kernels existed)"""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     lib.beamformer_hip_set_das_path(2)
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-        assert last_das_path(bflib) == 1
+        bp = acq.bp
+        gather = bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp) or bp.acquisition_count < 3
+        assert last_das_path(bflib) == (1 if gather else 3)
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--transmits", default="4,8,12,16,24,32,48,75,128")
 ap.add_argument("--planes", type=int, default=16)
 ap.add_argument("--json", default="")
+ap.add_argument("--cubic", action="store_true", help="cubic interpolation of IQ samples: das_staged_cubic.hip against the factored kernel (what path 2 runs for cubic)")
 ap.add_argument("--real", action="store_true", help="real samples (no Demodulate): das_staged_real.hip against the gather kernel")
 args = ap.parse_args()
 
@@ -29,14 +30,15 @@ for A in (int(v) for v in args.transmits.split(",")):
     path = S / 25e6 * configs.SPEED_OF_SOUND
     z0, z1 = 0.12 * path, 0.30 * path
     acq = configs.rca(f"sweep{A}", Cn, A, S, (512, 512, 512), (-half, -half, z0), (half, half, z1), seed=4, cw=True, pitch=0.15e-3,
-                      orientation=0x12, f_number=0.5, angles=np.linspace(-18.5, 18.5, A), demodulate=not args.real)
+                      orientation=0x12, f_number=0.5, angles=np.linspace(-18.5, 18.5, A), demodulate=not args.real,
+                      interp=P.InterpolationMode.Cubic if args.cubic else P.InterpolationMode.Linear)
     for s, fp in enumerate(acq.filters):
         assert L.beamformer_create_filter(C.byref(fp), s, 0)
     assert L.beamformer_push_simple_parameters(C.byref(acq.bp))
     assert L.beamformer_hip_set_output_shard(0, 256 - args.planes // 2, args.planes), lib.last_error()
     rf = np.ascontiguousarray(acq.rf)
     dev = torch.from_numpy(rf.view(np.uint8).reshape(-1)).cuda()
-    row = {"transmits": A, "planes": args.planes, "samples": "real" if args.real else "complex"}
+    row = {"transmits": A, "planes": args.planes, "samples": "real" if args.real else "complex", "interpolation": "cubic" if args.cubic else "linear"}
     for name, mode in (("gather", 2), ("staged", 3)):
         L.beamformer_hip_set_das_path(mode)
         t = P.HipFrameTimings()
