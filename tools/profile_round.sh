@@ -32,6 +32,8 @@ timeout -k 10 300 python bench.py --config 5 --frame-graph --steps 5 --warmup 2 
 timeout -k 10 300 python bench.py --config 1 --frame-graph --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg1_graph.json 2> $OUT/bench_cfg1_graph.err
 timeout -k 10 300 python bench.py --das-path 2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4_gather.json 2> $OUT/bench_cfg4_gather.err
 PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --json $OUT/profiles/r02_staged_threshold.json > $OUT/staged_threshold.log 2>&1 || echo "staged threshold sweep failed"
+PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --real --json $OUT/profiles/r02_staged_threshold_real.json > $OUT/staged_threshold_real.log 2>&1 || echo "staged threshold sweep (real) failed"
+PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --cubic --json $OUT/profiles/r02_staged_threshold_cubic.json > $OUT/staged_threshold_cubic.log 2>&1 || echo "staged threshold sweep (cubic) failed"
 PYTHONPATH=$ROOT timeout -k 10 300 python tools/pull_rate.py --json $OUT/profiles/r02_pull_rate.json > $OUT/pull_rate.log 2>&1 || echo "pull rate failed"
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
 python3 - <<'PY'
