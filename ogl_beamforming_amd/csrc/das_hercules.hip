@@ -124,7 +124,13 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
 
 /* Grid: q.tiles[0] * q.tiles[1] * q.tiles[2] blocks of 256 threads; a block is 4 waves = 4 output rows
  * (y) x 64 voxels along x of one z plane. */
-template <int INTERP, bool CPLX, bool CW>
+/* PL ("phase local", IQ only): the demodulation phase of a pair is sin / cos of turns = turns_per_sample x index, which the
+ * hardware takes in revolutions within +-256.  Absolute indices reach thousands, so the phase has to be reduced: by a v_fract per
+ * pair (PL = false), or -- when the host knows the indices of one inner loop stay within ~400 turns of each other
+ * (BfHerculesArgs::phase_local) -- by subtracting ONE integer per lane and outer element inside the fma that forms the turns:
+ * turns' = fma(index, turns_per_sample, -B), B = round(turns at the middle of the lane's index range).  One instruction less per
+ * pair, and the product is rounded at |turns'| <= a few hundred instead of at the absolute phase. */
+template <int INTERP, bool CPLX, bool CW, bool PL>
 __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
 {
 	constexpr uint32_t ES = CPLX ? 8 : 4;
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		const f32x2 od2p = splat(od2), z2p = splat(z2), T0p = splat(T0), kp = splat(fs_over_c),
 		            wsp = splat(w_scale), tpsp = splat(turns_per_sample),
 		            oz2p = splat(od2 + z2), wodp = splat(w_scale * od2);
+		[[maybe_unused]] const f32x2 btp = splat(PL ? __builtin_rintf(turns_per_sample * 0.5f * (i_lo + i_hi)) : 0.f);
 
 		/* B = 1 or BF_HERC_BATCH elements starting at inner element n; d2in = their table entries */
 		auto group = [&](auto checked_c, auto count_c, int n, const float *d2in, float first_weight) {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				}
 				dist[k]  = f32x2{hw_sqrt(dd.x), hw_sqrt(dd.y)};
 				index[k] = dist[k] * kp + T0p;
-				if constexpr (CPLX) turns[k] = index[k] * tpsp;
+				if constexpr (CPLX) { if constexpr (PL) turns[k] = index[k] * tpsp - btp; else turns[k] = index[k] * tpsp; }
 			}
 			/* (floor / fraction of two indices by packed adds -- index + 2^23 - 1/2 leaves floor(index) in the low
 			 * mantissa bits -- measured the same as v_cvt_flr + v_fract per index, 179.1 against 178.7 ms on 32 planes of
@@ -281,7 +288,8 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					sv = tap_finish<INTERP, CPLX>(tap[k], d[k]);
 				}
 				if constexpr (CPLX) {
-					float tr = hw_fract((k & 1) ? turns[k >> 1].y : turns[k >> 1].x);
+					float tr = (k & 1) ? turns[k >> 1].y : turns[k >> 1].x;
+					if constexpr (!PL) tr = hw_fract(tr);
 					f32x2 cs = f32x2{hw_cos_turns(tr), hw_sin_turns(tr)} * ap[k];
 					acc1 += sv.x * cs;
 					acc2 += sv.y * cs;
@@ -340,21 +348,24 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	reinterpret_cast<VT *>(p.out)[out_index] = coherent;
 }
 
-template <int INTERP, bool CPLX, bool CW>
+template <int INTERP, bool CPLX, bool CW, bool PL>
 static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
 {
 	hipLaunchKernelGGL(hercules_table_kernel, dim3(a->size[1]), dim3(256), 0, s, *a, *q);
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
-	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW>), dim3(grid), dim3(256), 0, s, *a, *q);
+	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL>), dim3(grid), dim3(256), 0, s, *a, *q);
 	return hipGetLastError();
 }
 
 template <int INTERP>
 static hipError_t launch_herc_kind(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
 {
-	if (a->complex_data) return a->coherency_weighting ? launch_herc<INTERP, true,  true>(a, q, s) : launch_herc<INTERP, true,  false>(a, q, s);
-	else                 return a->coherency_weighting ? launch_herc<INTERP, false, true>(a, q, s) : launch_herc<INTERP, false, false>(a, q, s);
+	if (a->complex_data) {
+		if (q->phase_local) return a->coherency_weighting ? launch_herc<INTERP, true, true, true>(a, q, s) : launch_herc<INTERP, true, false, true>(a, q, s);
+		return a->coherency_weighting ? launch_herc<INTERP, true, true, false>(a, q, s) : launch_herc<INTERP, true, false, false>(a, q, s);
+	}
+	return a->coherency_weighting ? launch_herc<INTERP, false, true, false>(a, q, s) : launch_herc<INTERP, false, false, false>(a, q, s);
 }
 
 extern "C" hipError_t bf_launch_das_hercules(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)

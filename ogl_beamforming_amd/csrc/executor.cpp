@@ -579,6 +579,13 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 		}
 		q.unit_scale2 = cached_s2; q.samples_per_unit = cached_k;
 	}
+	{
+		/* distances to two elements of the inner axis differ by at most their separation: at most 255 pitches (dense or
+		 * sparse element indices alike), i.e. this many turns of demodulation phase inside one inner loop */
+		const float span_turns = std::fabs(a.turns_per_sample) * 255.0f * std::fabs(a.pitch[inner]) * a.sampling_frequency * a.inv_speed_of_sound;
+		q.phase_local = a.complex_data && span_turns < 400.0f &&       /* (false for a NaN) */
+		                !std::getenv("BEAMFORMER_HIP_HERCULES_FRACT");  /* measurement aid: v_fract per pair */
+	}
 	return true;
 }
 
