@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				if constexpr (INTERP == BF_INTERP_LINEAR) {
 					frac[k] = hw_fract(idx);
 					uint32_t ki = (uint32_t)cvt_floor_i32(idx);
-					off[k] = row + ki * ES;
+					off[k] = CHECK ? row + ki * ES : ki * ES;
 					if constexpr (CHECK) {
 						bool ok = (ki < ulast) && (e < apodization_test);
 						off[k] = ok ? off[k] : q.zero_offset;
@@ -277,7 +277,16 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			}
 			TapData<INTERP, CPLX> d[B];
 			#pragma unroll
-			for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, off[k]);
+			for (int k = 0; k < B; k++) {
+				if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
+					/* the row (wave uniform) rides in the load's scalar base and the lane offset is one full-rate shift: a
+					 * three-operand v_lshl_add_u32 is a half-rate instruction (tools/microbench.hip) */
+					const char *rowp = rf + (row0 + (uint32_t)(n + k) * inner_stride);
+					d[k] = tap_load<INTERP, CPLX>(rowp, off[k]);
+				} else {
+					d[k] = tap_load<INTERP, CPLX>(rf, off[k]);
+				}
+			}
 			#pragma unroll
 			for (int k = 0; k < B; k++) {
 				VT sv;
