@@ -191,6 +191,7 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
  *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
  *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernel's range-checked loop for every wave
  *   BEAMFORMER_HIP_HERCULES_FRACT    the HERCULES kernel reduces the demodulation phase per pair (v_fract) as before round 2's last pass
+ *   BEAMFORMER_HIP_HERCULES_NOPAIRS  the HERCULES kernel gathers from the DAS input itself, not from its {sample, difference} copy
  *   BEAMFORMER_HIP_DEBUG             one line per staged-kernel plan on stderr */
 
 /* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----

@@ -95,6 +95,8 @@ typedef struct {
 	 * would be a relative bias common to every tap -- 2e-8, i.e. up to 1e-4 rad of demodulation phase on a
 	 * coherent peak -- and a per-pair division costs 9 % of the kernel. */
 	float    unit_scale2, samples_per_unit;
+	void    *pairs;           /* IQ + linear interpolation: scratch for the {sample, difference to the next} copy of the DAS input (16 bytes per
+	                             sample + 32 zero bytes), or null: the kernel then reads BfDasArgs.rf as every other kernel does */
 	uint32_t phase_local;     /* IQ: the indices of one inner loop stay within ~400 turns of demodulation phase of each other, so the
 	                             kernel subtracts one integer per lane and outer element instead of taking v_fract per pair */
 } BfHerculesArgs;

@@ -90,6 +90,22 @@ __device__ __forceinline__ void voxel_to_xdc(const BfDasArgs &p, uint32_t x, uin
 
 } /* namespace */
 
+/* pairs[i] = {rf[i], rf[i + 1] - rf[i]} for every complex sample of every row (the last sample of a row gets a zero
+ * difference: it is never a pair's first tap); 32 zero bytes behind the last row for the range-checked loop */
+__global__ __launch_bounds__(256) void hercules_pair_kernel(const f32x2 *__restrict__ rf, f32x4 *__restrict__ pairs, uint32_t total, uint32_t samples)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= total + 2u) return;
+	f32x4 out = {0.f, 0.f, 0.f, 0.f};
+	if (i < total) {
+		const f32x2 s0 = rf[i];
+		f32x2 ds = {0.f, 0.f};
+		if ((i + 1u) % samples != 0u) ds = rf[i + 1u] - s0;
+		out = f32x4{s0.x, s0.y, ds.x, ds.y};
+	}
+	pairs[i] = out;
+}
+
 /* D2[y * pitch + n] = (uniform lateral coordinate of output row y - position of inner element n)^2,
  * n < inner_count; entries up to the row pitch repeat the last element (never used for sums);
  * extremes[y] = {min, max} of the row.  One block per output row. */
@@ -130,10 +146,15 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
  * (BfHerculesArgs::phase_local) -- by subtracting ONE integer per lane and outer element inside the fma that forms the turns:
  * turns' = fma(index, turns_per_sample, -B), B = round(turns at the middle of the lane's index range).  One instruction less per
  * pair, and the product is rounded at |turns'| <= a few hundred instead of at the absolute phase. */
-template <int INTERP, bool CPLX, bool CW, bool PL>
+/* PD ("paired data", linear interpolation of IQ samples): the kernel reads q.pairs, a copy of the DAS input in which every
+ * sample carries the difference to its successor -- {s_k, s_(k+1) - s_k}, 16 bytes, written by hercules_pair_kernel in ~0.2 ms
+ * per frame -- so the two taps of a pair are one 16-byte ALIGNED gather and the interpolation one packed fma (the difference the
+ * loop used to form per pair is formed once per sample; the arithmetic and its rounding are the same). */
+template <int INTERP, bool CPLX, bool CW, bool PL, bool PD>
 __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
 {
-	constexpr uint32_t ES = CPLX ? 8 : 4;
+	static_assert(!PD || (CPLX && INTERP == BF_INTERP_LINEAR), "paired data: linear interpolation of complex samples");
+	constexpr uint32_t ES = PD ? 16 : CPLX ? 8 : 4;
 	using VT = sample_t<CPLX>;
 
 	/* blockIdx -> tile with each XCD walking a contiguous run of tiles (das.hip) */
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	const float *__restrict__ row_d2 = q.table + (size_t)y * q.table_pitch;
 	const float d2_min = q.extremes[2 * y], d2_max = q.extremes[2 * y + 1];
 
-	const char *rf = (const char *)p.rf;
+	const char *rf = PD ? (const char *)q.pairs : (const char *)p.rf;
 	const uint32_t ulast = (uint32_t)(S - 1);
 	const int   n_inner = (int)q.inner_count, n_outer = (int)q.outer_count;
 	/* byte strides of the RF rows along the two loops: rf[c][t] rows of S samples */
@@ -291,7 +312,8 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			for (int k = 0; k < B; k++) {
 				VT sv;
 				if constexpr (INTERP == BF_INTERP_LINEAR) {
-					if constexpr (CPLX) { f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * (s1 - s0); }
+					if constexpr (PD)        { f32x2 s0 = {d[k].a.x, d[k].a.y}, ds = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * ds; }
+					else if constexpr (CPLX) { f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * (s1 - s0); }
 					else                { sv = d[k].a.x + frac[k] * (d[k].a.y - d[k].a.x); }
 				} else {
 					sv = tap_finish<INTERP, CPLX>(tap[k], d[k]);
@@ -357,24 +379,35 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	reinterpret_cast<VT *>(p.out)[out_index] = coherent;
 }
 
-template <int INTERP, bool CPLX, bool CW, bool PL>
+template <int INTERP, bool CPLX, bool CW, bool PL, bool PD>
 static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
 {
 	hipLaunchKernelGGL(hercules_table_kernel, dim3(a->size[1]), dim3(256), 0, s, *a, *q);
+	if constexpr (PD) {
+		const uint32_t total = (uint32_t)a->channel_count * (uint32_t)a->acquisition_count * (uint32_t)a->sample_count;
+		hipLaunchKernelGGL(hercules_pair_kernel, dim3((total + 2u + 255u) / 256u), dim3(256), 0, s,
+		                   (const f32x2 *)a->rf, (f32x4 *)q->pairs, total, (uint32_t)a->sample_count);
+	}
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
-	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL>), dim3(grid), dim3(256), 0, s, *a, *q);
+	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD>), dim3(grid), dim3(256), 0, s, *a, *q);
 	return hipGetLastError();
+}
+
+template <int INTERP, bool CW>
+static hipError_t launch_herc_iq(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
+{
+	if constexpr (INTERP == BF_INTERP_LINEAR) {
+		if (q->pairs) return q->phase_local ? launch_herc<INTERP, true, CW, true, true>(a, q, s) : launch_herc<INTERP, true, CW, false, true>(a, q, s);
+	}
+	return q->phase_local ? launch_herc<INTERP, true, CW, true, false>(a, q, s) : launch_herc<INTERP, true, CW, false, false>(a, q, s);
 }
 
 template <int INTERP>
 static hipError_t launch_herc_kind(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
 {
-	if (a->complex_data) {
-		if (q->phase_local) return a->coherency_weighting ? launch_herc<INTERP, true, true, true>(a, q, s) : launch_herc<INTERP, true, false, true>(a, q, s);
-		return a->coherency_weighting ? launch_herc<INTERP, true, true, false>(a, q, s) : launch_herc<INTERP, true, false, false>(a, q, s);
-	}
-	return a->coherency_weighting ? launch_herc<INTERP, false, true, false>(a, q, s) : launch_herc<INTERP, false, false, false>(a, q, s);
+	if (a->complex_data) return a->coherency_weighting ? launch_herc_iq<INTERP, true>(a, q, s) : launch_herc_iq<INTERP, false>(a, q, s);
+	return a->coherency_weighting ? launch_herc<INTERP, false, true, false, false>(a, q, s) : launch_herc<INTERP, false, false, false, false>(a, q, s);
 }
 
 extern "C" hipError_t bf_launch_das_hercules(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)

@@ -164,7 +164,7 @@ static void release_one_device(Device &d)
 	for (auto &b : d.rf) b.release();
 	for (auto &b : d.scratch) b.release();
 	d.ring.release(); d.pair_counter.release(); d.minmax_scratch.release(); d.sum_scratch.release();
-	d.hercules_table.release();
+	d.hercules_table.release(); d.hercules_pairs.release();
 	for (auto &g : d.frame_exec) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
 	for (auto &g : d.graph_generation) g = 0;
 	for (auto &t : d.timing) {
@@ -896,6 +896,14 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					hq.zero_offset = (uint32_t)used;            /* as for the gather kernel above */
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
+					/* linear interpolation of IQ samples reads a {sample, difference} copy of the input (16 bytes per sample, 32-bit byte
+					 * offsets: under 4 GiB), built by the launcher; BEAMFORMER_HIP_HERCULES_NOPAIRS: measurement aid */
+					hq.pairs = nullptr;
+					if (plan.iq_pipeline && a.interpolation == 1 && used * 2 + 64 < (1ull << 32) && !std::getenv("BEAMFORMER_HIP_HERCULES_NOPAIRS") &&
+					    d.hercules_pairs.ensure(used * 2 + 64)) {
+						hq.pairs = d.hercules_pairs.ptr;
+						hq.zero_offset = (uint32_t)(used * 2);
+					}
 					hq.table    = (float *)d.hercules_table.ptr;
 					hq.extremes = hq.table + (size_t)hq.table_pitch * a.size[1];
 					ok &= HIP_OK(bf_launch_das_hercules(&a, &hq, s));
