@@ -106,6 +106,25 @@ __global__ __launch_bounds__(256) void hercules_pair_kernel(const f32x2 *__restr
 	pairs[i] = out;
 }
 
+/* poly[2 i], poly[2 i + 1] = {a0, a1}, {a2, a3} of the Catmull-Rom segment between samples i and i + 1 of its row
+ * (das.glsl:67-97); segments that are never valid (the first and the last two of a row: index < 1 or >= S - 2) are zero, and
+ * so are the 32 bytes behind the last row, the checked loop's target for invalid pairs */
+__global__ __launch_bounds__(256) void hercules_cubic_kernel(const f32x2 *__restrict__ rf, f32x4 *__restrict__ poly, uint32_t total, uint32_t samples)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i > total) return;
+	f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+	const uint32_t k = i % samples;
+	if (i < total && k >= 1u && k + 2u < samples) {
+		const f32x2 P0 = rf[i - 1u], P1 = rf[i], P2 = rf[i + 1u], P3 = rf[i + 2u];
+		const f32x2 T1 = 0.5f * (P2 - P0), T2 = 0.5f * (P3 - P1);
+		const f32x2 a2 = 3.f * (P2 - P1) - 2.f * T1 - T2, a3 = 2.f * (P1 - P2) + T1 + T2;
+		lo = f32x4{P1.x, P1.y, T1.x, T1.y};
+		hi = f32x4{a2.x, a2.y, a3.x, a3.y};
+	}
+	poly[2u * i] = lo; poly[2u * i + 1u] = hi;
+}
+
 /* D2[y * pitch + n] = (uniform lateral coordinate of output row y - position of inner element n)^2,
  * n < inner_count; entries up to the row pitch repeat the last element (never used for sums);
  * extremes[y] = {min, max} of the row.  One block per output row. */
@@ -149,12 +168,17 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
 /* PD ("paired data", linear interpolation of IQ samples): the kernel reads q.pairs, a copy of the DAS input in which every
  * sample carries the difference to its successor -- {s_k, s_(k+1) - s_k}, 16 bytes, written by hercules_pair_kernel in ~0.2 ms
  * per frame -- so the two taps of a pair are one 16-byte ALIGNED gather and the interpolation one packed fma (the difference the
- * loop used to form per pair is formed once per sample; the arithmetic and its rounding are the same). */
+ * loop used to form per pair is formed once per sample; the arithmetic and its rounding are the same).  With cubic
+ * interpolation (what the reference's throughput harness runs, tests/throughput.c:451) the copy holds, per sample k, the four
+ * complex coefficients of the Catmull-Rom segment [k, k + 1] as a polynomial in the fraction (das.glsl:67-97: a0 = P1,
+ * a1 = T1, a2 = 3 (P2 - P1) - 2 T1 - T2, a3 = 2 (P1 - P2) + T1 + T2) -- 32 bytes, two aligned gathers -- and the Hermite
+ * weights, the tangents and the four-term sum of every pair become a three-step Horner chain of packed fmas. */
 template <int INTERP, bool CPLX, bool CW, bool PL, bool PD>
 __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
 {
-	static_assert(!PD || (CPLX && INTERP == BF_INTERP_LINEAR), "paired data: linear interpolation of complex samples");
-	constexpr uint32_t ES = PD ? 16 : CPLX ? 8 : 4;
+	static_assert(!PD || (CPLX && INTERP != BF_INTERP_NEAREST), "prepared data: linear or cubic interpolation of complex samples");
+	constexpr bool POLY = PD && INTERP == BF_INTERP_CUBIC;       /* q.pairs holds the cubic segment polynomials (hercules_cubic_kernel) */
+	constexpr uint32_t ES = POLY ? 32 : PD ? 16 : CPLX ? 8 : 4;
 	using VT = sample_t<CPLX>;
 
 	/* blockIdx -> tile with each XCD walking a contiguous run of tiles (das.hip) */
@@ -281,12 +305,13 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				ap[k]     = (k & 1) ? apod[k >> 1].y : apod[k >> 1].x;
 				if (k == 0) ap[k] *= first_weight;
 				uint32_t row = row0 + (uint32_t)(n + k) * inner_stride;
-				if constexpr (INTERP == BF_INTERP_LINEAR) {
+				if constexpr (INTERP == BF_INTERP_LINEAR || POLY) {
 					frac[k] = hw_fract(idx);
 					uint32_t ki = (uint32_t)cvt_floor_i32(idx);
 					off[k] = CHECK ? row + ki * ES : ki * ES;
 					if constexpr (CHECK) {
-						bool ok = (ki < ulast) && (e < apodization_test);
+						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124) */
+						bool ok = (POLY ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test);
 						off[k] = ok ? off[k] : q.zero_offset;
 						ap[k]  = ok ? ap[k] : 0.f;
 					}
@@ -299,7 +324,11 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			TapData<INTERP, CPLX> d[B];
 			#pragma unroll
 			for (int k = 0; k < B; k++) {
-				if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
+				if constexpr (POLY) {
+					const char *rowp = CHECK ? rf : rf + (row0 + (uint32_t)(n + k) * inner_stride);
+					d[k].a = gather<f32x4>(rowp, off[k]);
+					d[k].b = gather<f32x4>(rowp, off[k] + 16u);
+				} else if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
 					/* the row (wave uniform) rides in the load's scalar base and the lane offset is one full-rate shift: a
 					 * three-operand v_lshl_add_u32 is a half-rate instruction (tools/microbench.hip) */
 					const char *rowp = rf + (row0 + (uint32_t)(n + k) * inner_stride);
@@ -311,7 +340,12 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			#pragma unroll
 			for (int k = 0; k < B; k++) {
 				VT sv;
-				if constexpr (INTERP == BF_INTERP_LINEAR) {
+				if constexpr (POLY) {
+					const float t = frac[k];
+					sv = f32x2{d[k].b.z, d[k].b.w} * t + f32x2{d[k].b.x, d[k].b.y};
+					sv = sv * t + f32x2{d[k].a.z, d[k].a.w};
+					sv = sv * t + f32x2{d[k].a.x, d[k].a.y};
+				} else if constexpr (INTERP == BF_INTERP_LINEAR) {
 					if constexpr (PD)        { f32x2 s0 = {d[k].a.x, d[k].a.y}, ds = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * ds; }
 					else if constexpr (CPLX) { f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * (s1 - s0); }
 					else                { sv = d[k].a.x + frac[k] * (d[k].a.y - d[k].a.x); }
@@ -385,8 +419,12 @@ static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipSt
 	hipLaunchKernelGGL(hercules_table_kernel, dim3(a->size[1]), dim3(256), 0, s, *a, *q);
 	if constexpr (PD) {
 		const uint32_t total = (uint32_t)a->channel_count * (uint32_t)a->acquisition_count * (uint32_t)a->sample_count;
-		hipLaunchKernelGGL(hercules_pair_kernel, dim3((total + 2u + 255u) / 256u), dim3(256), 0, s,
-		                   (const f32x2 *)a->rf, (f32x4 *)q->pairs, total, (uint32_t)a->sample_count);
+		if constexpr (INTERP == BF_INTERP_CUBIC)
+			hipLaunchKernelGGL(hercules_cubic_kernel, dim3((total + 1u + 255u) / 256u), dim3(256), 0, s,
+			                   (const f32x2 *)a->rf, (f32x4 *)q->pairs, total, (uint32_t)a->sample_count);
+		else
+			hipLaunchKernelGGL(hercules_pair_kernel, dim3((total + 2u + 255u) / 256u), dim3(256), 0, s,
+			                   (const f32x2 *)a->rf, (f32x4 *)q->pairs, total, (uint32_t)a->sample_count);
 	}
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
@@ -397,7 +435,7 @@ static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipSt
 template <int INTERP, bool CW>
 static hipError_t launch_herc_iq(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s)
 {
-	if constexpr (INTERP == BF_INTERP_LINEAR) {
+	if constexpr (INTERP != BF_INTERP_NEAREST) {
 		if (q->pairs) return q->phase_local ? launch_herc<INTERP, true, CW, true, true>(a, q, s) : launch_herc<INTERP, true, CW, false, true>(a, q, s);
 	}
 	return q->phase_local ? launch_herc<INTERP, true, CW, true, false>(a, q, s) : launch_herc<INTERP, true, CW, false, false>(a, q, s);

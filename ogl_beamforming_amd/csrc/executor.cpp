@@ -899,10 +899,11 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					/* linear interpolation of IQ samples reads a {sample, difference} copy of the input (16 bytes per sample, 32-bit byte
 					 * offsets: under 4 GiB), built by the launcher; BEAMFORMER_HIP_HERCULES_NOPAIRS: measurement aid */
 					hq.pairs = nullptr;
-					if (plan.iq_pipeline && a.interpolation == 1 && used * 2 + 64 < (1ull << 32) && !std::getenv("BEAMFORMER_HIP_HERCULES_NOPAIRS") &&
-					    d.hercules_pairs.ensure(used * 2 + 64)) {
+					const uint64_t prepared = used * (a.interpolation == 2 ? 4u : 2u);      /* cubic: four coefficients per sample, 32 bytes */
+					if (plan.iq_pipeline && (a.interpolation == 1 || a.interpolation == 2) && prepared + 64 < (1ull << 32) &&
+					    !std::getenv("BEAMFORMER_HIP_HERCULES_NOPAIRS") && d.hercules_pairs.ensure(prepared + 64)) {
 						hq.pairs = d.hercules_pairs.ptr;
-						hq.zero_offset = (uint32_t)(used * 2);
+						hq.zero_offset = (uint32_t)prepared;
 					}
 					hq.table    = (float *)d.hercules_table.ptr;
 					hq.extremes = hq.table + (size_t)hq.table_pitch * a.size[1];

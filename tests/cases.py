@@ -121,6 +121,11 @@ def _cases():
     c["uhercules_wide_sparse_cubic"] = lambda: cfg.hercules(
         "uhercules_wide_sparse_cubic", 16, 8, 512, (48, 4, 2), LO3, HI3, seed=53, kind=K.UHERCULES,
         sparse=[0, 3, 5, 9, 12, 14, 15], decode=0, data_kind=D.Float32Complex, cw=True, f_number=0.9, interp=I.Cubic)
+    # the reference harness's own setting: the canonical pipeline with cubic interpolation (the aligned-grid kernel then gathers the
+    # per-sample segment polynomials its pre-pass wrote)
+    c["hercules_wide_cubic_cw"] = lambda: cfg.hercules(
+        "hercules_wide_cubic_cw", 7, 16, 512, (64, 6, 3), LO3, HI3, seed=55, cw=True, f_number=0.7, interp=I.Cubic,
+        stages=(S.Demodulate, S.Decode, S.DAS))
     c["hercules_wide_nearest"] = lambda: cfg.hercules(
         "hercules_wide_nearest", 8, 7, 512, (40, 3, 3), LO3, HI3, seed=54, decode=0, interp=I.Nearest,
         data_kind=D.Float32Complex, f_number=0.6)
