@@ -44,7 +44,7 @@
  * arithmetic.  The host only launches this kernel when its bound on the delay spread of a tile fits
  * the window (plan_staged, executor.cpp).  No MFMA: gather-accumulate.  Measured (config 4, one
  * MI355X): 785-850 ms per 512^3 frame against 1116-1191 ms for the gather kernel; VALU 94 % busy,
- * 0.83-0.85 of the rate of its own VALU stream run without memory instructions.
+ * 0.83-0.86 of the rate of its own VALU stream run without memory instructions.
  */
 #include "das_common.h"
 
