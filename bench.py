@@ -411,7 +411,8 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
         to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
       * the LDS-staged kernel -- VALU issue: the inner loop's VALU stream (36 instructions per 4 (voxel, channel,
-        transmit) terms), measured as a stream with no memory instruction in it ("valu_stream", shipping form);
+        transmit) terms), measured as a stream with no memory instruction in it ("valu_stream", shipping form), and
+        next to it the same loop with its LDS reads ("inner_loop_with_lds": what the instruction mix allows);
     achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
     try:
@@ -431,6 +432,16 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_term_per_simd": per_term,
                 "source": "profiles/r02_microbench.json valu_stream (tools/microbench.hip term_probe); achieved measured in this run",
             }
+            # the same loop WITH its LDS reads (delays, phasors, taps at addresses formed as the kernel forms them) and
+            # nothing else of the kernel -- no staging, no barriers: what the instruction mix of the inner loop allows
+            loops = [v for v in micro["valu_stream"] if v["stream"].startswith("das_staged inner loop with its LDS reads: address by v_lshlrev_b16")]
+            if loops:
+                lp = min(loops, key=lambda v: v["cycles_per_term_per_simd_wall"])
+                lp_peak = cus * 4 * 64 * lp["clock_ghz"] * 1e9 / lp["cycles_per_term_per_simd_wall"]
+                out["inner_loop_with_lds"] = {
+                    "what": "tools/microbench.hip loop_probe: the inner loop's VALU stream and its LDS reads at config 4's shape, 8 waves per SIMD, no staging or barriers",
+                    "cycles_per_term_per_simd": lp["cycles_per_term_per_simd_wall"], "probe_clock_ghz": lp["clock_ghz"],
+                    "peak": lp_peak / 1e12, "frac": terms / das_s / lp_peak}
         else:
             inst = "global_load_dwordx4" if bytes_per_gather >= 16 else "global_load_dwordx2" if bytes_per_gather == 8 else "global_load_dword"
             rows = [g for g in micro["gather"] if g["inst"] == inst and g["level"] == "L1" and g["pattern"] == "das_like"]
@@ -463,6 +474,8 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             clock = entry["kernel_cycles_per_launch"] / das_s / 1e9
             out["sustained_clock_ghz_est"] = clock
             out["frac_at_sustained_clock"] = out["frac"] * out["probe_clock_ghz"] / clock
+            if "inner_loop_with_lds" in out:
+                out["inner_loop_with_lds"]["frac_at_sustained_clock"] = out["inner_loop_with_lds"]["frac"] * out["inner_loop_with_lds"]["probe_clock_ghz"] / clock
         out["valu_source"] = (f"profiles/r02_das_bound.json: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
                               f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash(kernel) else " (STALE: sources changed since)"))
         if kernel != "das_rca_staged_kernel" and entry["valu_busy_frac"] > out.get("frac", 0):

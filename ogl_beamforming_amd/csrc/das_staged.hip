@@ -28,8 +28,9 @@
  *     interpolation ONE packed fma of the position itself, c_j + p d_j -- no fraction is formed;
  *   * no v_fract, no v_cvt: adding M = 2^23 + 2 + a*W rounds p to the nearest integer and leaves the
  *     window ELEMENT INDEX in the low mantissa bits of y = p + M (a packed add over two terms); the
- *     tap's LDS address is (bits(y) & 0xFFFFFF) * 16, one v_mul_u32_u24, because the staging area
- *     starts two elements into an LDS that holds nothing static;
+ *     tap's LDS address is (bits(y) & 0xFFF) * 16, one v_lshlrev_b16 by 4 (full rate; a 16-bit op leaves the
+ *     upper half of its result zero on gfx950, which drops M's exponent bits), because the staging area
+ *     starts two elements into an LDS that holds nothing static and A4 * W <= 4096 elements;
  *   * transmits in pairs: one ds_read2_b64 serves four terms' delays, one ds_read_b128 two terms'
  *     phasors; the transmit table is padded to a multiple of 4 with zero phasors over a zero window
  *     row, so the last batch needs no select;
@@ -333,9 +334,12 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3);
 				/* Position -> tap without v_fract / v_cvt / a fraction: adding M = 2^23 + 2 + (first window element of the batch)
 				 * rounds the position to the nearest integer and leaves the ELEMENT INDEX 2 + a*W + round(p) in the low mantissa
-				 * bits of y = p + M (packed: two terms per instruction); the tap's LDS byte address is (bits(y) & 0xFFFFFF) * 16 --
-				 * one 24-bit multiply, no add: M's own bit pattern (0x4B000002 + a*W) contributes exactly 2 + a*W below bit 24,
-				 * and the staging area starts two elements into an LDS that holds nothing static.  M is a scalar, stepped by 4*W
+				 * bits of y = p + M (packed: two terms per instruction); the tap's LDS byte address is (bits(y) & 0xFFF) * 16 --
+				 * one 16-bit shift (full rate where 32-bit shifts and 24-bit multiplies are half rate; the upper half of a 16-bit
+				 * result is zero on gfx950, so M's exponent bits drop out), no add: M's own bit pattern (0x4B000002 + a*W) contributes
+				 * exactly 2 + a*W to the mantissa, a batch's base element 2 + a*W + round(p) is below 4096 (plan_staged: A4 * W <= 4096;
+				 * rows 1-3 of the batch ride in the read's immediate offset), and the staging area starts two elements into an LDS
+				 * that holds nothing static.  M is a scalar, stepped by 4*W
 				 * per batch as an integer (the mantissa of a float in [2^23, 2^24) counts integers); term k's row k*W is the read's
 				 * immediate offset.  The element is a line in window coordinates, so the interpolation uses p itself.
 				 * Why 2^23 + 2: (1) p = -1/2 (the lane with the smallest delays of the tile) must round inside [2^23, 2^24) --
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				 * (2) that tie must not round DOWN to the element in front of the row: 2 + a*W is even, so round-to-even takes it
 				 * up to element 0.  At every other tie both neighbouring lines give the same value.
 				 * (Tried and measured no faster: y = fma(p, 2^-149, B) into a denormal whose bit pattern is the index, then a
-				 * full-rate shift instead of the half-rate 24-bit multiply -- 0.721 of the gather kernel's time against 0.710.) */
+				 * 32-bit shift -- itself half rate, as it turned out -- instead of the 24-bit multiply: 0.721 of the gather kernel's
+				 * time against 0.710.  The multiply before the 16-bit shift: 0.701 against 0.700.) */
 				uint32_t m_bits = 0x4B000002u;
 				const f32x2 rr = {r_rel, r_rel};
 				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
 						const uint32_t yb = __builtin_bit_cast(uint32_t, ys[k]);
-						asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at[k]) : "v"(yb));   /* (hipcc turns the builtin into shift + and) */
+						asm("v_lshlrev_b16 %0, 4, %1" : "=v"(at[k]) : "v"(yb));     /* upper half of the result: zero */
 						if constexpr (CHECK) {
 							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfloor[cl] + tfl[a + k]);      /* yb - m_bits = round(p) */
 							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : (stage_elements + 2u) * 16u;

@@ -8,7 +8,7 @@
  * of the position itself), magic-number rounding for the tap address, transmit delays in pairs, the
  * per-lane range flag in the sign of the receive weight, buffer-load staging with the next channel's
  * windows in flight -- minus the phasor tables and the complex multiply-accumulate.  Per term the inner
- * loop is: half a packed add (position), half a packed add (rounding), one v_mul_u32_u24 (address), one
+ * loop is: half a packed add (position), half a packed add (rounding), one v_lshlrev_b16 (address), one
  * fma (interpolation), one add (sum), and with coherency weighting one add of |sample| (a free modifier).
  * The gather kernel (das_separable.hip) pays 16.3 clk per wave64 gather for the same term.
  */
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 					#pragma unroll
 					for (int k = 0; k < 4; k++) {
 						const uint32_t yb = __builtin_bit_cast(uint32_t, ys[k]);
-						asm("v_mul_u32_u24 %0, 8, %1" : "=v"(at[k]) : "v"(yb));
+						asm("v_lshlrev_b16 %0, 3, %1" : "=v"(at[k]) : "v"(yb));
 						if constexpr (CHECK) {
 							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfloor[cl] + tfl[a + k]);      /* yb - m_bits = round(p) */
 							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 8u : (stage_elements + 2u) * 8u;

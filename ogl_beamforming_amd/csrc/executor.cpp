@@ -482,7 +482,9 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 					ws = fw;
 				}
 			}
-			if (((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;  /* window elements a thread stages per channel: 4 (complex: registers), 8 (real) */
+			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
+			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
+			if (((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */

@@ -37,11 +37,12 @@ __device__ __forceinline__ uint64_t memrealtime() { return __builtin_amdgcn_s_me
 
 /* ------------------------------------------------------------------ VALU issue */
 enum { OP_FMA, OP_PK_FMA, OP_SQRT, OP_SIN, OP_RCP, OP_CVT_FLR, OP_FRACT, OP_MUL, OP_ADD, OP_LSHL_ADD, OP_PK_ADD, OP_PK_ADD_SGPR, OP_PK_ADD_NEG,
-       OP_PK_FMA_SEL, OP_MUL_U24, OP_COUNT };
+       OP_PK_FMA_SEL, OP_MUL_U24, OP_LSHL_B16, OP_PK_LSHL_B16, OP_LSHL_B32, OP_COUNT };
 static const char *op_name[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_sqrt_f32", "v_sin_f32", "v_rcp_f32",
                                         "v_cvt_flr_i32_f32", "v_fract_f32", "v_mul_f32", "v_add_f32", "v_lshl_add_u32", "v_pk_add_f32",
                                         "v_pk_add_f32 (scalar-pair operand, op_sel_hi:[1,0])", "v_pk_add_f32 (neg_lo neg_hi on one operand)",
-                                        "v_pk_fma_f32 (op_sel_hi:[0,1,1]: one half broadcast)", "v_mul_u32_u24"};
+                                        "v_pk_fma_f32 (op_sel_hi:[0,1,1]: one half broadcast)", "v_mul_u32_u24",
+                                        "v_lshlrev_b16", "v_pk_lshlrev_b16", "v_lshlrev_b32"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, int iters)
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 	f32x2 pb = {0.999f, 0.998f}, pc = {0.0001f, 0.0002f};
 	uint64_t spair = 0x3a83126f3a83126full;                  /* two small floats in a scalar register pair */
 	asm volatile("" : "+s"(spair));
+	uint32_t shifts = 0x000f0004u;                           /* v_pk_lshlrev_b16: low half << 4, high half << 15 */
+	asm volatile("" : "+v"(shifts));
 	__syncthreads();
 	uint64_t t0 = memtime(), r0 = memrealtime();
 	for (int i = 0; i < iters; i++) {
@@ -69,6 +72,9 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 				if constexpr (OP == OP_PK_ADD_NEG)  asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[k]) : "v"(pc));
 				if constexpr (OP == OP_PK_FMA_SEL)  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[k]) : "v"(pb), "v"(pc));
 				if constexpr (OP == OP_MUL_U24) asm volatile("v_mul_u32_u24 %0, 3, %0" : "+v"(a[k]));
+				if constexpr (OP == OP_LSHL_B16) asm volatile("v_lshlrev_b16 %0, 4, %0" : "+v"(a[k]));
+				if constexpr (OP == OP_PK_LSHL_B16) asm volatile("v_pk_lshlrev_b16 %0, %1, %0" : "+v"(a[k]) : "v"(shifts));
+				if constexpr (OP == OP_LSHL_B32) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[k]));
 				if constexpr (OP == OP_PK_FMA)  asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pb), "v"(pc));
 				if constexpr (OP == OP_SQRT)    asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
 				if constexpr (OP == OP_SIN)     asm volatile("v_sin_f32 %0, %0" : "+v"(a[k]));
@@ -86,6 +92,14 @@ __global__ __launch_bounds__(1024) void valu_probe(Stamp *stamps, float *sink, i
 		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 		stamps[wave] = Stamp{t1 - t0, r1 - r0};
 	}
+}
+
+__global__ void shift_semantics(uint32_t *out)
+{
+	uint32_t a = 0x4b000923u, b = 0x4b000923u, shifts = 0x000f0004u;
+	asm volatile("v_lshlrev_b16 %0, 4, %0" : "+v"(a));
+	asm volatile("v_pk_lshlrev_b16 %0, %1, %0" : "+v"(b) : "v"(shifts));
+	if (threadIdx.x == 0) { out[0] = a; out[1] = b; }
 }
 
 /* ------------------------------------------------------------------ the VALU stream of one DAS term
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(1024) void term_probe(Stamp *stamps, float *sink, i
 /* The stream das_staged.hip ships (round 2, final form): per batch of four terms 4 packed adds (window position,
  * round-by-magic-number), 4 v_mul_u32_u24 (tap address), 4 + 8 packed fmas (interpolation, rotate-accumulate),
  * 4 x (v_mul, v_fmac, v_sqrt) and 2 packed adds for |s|: 36 VALU instructions per 4 terms. */
-/* PARTS: bit 0 = position / rounding / address (4 packed adds + 4 v_mul_u32_u24 per 4 terms), bit 1 = interpolation and
+/* PARTS: bit 0 = position / rounding / address (4 packed adds + 4 v_lshlrev_b16 per 4 terms), bit 1 = interpolation and
  * rotate-accumulate (12 packed fmas), bit 2 = |s| (4 x v_mul, v_fmac, v_sqrt + 2 packed adds); 7 = the whole stream.  The
  * parts run alone tell which of them the whole costs more than. */
 template <int PARTS>
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(1024) void term_probe_packed(Stamp *stamps, float *
 			#pragma unroll
 			for (int k = 0; k < 4; k++) {
 				uint32_t at;
-				asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at) : "v"(__builtin_bit_cast(uint32_t, ys[k])));
+				asm("v_lshlrev_b16 %0, 4, %1" : "=v"(at) : "v"(__builtin_bit_cast(uint32_t, ys[k])));
 				asm volatile("" :: "v"(at));
 			}
 			if constexpr (!(PARTS & 2)) asm volatile("" :: "v"(g01), "v"(g23));
@@ -187,6 +201,111 @@ __global__ __launch_bounds__(1024) void term_probe_packed(Stamp *stamps, float *
 		if constexpr (PARTS & 4) { mag2 += f32x2{q[0], q[1]}; mag2 += f32x2{q[2], q[3]}; }
 		m_bits += 128;
 		if (m_bits > 0x4B000801u) m_bits = 0x4B000001u;
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (mag2.x + mag2.y + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag2.x;
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		stamps[wave] = Stamp{t1 - t0, r1 - r0};
+	}
+}
+
+/* ------------------------------------------------------------------ the whole inner loop of das_staged.hip: VALU stream AND its LDS reads
+ * Config 4's shape (76 padded transmits, 32-element windows, a 32 x 32 tile, 16 waves per block, two blocks per CU): per batch
+ * of 4 terms one ds_read2_b64 (delays), two ds_read_b128 (phasors) and four ds_read_b128 taps at addresses formed from the
+ * positions, as the kernel forms them -- everything but the per-channel staging and its barriers.
+ * MODE bit 0: address by v_lshlrev_b16 instead of v_mul_u32_u24; bit 1: no LDS reads at all (operands stay in registers);
+ * bit 2: taps by ds_read_b64 (half the returned bytes: how sensitive the loop is to LDS return traffic);
+ * bit 3: LDS reads and address arithmetic only (no interpolation / accumulate / |s|);
+ * bit 4: the delays of the NEXT batch are read a batch ahead (4 more registers); bit 5: the phasors too (8 more). */
+typedef __attribute__((address_space(3))) f32x2 mb_lds_f32x2;
+typedef __attribute__((address_space(3))) f32x4 mb_lds_f32x4;
+template <int MODE>
+__global__ __launch_bounds__(1024, 8) void loop_probe(Stamp *stamps, float *sink, int iters)
+{
+	extern __shared__ __attribute__((aligned(16))) f32x4 probe_lds[];
+	constexpr uint32_t A4 = 76, W = 32, V = 32;
+	f32x4 *stage = probe_lds + 2;
+	f32x4 *Tcs = stage + A4 * W + 1;
+	f32x2 *Tz = reinterpret_cast<f32x2 *>(Tcs + (A4 / 2) * V);
+	for (uint32_t i = threadIdx.x; i < A4 * W + 3; i += blockDim.x) probe_lds[i] = f32x4{0.5f + 0.001f * i, 0.25f, 0.125f, -0.5f};
+	for (uint32_t i = threadIdx.x; i < (A4 / 2) * V; i += blockDim.x) {
+		uint32_t v = i % V, a2 = i / V;
+		Tcs[i] = f32x4{0.6f, 0.8f, 0.8f, 0.6f};
+		Tz[i] = f32x2{1.f + 0.3f * v + 0.7f * (float)((2 * a2) % 5), 1.f + 0.3f * v + 0.7f * (float)((2 * a2 + 1) % 5)};
+	}
+	__syncthreads();
+	const uint32_t lane_v = threadIdx.x >> 5, lane_u = threadIdx.x & 31u;
+	const float r_rel = 0.5f * (float)lane_u;
+	const uint32_t tcs_base = (uint32_t)(uintptr_t)(mb_lds_f32x4 *)Tcs, tz_base = (uint32_t)(uintptr_t)(mb_lds_f32x2 *)Tz;
+	f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, mag2 = {0.f, 0.f};
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		uint32_t tcs_at = tcs_base + (lane_v << 4), tz_at = tz_base + (lane_v << 3);
+		uint32_t m_bits = 0x4B000002u;
+		const f32x2 rr = {r_rel, r_rel};
+		f32x4 cs01 = {0.6f, 0.8f, 0.8f, 0.6f}, cs23 = cs01, tap[4];
+		f32x2 tz01 = {1.5f, 2.5f}, tz23 = {3.5f, 4.5f};
+		for (int k = 0; k < 4; k++) tap[k] = f32x4{0.5f + k, 0.25f, 0.125f, -0.5f};
+		f32x2 ntz01 = tz01, ntz23 = tz23; f32x4 ncs01 = cs01, ncs23 = cs23;
+		if constexpr (MODE & 16) { ntz01 = *(mb_lds_f32x2 *)(uintptr_t)tz_at; ntz23 = *(mb_lds_f32x2 *)(uintptr_t)(tz_at + V * 8u); }
+		if constexpr (MODE & 32) { ncs01 = *(mb_lds_f32x4 *)(uintptr_t)tcs_at; ncs23 = *(mb_lds_f32x4 *)(uintptr_t)(tcs_at + V * 16u); }
+		for (uint32_t a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
+			const float M = __builtin_bit_cast(float, m_bits);
+			const f32x2 M2 = {M, M};
+			if constexpr (!(MODE & 2)) {
+				if constexpr (MODE & 32) {
+					cs01 = ncs01; cs23 = ncs23;              /* (the table is padded by a batch, as the kernel's is by the zero rows) */
+					ncs01 = *(mb_lds_f32x4 *)(uintptr_t)(tcs_at + 2u * V * 16u);
+					ncs23 = *(mb_lds_f32x4 *)(uintptr_t)(tcs_at + 3u * V * 16u);
+				} else {
+					cs01 = *(mb_lds_f32x4 *)(uintptr_t)tcs_at;
+					cs23 = *(mb_lds_f32x4 *)(uintptr_t)(tcs_at + V * 16u);
+				}
+				if constexpr (MODE & 16) {
+					tz01 = ntz01; tz23 = ntz23;
+					ntz01 = *(mb_lds_f32x2 *)(uintptr_t)(tz_at + 2u * V * 8u);
+					ntz23 = *(mb_lds_f32x2 *)(uintptr_t)(tz_at + 3u * V * 8u);
+				} else {
+					tz01 = *(mb_lds_f32x2 *)(uintptr_t)tz_at;
+					tz23 = *(mb_lds_f32x2 *)(uintptr_t)(tz_at + V * 8u);
+				}
+			} else {
+				asm volatile("" : "+v"(tz01), "+v"(tz23), "+v"(cs01), "+v"(cs23), "+v"(tap[0]), "+v"(tap[1]), "+v"(tap[2]), "+v"(tap[3]));
+			}
+			const f32x2 p01 = rr + tz01, p23 = rr + tz23;
+			const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
+			const float ys[4] = {y01.x, y01.y, y23.x, y23.y}, ps[4] = {p01.x, p01.y, p23.x, p23.y};
+			uint32_t at[4];
+			#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t yb = __builtin_bit_cast(uint32_t, ys[k]);
+				if constexpr (MODE & 1) asm("v_lshlrev_b16 %0, 4, %1" : "=v"(at[k]) : "v"(yb));
+				else                    asm("v_mul_u32_u24 %0, 16, %1" : "=v"(at[k]) : "v"(yb));
+				if constexpr (MODE & 2) asm volatile("" :: "v"(at[k]));
+			}
+			if constexpr (!(MODE & 2)) {
+				#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					if constexpr (MODE & 4) { f32x2 h = *(mb_lds_f32x2 *)(uintptr_t)(at[k] + (uint32_t)k * W * 16u); tap[k].x = h.x; tap[k].y = h.y; }
+					else tap[k] = *(mb_lds_f32x4 *)(uintptr_t)(at[k] + (uint32_t)k * W * 16u);
+				}
+			}
+			if constexpr (MODE & 8) {
+				asm volatile("" :: "v"(tap[0]), "v"(tap[1]), "v"(tap[2]), "v"(tap[3]), "v"(cs01), "v"(cs23));
+			} else {
+				const f32x2 cs[4] = {{cs01.x, cs01.y}, {cs01.z, cs01.w}, {cs23.x, cs23.y}, {cs23.z, cs23.w}};
+				float q[4];
+				#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					f32x2 sv = f32x2{tap[k].x, tap[k].y} + ps[k] * f32x2{tap[k].z, tap[k].w};
+					acc1 += sv.x * cs[k];
+					acc2 += sv.y * cs[k];
+					q[k] = __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+				}
+				mag2 += f32x2{q[0], q[1]}; mag2 += f32x2{q[2], q[3]};
+			}
+		}
 	}
 	uint64_t t1 = memtime(), r1 = memrealtime();
 	if (mag2.x + mag2.y + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag2.x;
@@ -404,6 +523,20 @@ template <int PARTS> static void term_packed_case(const char *what)
 	}
 }
 
+template <int MODE> static void loop_case(const char *what)
+{
+	const int iters = 1000;                            /* 76k terms per wave */
+	const uint32_t lds = 16u * (76u * 32u + 3u) + 16u * 38u * 32u + 8u * 38u * 32u + 64u + 2048u;   /* (+ a batch of table rows: the read-ahead variants) */
+	CHECK(hipFuncSetAttribute((const void *)loop_probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	int blocks = n_cu * 2, waves = blocks * 16;
+	Result r = run([&] { hipLaunchKernelGGL(loop_probe<MODE>, dim3(blocks), dim3(1024), lds, 0, d_stamps, d_sink, iters); }, waves);
+	double terms = 76.0 * iters;
+	double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+	emit(",\n  {\"stream\":\"%s\",\"waves_per_simd\":8,"
+	     "\"cycles_per_term_per_simd_wall\":%.3f,\"cycles_per_term_per_simd_stamps\":%.3f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
+	     what, wall_cycles / (terms * 8), r.cycles_per_wave / (terms * 8), r.clock_ghz, r.wall_ms);
+}
+
 static char *d_window;
 
 template <int WIDTH, int PAT> static void gather_case(const char *level, uint32_t window, bool per_block, bool &first)
@@ -480,15 +613,34 @@ int main(int argc, char **argv)
 	valu_case<OP_PK_ADD_NEG>(false);
 	valu_case<OP_PK_FMA_SEL>(false);
 	valu_case<OP_MUL_U24>(false);
+	valu_case<OP_LSHL_B16>(false);
+	valu_case<OP_PK_LSHL_B16>(false);
+	valu_case<OP_LSHL_B32>(false);
 	emit("],\n");
+	{   /* what the 16-bit shifts leave in the upper half of the destination (the staged kernels' tap address relies on it) */
+		uint32_t *d_bits, h_bits[2] = {0, 0};
+		CHECK(hipMalloc(&d_bits, 8));
+		hipLaunchKernelGGL(shift_semantics, dim3(1), dim3(64), 0, 0, d_bits);
+		CHECK(hipMemcpy(h_bits, d_bits, 8, hipMemcpyDeviceToHost));
+		emit(" \"shift_semantics\":{\"input\":\"0x4b000923\",\"v_lshlrev_b16 by 4\":\"0x%08x\",\"v_pk_lshlrev_b16 by {4, 15}\":\"0x%08x\"},\n", h_bits[0], h_bits[1]);
+		CHECK(hipFree(d_bits));
+	}
 	emit(" \"valu_stream\":[\n  ");
 	term_case();
-	term_packed_case<7>("das_staged term, shipping form: per 4 terms 4 x v_pk_add_f32 (position, magic-number rounding), 4 x v_mul_u32_u24, "
+	term_packed_case<7>("das_staged term, shipping form: per 4 terms 4 x v_pk_add_f32 (position, magic-number rounding), 4 x v_lshlrev_b16, "
 	                    "12 x v_pk_fma_f32, 4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32), 2 x v_pk_add_f32 = 36 VALU instructions");
-	term_packed_case<1>("part of the shipping form alone: position / rounding / address (4 x v_pk_add_f32 + 4 x v_mul_u32_u24 per 4 terms)");
+	term_packed_case<1>("part of the shipping form alone: position / rounding / address (4 x v_pk_add_f32 + 4 x v_lshlrev_b16 per 4 terms)");
 	term_packed_case<2>("part of the shipping form alone: interpolation + rotate-accumulate (12 x v_pk_fma_f32 per 4 terms)");
 	term_packed_case<4>("part of the shipping form alone: |s| (4 x (v_mul_f32, v_fmac_f32, v_sqrt_f32) + 2 x v_pk_add_f32 per 4 terms)");
 	term_packed_case<6>("parts of the shipping form: interpolation + rotate-accumulate + |s| (no position part)");
+	loop_case<0>("das_staged inner loop with its LDS reads (config 4's shape, no staging / barriers): address by v_mul_u32_u24");
+	loop_case<1>("das_staged inner loop with its LDS reads: address by v_lshlrev_b16");
+	loop_case<3>("das_staged inner loop, VALU only (operands stay in registers): address by v_lshlrev_b16");
+	loop_case<2>("das_staged inner loop, VALU only: address by v_mul_u32_u24");
+	loop_case<17>("das_staged inner loop with its LDS reads, delays read a batch ahead (v_lshlrev_b16)");
+	loop_case<49>("das_staged inner loop with its LDS reads, delays and phasors read a batch ahead (v_lshlrev_b16)");
+	loop_case<5>("das_staged inner loop, taps read as ds_read_b64 (half the returned bytes; v_lshlrev_b16)");
+	loop_case<9>("das_staged inner loop, LDS reads and position / address arithmetic only (v_lshlrev_b16)");
 	emit("],\n");
 
 	bool first = true;
