@@ -74,6 +74,11 @@ typedef struct {
 	uint32_t window_shift;    /* staged kernel: log2 of the RF window (samples) copied to LDS per transmit */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes the host keeps behind
 	                             the DAS input: where out-of-range lanes gather from */
+	/* staged kernel (complex, linear), 64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are
+	 * uniform and come from a global table (bf_launch_das_staged_tables writes it per frame) through scalar loads */
+	uint32_t uniform;         /* 1: use `tables` */
+	uint32_t table_stride;    /* bytes per (lateral tile row, plane) slice: 4 A4 + 16 + 16 (A4 / 4) 48, A4 = transmits rounded up to 4 */
+	void    *tables;          /* tiles[1] * tiles[2] slices */
 } BfSeparableArgs;
 
 /* geometry of the HERCULES fast path (das_hercules.hip): lanes of a wave lie along the output's x
@@ -153,6 +158,7 @@ hipError_t bf_launch_das(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_count(const BfDasArgs *a, hipStream_t s);
 hipError_t bf_launch_das_separable(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
+hipError_t bf_launch_das_staged_tables(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 hipError_t bf_launch_das_staged_real(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 hipError_t bf_launch_das_staged_cubic(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s);
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds

@@ -99,6 +99,7 @@ struct Device {
 	uint64_t     replan_frame = 0;                             /* first frame of the current plan */
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
 	DeviceBuffer hercules_pairs;                               /* das_hercules.hip: {sample, difference} copy of the DAS input (IQ, linear) */
+	DeviceBuffer staged_tables;        /* das_staged.hip, wave-uniform transmit tables (bf_launch_das_staged_tables) */
 	DeviceBuffer hercules_table;                               /* das_hercules.hip: per-row lateral table, rebuilt per launch */
 	/* multi-device frames (executor.cpp push_multi): the RF of slot k landed on this device / the frame
 	 * that read slot k has finished */

@@ -71,8 +71,14 @@ __device__ __forceinline__ float staged_phase_turns(float k, float index)
  *                      the weight's sign bit set = the lane may leave the RF row (checked loop)                  f32x4
  *   Tz[(a/2)*V + v]  = { T'' = t_index - floor(tmin_a) - 1/2 of transmit a & ~1, of transmit a | 1 }             f32x2
  *   tfl[a]           = floor(tmin_a)  (checked loop and staging only),  rfloor[cl] = floor(rmin_c)               int */
-/* NL: window elements a thread stages per channel, ceil(A4 * W / threads) */
-template <bool CW, int VS, int WS, int NL>
+/* NL: window elements a thread stages per channel, ceil(A4 * W / threads)
+ * UNI: the tile is 64 voxels along the receive axis (= x), so a wave's lanes share ONE row of the transmit axis: the transmit
+ *      delays and phasors are wave uniform.  They then come from a table in global memory (staged_tables_kernel below writes it
+ *      once per frame, the same arithmetic the block otherwise does per tile) through SCALAR loads and enter the packed
+ *      instructions as scalar operands: the LDS serves the four taps of a batch and nothing else (tools/microbench.hip
+ *      loop_probe_uniform: 40.2 clk per term against 43.7, at a higher sustained clock). */
+typedef __attribute__((address_space(4))) const f32x4 const_f32x4;
+template <bool CW, int VS, int WS, int NL, bool UNI>
 __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs p, const BfSeparableArgs q)
 {
 	extern __shared__ __attribute__((aligned(16))) f32x4 staged_lds[];
@@ -85,9 +91,10 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	 * address, which the inner loop forms with one shift */
 	f32x4 *stage  = staged_lds + 2;                          /* (two unused elements in front: see the rounding of the inner loop) */
 	f32x4 *Tcs    = stage + (size_t)A4 * W + 1;
-	f32x4 *R      = Tcs + (size_t)(A4 / 2) * V;
+	const size_t table_rows = UNI ? 0 : (size_t)(A4 / 2) * V;  /* (UNI: no transmit tables in LDS) */
+	f32x4 *R      = Tcs + table_rows;
 	f32x2 *Tz     = reinterpret_cast<f32x2 *>(R + (size_t)chunk * U);
-	int   *tfl    = reinterpret_cast<int *>(Tz + (size_t)(A4 / 2) * V);
+	int   *tfl    = reinterpret_cast<int *>(Tz + table_rows);
 	int   *rfloor = tfl + A4;
 	f32x2 *wave_range = reinterpret_cast<f32x2 *>(rfloor + ((chunk + 1) & ~1));      /* 16 entries, 8-byte aligned */
 	const uint32_t stage_elements = (uint32_t)A4 * W;
@@ -118,51 +125,61 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
 
-	/* ---- transmit tables (absolute delays first) */
-	for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
-		uint32_t a = e >> VS, iv = e & (V - 1);
-		float cs_c = 0.f, cs_s = 0.f, t_idx = 0.f;           /* padding transmits: zero phasor, window position 0 */
-		if (a < (uint32_t)A) {
-			float coord[3] = {0.f, 0.f, pz};
-			coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
-			float wx, wy, wz;
-			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
-			const BfTransmit t = p.transmits[a];
-			float dist = 0.f;
-			if (!(t.flags & BF_TX_NONE)) {
-				float px = (t.flags & BF_TX_ROWS) ? wy : wx;
-				if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
-				else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
-			}
-			t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
-			float turns = staged_phase_turns(phase_k, t_idx);
-			cs_c = hw_cos_turns(turns); cs_s = hw_sin_turns(turns);
-		}
-		const uint32_t pair = (a >> 1) * V + iv, half = a & 1u;
-		reinterpret_cast<f32x2 *>(Tcs + pair)[half] = f32x2{cs_c, cs_s};
-		reinterpret_cast<float *>(Tz + pair)[half]  = t_idx;
-	}
-	if (tid == 0) stage[stage_elements] = f32x4{0.f, 0.f, 0.f, 0.f};
-	/* tile-wide extremes of the absolute transmit delay (range-test shortcut, as das_separable.hip) */
-	__syncthreads();
-	{
-		float lo = __builtin_inff(), hi = -__builtin_inff();
-		for (uint32_t e = tid; e < (uint32_t)A * V; e += nthreads) {
+	/* UNI: the tile's slice of the global table: [A4] floors, {lo, hi} of the absolute delays, then per lateral row of the tile and
+	 * batch of 4 transmits 48 bytes: {T'' x 4}, {cos, sin} x 4 */
+	const unsigned char *tile_tab = UNI ? reinterpret_cast<const unsigned char *>(q.tables) + (size_t)(zl * q.tiles[1] + tv) * q.table_stride : nullptr;
+	f32x2 range;
+	if constexpr (UNI) {
+		for (uint32_t a = tid; a < (uint32_t)A4; a += nthreads) tfl[a] = reinterpret_cast<const int *>(tile_tab)[a];
+		if (tid == 0) stage[stage_elements] = f32x4{0.f, 0.f, 0.f, 0.f};
+		range = *reinterpret_cast<const f32x2 *>(tile_tab + 4u * (uint32_t)A4);
+	} else {
+		/* ---- transmit tables (absolute delays first) */
+		for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
 			uint32_t a = e >> VS, iv = e & (V - 1);
-			float v = reinterpret_cast<const float *>(Tz + (a >> 1) * V + iv)[a & 1u];
-			lo = fminf(lo, v); hi = fmaxf(hi, v);
+			float cs_c = 0.f, cs_s = 0.f, t_idx = 0.f;           /* padding transmits: zero phasor, window position 0 */
+			if (a < (uint32_t)A) {
+				float coord[3] = {0.f, 0.f, pz};
+				coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
+				float wx, wy, wz;
+				m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+				const BfTransmit t = p.transmits[a];
+				float dist = 0.f;
+				if (!(t.flags & BF_TX_NONE)) {
+					float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+					if (t.flags & BF_TX_PLANE) dist = px * t.sin_a + wz * t.cos_a;
+					else { float ddx = px - t.focus_x, ddz = wz - t.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
+				}
+				t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+				float turns = staged_phase_turns(phase_k, t_idx);
+				cs_c = hw_cos_turns(turns); cs_s = hw_sin_turns(turns);
+			}
+			const uint32_t pair = (a >> 1) * V + iv, half = a & 1u;
+			reinterpret_cast<f32x2 *>(Tcs + pair)[half] = f32x2{cs_c, cs_s};
+			reinterpret_cast<float *>(Tz + pair)[half]  = t_idx;
 		}
-		for (int off = 32; off > 0; off >>= 1) {
-			lo = fminf(lo, __shfl_xor(lo, off, 64));
-			hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+		if (tid == 0) stage[stage_elements] = f32x4{0.f, 0.f, 0.f, 0.f};
+		/* tile-wide extremes of the absolute transmit delay (range-test shortcut, as das_separable.hip) */
+		__syncthreads();
+		{
+			float lo = __builtin_inff(), hi = -__builtin_inff();
+			for (uint32_t e = tid; e < (uint32_t)A * V; e += nthreads) {
+				uint32_t a = e >> VS, iv = e & (V - 1);
+				float v = reinterpret_cast<const float *>(Tz + (a >> 1) * V + iv)[a & 1u];
+				lo = fminf(lo, v); hi = fmaxf(hi, v);
+			}
+			for (int off = 32; off > 0; off >>= 1) {
+				lo = fminf(lo, __shfl_xor(lo, off, 64));
+				hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+			}
+			if ((tid & 63u) == 0) wave_range[tid >> 6] = f32x2{lo, hi};
 		}
-		if ((tid & 63u) == 0) wave_range[tid >> 6] = f32x2{lo, hi};
-	}
-	__syncthreads();
-	f32x2 range = wave_range[0];
-	for (uint32_t w = 1; w < (nthreads >> 6); w++) {
-		range.x = fminf(range.x, wave_range[w].x);
-		range.y = fmaxf(range.y, wave_range[w].y);
+		__syncthreads();
+		range = wave_range[0];
+		for (uint32_t w = 1; w < (nthreads >> 6); w++) {
+			range.x = fminf(range.x, wave_range[w].x);
+			range.y = fmaxf(range.y, wave_range[w].y);
+		}
 	}
 	/* the same for every lane: keep it in scalar registers.  (Through scalar temporaries: __builtin_bit_cast applied
 	 * directly to a vector component reads the vector's FIRST component with this hipcc -- range.y silently became
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 		range.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
 	}
 	/* per transmit: floor of the smallest delay of its table row; the row becomes window-relative */
-	for (uint32_t a = tid; a < (uint32_t)A4; a += nthreads) {
+	for (uint32_t a = tid; !UNI && a < (uint32_t)A4; a += nthreads) {
 		float *row = reinterpret_cast<float *>(Tz + (size_t)(a >> 1) * V) + (a & 1u);
 		float  m   = row[0];
 		#pragma unroll 4
@@ -351,14 +368,29 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				 * time against 0.710.  The multiply before the 16-bit shift: 0.701 against 0.700.) */
 				uint32_t m_bits = 0x4B000002u;
 				const f32x2 rr = {r_rel, r_rel};
-				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
+				/* UNI: the wave's row of the global table (lv = tid >> 6 for a 64-wide tile), read through the constant address
+				 * space so that the uniform reads become s_load_dwordx8 + s_load_dwordx4 per batch */
+				const_f32x4 *uni_row = nullptr;
+				if constexpr (UNI)
+					uni_row = (const_f32x4 *)(uintptr_t)(tile_tab + 4u * (uint32_t)A4 + 16u +
+					                                      (size_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * (size_t)(A4 / 4) * 48u);
+				for (int a = 0; a < A4; a += 4, m_bits += 4u * W) {
 					uint32_t at[4]; f32x4 tap[4];
 					const float M = __builtin_bit_cast(float, m_bits);
 					const f32x2 M2 = {M, M};
-					const f32x4 cs01 = *(lds_f32x4 *)(uintptr_t)tcs_at;
-					const f32x4 cs23 = *(lds_f32x4 *)(uintptr_t)(tcs_at + V * 16u);
-					const f32x2 tz01 = *(lds_f32x2 *)(uintptr_t)tz_at;
-					const f32x2 tz23 = *(lds_f32x2 *)(uintptr_t)(tz_at + V * 8u);
+					f32x4 cs01, cs23; f32x2 tz01, tz23;
+					if constexpr (UNI) {
+						const f32x4 tz = uni_row[0];
+						cs01 = uni_row[1]; cs23 = uni_row[2];
+						tz01 = f32x2{tz.x, tz.y}; tz23 = f32x2{tz.z, tz.w};
+						uni_row += 3;
+					} else {
+						cs01 = *(lds_f32x4 *)(uintptr_t)tcs_at;
+						cs23 = *(lds_f32x4 *)(uintptr_t)(tcs_at + V * 16u);
+						tz01 = *(lds_f32x2 *)(uintptr_t)tz_at;
+						tz23 = *(lds_f32x2 *)(uintptr_t)(tz_at + V * 8u);
+						tcs_at += 2u * V * 16u; tz_at += 2u * V * 8u;
+					}
 					const f32x2 p01 = rr + tz01, p23 = rr + tz23;
 					const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
 					const float ys[4] = {y01.x, y01.y, y23.x, y23.y};
@@ -398,27 +430,27 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	reinterpret_cast<f32x2 *>(p.out)[out_index] = coherent;
 }
 
-template <bool CW, int VS, int WS, int NL>
+template <bool CW, int VS, int WS, int NL, bool UNI>
 static hipError_t launch_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
-	auto kernel = das_rca_staged_kernel<CW, VS, WS, NL>;
+	auto kernel = das_rca_staged_kernel<CW, VS, WS, NL, UNI>;
 	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes);
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(kernel, dim3(grid), dim3(q->threads), q->lds_bytes, s, *a, *q);
 	return hipGetLastError();
 }
 
-template <bool CW, int VS, int WS>
+template <bool CW, int VS, int WS, bool UNI>
 static hipError_t launch_staged_loads(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	const uint32_t A4 = ((uint32_t)a->acquisition_count + 3u) & ~3u;
 	switch (((A4 << WS) + q->threads - 1) / q->threads) {
-	case 1: return launch_staged<CW, VS, WS, 1>(a, q, s);
-	case 2: return launch_staged<CW, VS, WS, 2>(a, q, s);
-	case 3: return launch_staged<CW, VS, WS, 3>(a, q, s);
-	case 4: return launch_staged<CW, VS, WS, 4>(a, q, s);
+	case 1: return launch_staged<CW, VS, WS, 1, UNI>(a, q, s);
+	case 2: return launch_staged<CW, VS, WS, 2, UNI>(a, q, s);
+	case 3: return launch_staged<CW, VS, WS, 3, UNI>(a, q, s);
+	case 4: return launch_staged<CW, VS, WS, 4, UNI>(a, q, s);
 	}
 	return hipErrorInvalidValue;
 }
@@ -426,13 +458,20 @@ static hipError_t launch_staged_loads(const BfDasArgs *a, const BfSeparableArgs 
 template <bool CW>
 static hipError_t launch_staged_shape(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
+	if (q->uniform) {
+		/* wave-uniform transmit tables: a 64 x 16 tile with x along the receive axis, 1024 threads, tables written by bf_launch_das_staged_tables */
+		if (q->u_axis != 0 || q->u_shift != 6 || q->v_shift != 4 || q->threads != 1024 || !q->tables) return hipErrorInvalidValue;
+		if (q->window_shift == 5) return launch_staged_loads<CW, 4, 5, true>(a, q, s);
+		if (q->window_shift == 6) return launch_staged_loads<CW, 4, 6, true>(a, q, s);
+		return hipErrorInvalidValue;
+	}
 	switch ((q->v_shift << 4) | q->window_shift) {
-	case (4 << 4) | 5: return launch_staged_loads<CW, 4, 5>(a, q, s);
-	case (5 << 4) | 5: return launch_staged_loads<CW, 5, 5>(a, q, s);
-	case (6 << 4) | 5: return launch_staged_loads<CW, 6, 5>(a, q, s);
-	case (4 << 4) | 6: return launch_staged_loads<CW, 4, 6>(a, q, s);
-	case (5 << 4) | 6: return launch_staged_loads<CW, 5, 6>(a, q, s);
-	case (6 << 4) | 6: return launch_staged_loads<CW, 6, 6>(a, q, s);
+	case (4 << 4) | 5: return launch_staged_loads<CW, 4, 5, false>(a, q, s);
+	case (5 << 4) | 5: return launch_staged_loads<CW, 5, 5, false>(a, q, s);
+	case (6 << 4) | 5: return launch_staged_loads<CW, 6, 5, false>(a, q, s);
+	case (4 << 4) | 6: return launch_staged_loads<CW, 4, 6, false>(a, q, s);
+	case (5 << 4) | 6: return launch_staged_loads<CW, 5, 6, false>(a, q, s);
+	case (6 << 4) | 6: return launch_staged_loads<CW, 6, 6, false>(a, q, s);
 	}
 	return hipErrorInvalidValue;
 }
@@ -444,4 +483,99 @@ extern "C" hipError_t bf_launch_das_staged(const BfDasArgs *a, const BfSeparable
 	/* the staging loads address the DAS input through 32-bit buffer offsets with out-of-range padding at 2^31 */
 	if ((uint64_t)a->channel_count * (uint64_t)a->acquisition_count * (uint64_t)a->sample_count * 8u >= (1ull << 31)) return hipErrorInvalidValue;
 	return a->coherency_weighting ? launch_staged_shape<true>(a, q, s) : launch_staged_shape<false>(a, q, s);
+}
+
+/* ---- the transmit tables of the UNI variant, once per frame: one block per (lateral tile row tv, plane zl), the arithmetic of the
+ * kernel's own table build (same functions, same order: the entries are bit-identical to what a block would compute in LDS).
+ * Layout per tile slice of q.table_stride bytes: int floor(tmin_a)[A4] | {lo, hi} of the absolute delays + 8 bytes of padding |
+ * per lateral row iv < 16 and batch b < A4 / 4: {T'' of transmits 4b .. 4b + 3}, {cos, sin} of 4b, 4b + 1, {cos, sin} of 4b + 2, 4b + 3. */
+__global__ __launch_bounds__(256) void staged_tables_kernel(const BfDasArgs p, const BfSeparableArgs q)
+{
+	extern __shared__ __attribute__((aligned(16))) f32x4 tables_lds[];
+	constexpr uint32_t VS = 4, V = 1u << VS;
+	const int A = p.acquisition_count;
+	const int A4 = (A + 3) & ~3;
+	float *t  = reinterpret_cast<float *>(tables_lds);                 /* [A4][V] */
+	f32x2 *cs = reinterpret_cast<f32x2 *>(t + (size_t)A4 * V);          /* [A4][V] */
+	f32x2 *wave_range = cs + (size_t)A4 * V;                            /* [4] */
+	const uint32_t tv = blockIdx.x % q.tiles[1], zl = blockIdx.x / q.tiles[1];
+	const uint32_t z  = p.z_first + zl;
+	const uint32_t v_axis = 1u - q.u_axis;
+	const float denom[3] = {fmaxf(1.0f, (float)p.size[0] - 1.0f), fmaxf(1.0f, (float)p.size[1] - 1.0f),
+	                        fmaxf(1.0f, (float)p.size[2] - 1.0f)};
+	const float pz = (float)z / denom[2];
+	const float phase_k = p.demodulation_frequency * p.inv_sampling_frequency;
+	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+	for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
+		uint32_t a = e >> VS, iv = e & (V - 1);
+		float cs_c = 0.f, cs_s = 0.f, t_idx = 0.f;
+		if (a < (uint32_t)A) {
+			float coord[3] = {0.f, 0.f, pz};
+			coord[v_axis] = (float)(tv * V + iv) / denom[v_axis];
+			float wx, wy, wz;
+			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			const BfTransmit t_a = p.transmits[a];
+			float dist = 0.f;
+			if (!(t_a.flags & BF_TX_NONE)) {
+				float px = (t_a.flags & BF_TX_ROWS) ? wy : wx;
+				if (t_a.flags & BF_TX_PLANE) dist = px * t_a.sin_a + wz * t_a.cos_a;
+				else { float ddx = px - t_a.focus_x, ddz = wz - t_a.focus_z; dist = hw_sqrt(ddx * ddx + ddz * ddz); }
+			}
+			t_idx = (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+			float turns = staged_phase_turns(phase_k, t_idx);
+			cs_c = hw_cos_turns(turns); cs_s = hw_sin_turns(turns);
+		}
+		t[e] = t_idx; cs[e] = f32x2{cs_c, cs_s};
+	}
+	__syncthreads();
+	{
+		float lo = __builtin_inff(), hi = -__builtin_inff();
+		for (uint32_t e = tid; e < (uint32_t)A * V; e += nthreads) { lo = fminf(lo, t[e]); hi = fmaxf(hi, t[e]); }
+		for (int off = 32; off > 0; off >>= 1) {
+			lo = fminf(lo, __shfl_xor(lo, off, 64));
+			hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+		}
+		if ((tid & 63u) == 0) wave_range[tid >> 6] = f32x2{lo, hi};
+	}
+	__syncthreads();
+	unsigned char *tile_tab = reinterpret_cast<unsigned char *>(q.tables) + (size_t)blockIdx.x * q.table_stride;
+	if (tid == 0) {
+		f32x2 range = wave_range[0];
+		for (uint32_t w = 1; w < (nthreads >> 6); w++) {
+			range.x = fminf(range.x, wave_range[w].x);
+			range.y = fmaxf(range.y, wave_range[w].y);
+		}
+		*reinterpret_cast<f32x4 *>(tile_tab + 4u * (uint32_t)A4) = f32x4{range.x, range.y, 0.f, 0.f};
+	}
+	for (uint32_t a = tid; a < (uint32_t)A4; a += nthreads) {
+		float *row = t + (size_t)a * V;
+		float  m   = row[0];
+		for (uint32_t iv = 1; iv < V; iv++) m = fminf(m, row[iv]);
+		float fl = __builtin_floorf(m);
+		for (uint32_t iv = 0; iv < V; iv++) row[iv] = (row[iv] - fl) - 0.5f;      /* both steps exact */
+		reinterpret_cast<int *>(tile_tab)[a] = (int)fl;
+	}
+	__syncthreads();
+	const uint32_t batches = (uint32_t)A4 / 4u;
+	f32x4 *rows = reinterpret_cast<f32x4 *>(tile_tab + 4u * (uint32_t)A4 + 16u);
+	for (uint32_t e = tid; e < V * batches; e += nthreads) {
+		const uint32_t iv = e / batches, b = e % batches;
+		const float *t4 = t + (size_t)(4u * b) * V + iv;
+		const f32x2 *c4 = cs + (size_t)(4u * b) * V + iv;
+		f32x4 *row = rows + (size_t)e * 3u;
+		row[0] = f32x4{t4[0], t4[V], t4[2 * V], t4[3 * V]};
+		row[1] = f32x4{c4[0].x, c4[0].y, c4[V].x, c4[V].y};
+		row[2] = f32x4{c4[2 * V].x, c4[2 * V].y, c4[3 * V].x, c4[3 * V].y};
+	}
+}
+
+/* one launch per frame and shard, before bf_launch_das_staged with q->uniform set; q->tables holds q->tiles[1] * q->tiles[2] slices */
+extern "C" hipError_t bf_launch_das_staged_tables(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
+{
+	if (!q->uniform || !q->tables || q->v_shift != 4) return hipErrorInvalidValue;
+	const uint32_t A4 = ((uint32_t)a->acquisition_count + 3u) & ~3u;
+	if (q->table_stride < 4u * A4 + 16u + 16u * (A4 / 4u) * 48u) return hipErrorInvalidValue;
+	const uint32_t lds = A4 * 16u * 12u + 64u;
+	hipLaunchKernelGGL(staged_tables_kernel, dim3(q->tiles[1] * q->tiles[2]), dim3(256), lds, s, *a, *q);
+	return hipGetLastError();
 }

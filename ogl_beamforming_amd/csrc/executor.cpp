@@ -164,7 +164,7 @@ static void release_one_device(Device &d)
 	for (auto &b : d.rf) b.release();
 	for (auto &b : d.scratch) b.release();
 	d.ring.release(); d.pair_counter.release(); d.minmax_scratch.release(); d.sum_scratch.release();
-	d.hercules_table.release(); d.hercules_pairs.release();
+	d.hercules_table.release(); d.hercules_pairs.release(); d.staged_tables.release();
 	for (auto &g : d.frame_exec) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
 	for (auto &g : d.graph_generation) g = 0;
 	for (auto &t : d.timing) {
@@ -435,7 +435,7 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
  * most one lateral voxel step (in samples) per voxel along u; the transmit delay likewise along
  * v, scaled by max|sin(angle)| when every transmit is a plane wave. */
 static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
-                        uint32_t zcount, BfSeparableArgs &q)
+                        uint32_t zcount, BfSeparableArgs &q, bool allow_uniform = true)
 {
 	const bool cplx = a.complex_data != 0;                       /* das_staged.hip / das_staged_real.hip */
 	const bool cubic = a.interpolation == 2;                     /* das_staged_cubic.hip: complex samples only */
@@ -485,11 +485,16 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
 			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
 			if (((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
+			/* complex samples, linear interpolation, x along the receive axis and a 64 x 16 tile: a wave's lanes share one row of the
+			 * transmit axis, the transmit tables leave the LDS for a global table read through scalar loads (das_staged.hip, UNI).
+			 * Measured faster than every other shape, so it is preferred wherever its window fits. */
+			const bool uniform = allow_uniform && cplx && !cubic && u_axis == 0 && threads_shift == 10 && us == 6 && vs == 4 &&
+			                     !std::getenv("BEAMFORMER_HIP_STAGED_NOUNIFORM");
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
 				uint64_t lds = cubic ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 32ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
-				             : cplx ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
+				             : cplx ? (uniform ? 0ull : 12ull * ((uint64_t)A4 << vs)) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
 				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (((uint64_t)A4 << ws) + 4) + 4ull * (A4 + cc + 1) + 128;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
@@ -497,11 +502,13 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 				if (blocks > by_waves) blocks = by_waves;
 				uint32_t waves = blocks << (threads_shift - 6);
 				uint32_t balance = us > vs ? us - vs : vs - us;
-				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (ws == 5 ? 500u : 0u);
+				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (ws == 5 ? 500u : 0u) + (uniform && ws == 5 ? 2000u : 0u);
 				if (waves > best_waves || (waves == best_waves && score > best_score)) {
 					best_waves = waves; best_score = score;
 					best.u_shift = us; best.v_shift = vs; best.threads = 1u << threads_shift;
 					best.channel_chunk = cc; best.lds_bytes = (uint32_t)lds; best.window_shift = ws;
+					best.uniform = uniform ? 1u : 0u;
+					best.table_stride = uniform ? 4u * A4 + 16u + 16u * (A4 / 4u) * 48u : 0u;
 				}
 				if (cc == C) break;
 			}
@@ -509,8 +516,8 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 	}
 	if (std::getenv("BEAMFORMER_HIP_STAGED_CHECKED")) best.depth_major |= 2u;      /* test hook: the range-checked loop for every wave */
 	if (std::getenv("BEAMFORMER_HIP_DEBUG"))
-		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u\n",
-		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_shift, best.channel_chunk, best.lds_bytes);
+		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u uniform %u\n",
+		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_shift, best.channel_chunk, best.lds_bytes, best.uniform);
 	if (!best_waves) return false;
 	q = best;
 	uint32_t nu = a.size[u_axis], nv = a.size[v_axis];
@@ -884,7 +891,22 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					/* the LDS-staged kernel pays two block barriers and a window copy per channel: it wins once a channel
 					 * carries enough transmits to amortise them (kStagedMinTransmits, measured: tools/staged_threshold.py) */
 					const bool want_staged = das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits);
-					if (want_staged && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
+					bool staged = want_staged && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep);
+					if (staged && sep.uniform) {
+						/* the wave-uniform transmit tables live in global memory: one slice per (lateral tile row, plane), written per frame
+						 * (a few MB to 244 MB at 512^3 with 75 transmits; too big or no memory: the shapes with the tables in LDS) */
+						const uint64_t table_bytes = (uint64_t)sep.table_stride * sep.tiles[1] * sep.tiles[2];
+						if (table_bytes <= (2ull << 30) && d.staged_tables.ensure(table_bytes)) {
+							sep.tables = d.staged_tables.ptr;
+							ok &= HIP_OK(bf_launch_das_staged_tables(&a, &sep, s));
+						} else {
+							BfSeparableArgs again = sep;
+							again.uniform = 0; again.table_stride = 0; again.tables = nullptr;
+							staged = plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, again, false);
+							if (staged) sep = again;
+						}
+					}
+					if (staged) {
 						ok &= HIP_OK(!plan.iq_pipeline ? bf_launch_das_staged_real(&a, &sep, s) :
 						             a.interpolation == 2 ? bf_launch_das_staged_cubic(&a, &sep, s) : bf_launch_das_staged(&a, &sep, s));
 						das_path = 2;

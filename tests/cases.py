@@ -73,6 +73,14 @@ def _cases():
     c["rca_staged_cubic_short_rows"] = lambda: cfg.rca("rca_staged_cubic_short_rows", 24, 7, 384, (45, 70, 2), LO3, HI3, seed=52,
                                                        orientation=0x21, cw=False, interp=I.Cubic, f_number=0.6,
                                                        angles=np.linspace(-12, 12, 7))
+    # a lateral grid fine enough for 64 x 16 tiles (64 voxels along the receive axis = x): the staged kernel's wave-uniform
+    # transmit tables (global table + scalar loads), with coherency weighting and 13 transmits (padded batch), and with focused
+    # transmits over short rows (its checked loop)
+    c["rca_staged_fine"] = lambda: cfg.rca("rca_staged_fine", 32, 13, 512, (150, 36, 3), LO3, HI3, seed=53, orientation=0x12,
+                                           cw=True, f_number=0.6, angles=np.linspace(-12, 12, 13))
+    c["rca_staged_fine_vls_short_rows"] = lambda: cfg.rca("rca_staged_fine_vls_short_rows", 32, 8, 512, (150, 20, 2), LO3, HI3, seed=54,
+                                                          orientation=0x12, cw=False, kind=K.RCA_VLS, f_number=0.6, angles=np.linspace(-8, 8, 8),
+                                                          depths=np.array([-12e-3, 30e-3, -20e-3, 45e-3, 25e-3, -15e-3, 60e-3, -30e-3]))
     c["rca_f32_complex_in"] = lambda: cfg.rca("rca_f32_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=14,
                                               demodulate=False, data_kind=D.Float32Complex, interp=I.Cubic)
     c["rca_i16_complex_in"] = lambda: cfg.rca("rca_i16_complex_in", 16, 2, 256, (16, 16, 1), LO3, HI3, seed=15,

@@ -59,13 +59,14 @@ def last_das_path(bflib):
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
 # them up on its own (das_separable.hip)
 SEPARABLE = {"config4_small", "rca_vls_cw", "rca_sep_ragged_cubic", "rca_sep_real_nearest",
-             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows", "rca_staged_cubic", "rca_staged_cubic_short_rows"}
+             "rca_staged_w64", "rca_staged_too_wide", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows", "rca_staged_cubic", "rca_staged_cubic_short_rows",
+             "rca_staged_fine", "rca_staged_fine_vls_short_rows"}
 # ... and of those, the ones with linear interpolation (complex or real samples) or cubic interpolation of complex samples whose
 # delay spread fits an LDS window
 # can run the LDS-staged kernel (das_staged.hip): automatically from STAGED_MIN_TRANSMITS transmits per
 # channel (executor.cpp kStagedMinTransmits), on request (path 3) below that
 STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_auto", "rca_vls_staged", "rca_vls_staged_short_rows", "rca_staged_real", "rca_staged_real_short_rows", "rca_staged_cubic", "rca_staged_cubic_short_rows",
-          "rca_sep_ragged_cubic"}
+          "rca_sep_ragged_cubic", "rca_staged_fine", "rca_staged_fine_vls_short_rows"}
 STAGED_MIN_TRANSMITS = 6
 
 
@@ -191,6 +192,40 @@ def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracl
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)
+
+
+@pytest.mark.parametrize("shape", ["6,4,5", "6,4,6"])
+@pytest.mark.parametrize("name", ["rca_staged_fine", "rca_staged_fine_vls_short_rows", "rca_staged_auto"])
+def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, monkeypatch, capfd):
+    """64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are uniform and come from a global
+    table (written per frame by a pre-pass) through scalar loads instead of from LDS.  Same arithmetic: the frame is
+    BIT-IDENTICAL to the one the same tile shape gives with the tables in LDS (BEAMFORMER_HIP_STAGED_NOUNIFORM), and both
+    are the oracle's."""
+    acq = cases.make(name)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    monkeypatch.setenv("BEAMFORMER_HIP_STAGED_SHAPE", shape)
+    monkeypatch.setenv("BEAMFORMER_HIP_DEBUG", "1")
+    lib.beamformer_hip_set_das_path(3)
+    try:
+        capfd.readouterr()
+        uniform = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        path_uniform = last_das_path(bflib)
+        log = capfd.readouterr().err
+        monkeypatch.setenv("BEAMFORMER_HIP_STAGED_NOUNIFORM", "1")
+        tables_in_lds = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        path_lds = last_das_path(bflib)
+        log_lds = capfd.readouterr().err
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    assert path_uniform == path_lds
+    if path_uniform == 2:
+        assert "uniform 1" in log and "uniform 1" not in log_lds, (log, log_lds)
+        assert np.array_equal(np.asarray(uniform).view(np.uint32), np.asarray(tables_in_lds).view(np.uint32))
+    if name == "rca_staged_fine":
+        assert path_uniform == 2                 # (rca_staged_auto's coarse grid fits no window 64 voxels wide, the focused transmits'
+                                                 #  spread not every window: declined either way, the gather kernel runs)
+    compare(uniform, ref, acq, flags)
 
 
 @pytest.mark.parametrize("name", sorted(STAGED))

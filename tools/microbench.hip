@@ -315,6 +315,57 @@ __global__ __launch_bounds__(1024, 8) void loop_probe(Stamp *stamps, float *sink
 	}
 }
 
+/* The same loop when a wave's 64 voxels share one lateral row of the transmit axis (a 64 x 16 tile): delays and phasors are wave
+ * uniform, come from a table in global memory through SCALAR loads (3 x s_load_dwordx4 per batch) and enter the packed ops as
+ * scalar operands; the LDS serves the four taps only. */
+__global__ __launch_bounds__(1024, 8) void loop_probe_uniform(const f32x4 *table, Stamp *stamps, float *sink, int iters)
+{
+	extern __shared__ __attribute__((aligned(16))) f32x4 probe_lds[];
+	constexpr uint32_t A4 = 76, W = 32;
+	for (uint32_t i = threadIdx.x; i < A4 * W + 3; i += blockDim.x) probe_lds[i] = f32x4{0.5f + 0.001f * i, 0.25f, 0.125f, -0.5f};
+	__syncthreads();
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const float r_rel = 0.4f * (float)(threadIdx.x & 63u);
+	typedef __attribute__((address_space(4))) const f32x4 const_f32x4;        /* constant address space: uniform reads become s_load */
+	const_f32x4 *row = (const_f32x4 *)(uintptr_t)(table + (size_t)wave * (A4 / 4) * 3);   /* per wave and batch: {tz0..3}, {cs0, cs1}, {cs2, cs3} */
+	f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, mag2 = {0.f, 0.f};
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		uint32_t m_bits = 0x4B000002u;
+		const f32x2 rr = {r_rel, r_rel};
+		const_f32x4 *at_row = row;
+		for (uint32_t a = 0; a < A4; a += 4, at_row += 3, m_bits += 4u * W) {
+			const float M = __builtin_bit_cast(float, m_bits);
+			const f32x2 M2 = {M, M};
+			const f32x4 tz = at_row[0], cs01 = at_row[1], cs23 = at_row[2];
+			const f32x2 p01 = rr + f32x2{tz.x, tz.y}, p23 = rr + f32x2{tz.z, tz.w};
+			const f32x2 y01 = p01 + M2,  y23 = p23 + M2;
+			const float ys[4] = {y01.x, y01.y, y23.x, y23.y}, ps[4] = {p01.x, p01.y, p23.x, p23.y};
+			uint32_t at[4]; f32x4 tap[4];
+			#pragma unroll
+			for (int k = 0; k < 4; k++) asm("v_lshlrev_b16 %0, 4, %1" : "=v"(at[k]) : "v"(__builtin_bit_cast(uint32_t, ys[k])));
+			#pragma unroll
+			for (int k = 0; k < 4; k++) tap[k] = *(mb_lds_f32x4 *)(uintptr_t)(at[k] + (uint32_t)k * W * 16u);
+			const f32x2 cs[4] = {{cs01.x, cs01.y}, {cs01.z, cs01.w}, {cs23.x, cs23.y}, {cs23.z, cs23.w}};
+			float q[4];
+			#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				f32x2 sv = f32x2{tap[k].x, tap[k].y} + ps[k] * f32x2{tap[k].z, tap[k].w};
+				acc1 += sv.x * cs[k];
+				acc2 += sv.y * cs[k];
+				q[k] = __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+			}
+			mag2 += f32x2{q[0], q[1]}; mag2 += f32x2{q[2], q[3]};
+		}
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (mag2.x + mag2.y + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag2.x;
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		stamps[w] = Stamp{t1 - t0, r1 - r0};
+	}
+}
+
 /* ------------------------------------------------------------------ per-lane gathers from global memory */
 enum { PAT_COALESCED, PAT_DAS, PAT_RANDOM, PAT_COUNT };
 static const char *pat_name[PAT_COUNT] = {"contiguous", "das_like", "random"};
@@ -537,6 +588,30 @@ template <int MODE> static void loop_case(const char *what)
 	     what, wall_cycles / (terms * 8), r.cycles_per_wave / (terms * 8), r.clock_ghz, r.wall_ms);
 }
 
+static void loop_uniform_case(const char *what)
+{
+	const int iters = 1000;
+	const uint32_t lds = 16u * (76u * 32u + 3u) + 64u;
+	CHECK(hipFuncSetAttribute((const void *)loop_probe_uniform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	std::vector<float> h(16 * 19 * 12);
+	for (int w = 0; w < 16; w++) for (int b = 0; b < 19; b++) {
+		float *e = &h[(size_t)(w * 19 + b) * 12];
+		for (int k = 0; k < 4; k++) e[k] = 1.f + 0.3f * w + 0.7f * (float)((4 * b + k) % 5);
+		for (int k = 0; k < 4; k++) { e[4 + 2 * k] = 0.6f; e[5 + 2 * k] = 0.8f; }
+	}
+	f32x4 *d_table;
+	CHECK(hipMalloc(&d_table, h.size() * 4));
+	CHECK(hipMemcpy(d_table, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+	int blocks = n_cu * 2, waves = blocks * 16;
+	Result r = run([&] { hipLaunchKernelGGL(loop_probe_uniform, dim3(blocks), dim3(1024), lds, 0, d_table, d_stamps, d_sink, iters); }, waves);
+	double terms = 76.0 * iters;
+	double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+	emit(",\n  {\"stream\":\"%s\",\"waves_per_simd\":8,"
+	     "\"cycles_per_term_per_simd_wall\":%.3f,\"cycles_per_term_per_simd_stamps\":%.3f,\"clock_ghz\":%.3f,\"wall_ms\":%.3f}",
+	     what, wall_cycles / (terms * 8), r.cycles_per_wave / (terms * 8), r.clock_ghz, r.wall_ms);
+	CHECK(hipFree(d_table));
+}
+
 static char *d_window;
 
 template <int WIDTH, int PAT> static void gather_case(const char *level, uint32_t window, bool per_block, bool &first)
@@ -637,6 +712,7 @@ int main(int argc, char **argv)
 	loop_case<1>("das_staged inner loop with its LDS reads: address by v_lshlrev_b16");
 	loop_case<3>("das_staged inner loop, VALU only (operands stay in registers): address by v_lshlrev_b16");
 	loop_case<2>("das_staged inner loop, VALU only: address by v_mul_u32_u24");
+	loop_uniform_case("das_staged inner loop, wave-uniform delays and phasors through scalar loads (a 64 x 16 tile), LDS serves the taps only");
 	loop_case<17>("das_staged inner loop with its LDS reads, delays read a batch ahead (v_lshlrev_b16)");
 	loop_case<49>("das_staged inner loop with its LDS reads, delays and phasors read a batch ahead (v_lshlrev_b16)");
 	loop_case<5>("das_staged inner loop, taps read as ds_read_b64 (half the returned bytes; v_lshlrev_b16)");

@@ -34,6 +34,7 @@ timeout -k 10 300 python bench.py --das-path 2 --steps 3 --warmup 1 --no-cpu-bas
 PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --json $OUT/profiles/r02_staged_threshold.json > $OUT/staged_threshold.log 2>&1 || echo "staged threshold sweep failed"
 PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --real --json $OUT/profiles/r02_staged_threshold_real.json > $OUT/staged_threshold_real.log 2>&1 || echo "staged threshold sweep (real) failed"
 PYTHONPATH=$ROOT timeout -k 10 300 python tools/staged_threshold.py --cubic --json $OUT/profiles/r02_staged_threshold_cubic.json > $OUT/staged_threshold_cubic.log 2>&1 || echo "staged threshold sweep (cubic) failed"
+PYTHONPATH=$ROOT timeout -k 10 200 python tools/staged_uniform.py --json $OUT/profiles/r02_staged_uniform.json > $OUT/staged_uniform.log 2>&1 || echo "staged uniform-tables comparison failed"
 PYTHONPATH=$ROOT timeout -k 10 300 python tools/pull_rate.py --json $OUT/profiles/r02_pull_rate.json > $OUT/pull_rate.log 2>&1 || echo "pull rate failed"
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
 python3 - <<'PY'
