@@ -77,6 +77,7 @@ typedef struct {
 	/* staged kernel (complex, linear), 64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are
 	 * uniform and come from a global table (bf_launch_das_staged_tables writes it per frame) through scalar loads */
 	uint32_t uniform;         /* 1: use `tables` */
+	uint32_t window_samples;  /* 32, 64 (= 1 << window_shift), or 48: the uniform variant's in-between window */
 	uint32_t table_stride;    /* bytes per (lateral tile row, plane) slice: 4 A4 + 16 + 16 (A4 / 4) 48, A4 = transmits rounded up to 4 */
 	void    *tables;          /* tiles[1] * tiles[2] slices */
 } BfSeparableArgs;

@@ -474,39 +474,48 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
 			if (!ws) continue;
 			/* BEAMFORMER_HIP_STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
-			 * a window larger than needed is legal, a smaller one is not taken) */
+			 * a window larger than needed is legal, a smaller one is not taken; ws = 48: the uniform variant's 48-sample window) */
+			bool force_w48 = false;
 			if (const char *force = std::getenv("BEAMFORMER_HIP_STAGED_SHAPE")) {
 				unsigned fu = 0, fv = 0, fw = 0;
 				if (std::sscanf(force, "%u,%u,%u", &fu, &fv, &fw) == 3) {
-					if (fu != us || fv != vs || fw < ws || fw > 6) continue;
-					ws = fw;
+					if (fu != us || fv != vs) continue;
+					if (fw == 48) { if (need > 48) continue; force_w48 = true; }
+					else { if (fw < ws || fw > 6) continue; ws = fw; }
 				}
 			}
-			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
-			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
-			if (((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
 			/* complex samples, linear interpolation, x along the receive axis and a 64 x 16 tile: a wave's lanes share one row of the
 			 * transmit axis, the transmit tables leave the LDS for a global table read through scalar loads (das_staged.hip, UNI).
-			 * Measured faster than every other shape, so it is preferred wherever its window fits. */
+			 * Measured faster than every other shape, so it is preferred wherever its window fits -- with a
+			 * 48-sample window where 32 samples are too few (64-sample windows of 64 and more transmits leave no room for two
+			 * blocks per CU): 63 elements per wave and pass, at most 4 passes of the 16 waves */
 			const bool uniform = allow_uniform && cplx && !cubic && u_axis == 0 && threads_shift == 10 && us == 6 && vs == 4 &&
 			                     !std::getenv("BEAMFORMER_HIP_STAGED_NOUNIFORM");
+			uint32_t window = 1u << ws;
+			if (uniform && (force_w48 || (need > 32 && need <= 48)) && (A4 * 48u + 62u) / 63u <= 64u) window = 48;
+			else if (force_w48) continue;
+			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
+			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
+			if (window != 48 && ((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
+			const uint64_t stage_elements = (uint64_t)A4 * window;
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
 				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
-				uint64_t lds = cubic ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 32ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
-				             : cplx ? (uniform ? 0ull : 12ull * ((uint64_t)A4 << vs)) + 16ull * ((uint64_t)cc << us) + 16ull * (((uint64_t)A4 << ws) + 3) + 4ull * (A4 + cc + 1) + 128
-				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (((uint64_t)A4 << ws) + 4) + 4ull * (A4 + cc + 1) + 128;
+				uint64_t lds = cubic ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 32ull * (stage_elements + 3) + 4ull * (A4 + cc + 1) + 128
+				             : cplx ? (uniform ? 0ull : 12ull * ((uint64_t)A4 << vs)) + 16ull * ((uint64_t)cc << us) + 16ull * (stage_elements + 3) + 4ull * (A4 + cc + 1) + 128
+				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (stage_elements + 4) + 4ull * (A4 + cc + 1) + 128;
 				lds = (lds + 15) & ~15ull;
 				if (lds > lds_cu) continue;
 				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = (cubic ? 1024u : 2048u) >> threads_shift;   /* (cubic: 128 VGPRs per lane) */
 				if (blocks > by_waves) blocks = by_waves;
 				uint32_t waves = blocks << (threads_shift - 6);
 				uint32_t balance = us > vs ? us - vs : vs - us;
-				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (ws == 5 ? 500u : 0u) + (uniform && ws == 5 ? 2000u : 0u);
+				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (window == 32 ? 500u : 0u) +
+				                 (uniform && window == 32 ? 2000u : uniform && window == 48 ? 1500u : 0u);
 				if (waves > best_waves || (waves == best_waves && score > best_score)) {
 					best_waves = waves; best_score = score;
 					best.u_shift = us; best.v_shift = vs; best.threads = 1u << threads_shift;
-					best.channel_chunk = cc; best.lds_bytes = (uint32_t)lds; best.window_shift = ws;
+					best.channel_chunk = cc; best.lds_bytes = (uint32_t)lds; best.window_shift = ws; best.window_samples = window;
 					best.uniform = uniform ? 1u : 0u;
 					best.table_stride = uniform ? 4u * A4 + 16u + 16u * (A4 / 4u) * 48u : 0u;
 				}
@@ -517,7 +526,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 	if (std::getenv("BEAMFORMER_HIP_STAGED_CHECKED")) best.depth_major |= 2u;      /* test hook: the range-checked loop for every wave */
 	if (std::getenv("BEAMFORMER_HIP_DEBUG"))
 		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u uniform %u\n",
-		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_shift, best.channel_chunk, best.lds_bytes, best.uniform);
+		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_samples, best.channel_chunk, best.lds_bytes, best.uniform);
 	if (!best_waves) return false;
 	q = best;
 	uint32_t nu = a.size[u_axis], nv = a.size[v_axis];

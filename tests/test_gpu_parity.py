@@ -194,13 +194,13 @@ def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracl
     compare(gpu, ref, acq, flags)
 
 
-@pytest.mark.parametrize("shape", ["6,4,5", "6,4,6"])
+@pytest.mark.parametrize("shape", ["6,4,5", "6,4,48", "6,4,6"])
 @pytest.mark.parametrize("name", ["rca_staged_fine", "rca_staged_fine_vls_short_rows", "rca_staged_auto"])
 def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, monkeypatch, capfd):
     """64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are uniform and come from a global
     table (written per frame by a pre-pass) through scalar loads instead of from LDS.  Same arithmetic: the frame is
     BIT-IDENTICAL to the one the same tile shape gives with the tables in LDS (BEAMFORMER_HIP_STAGED_NOUNIFORM), and both
-    are the oracle's."""
+    are the oracle's.  "6,4,48": the 48-sample window only this variant has (63 staged elements per wave and pass)."""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
@@ -218,14 +218,20 @@ def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, monkeypatc
         log_lds = capfd.readouterr().err
     finally:
         lib.beamformer_hip_set_das_path(0)
-    assert path_uniform == path_lds
+    if shape == "6,4,48":
+        assert path_lds == 1                     # no 48-sample window with the tables in LDS: declined, the gather kernel runs
+    else:
+        assert path_uniform == path_lds
     if path_uniform == 2:
         assert "uniform 1" in log and "uniform 1" not in log_lds, (log, log_lds)
-        assert np.array_equal(np.asarray(uniform).view(np.uint32), np.asarray(tables_in_lds).view(np.uint32))
+        if path_lds == 2:
+            assert np.array_equal(np.asarray(uniform).view(np.uint32), np.asarray(tables_in_lds).view(np.uint32))
     if name == "rca_staged_fine":
         assert path_uniform == 2                 # (rca_staged_auto's coarse grid fits no window 64 voxels wide, the focused transmits'
                                                  #  spread not every window: declined either way, the gather kernel runs)
     compare(uniform, ref, acq, flags)
+    if path_lds == 1 and path_uniform == 2:
+        compare(tables_in_lds, ref, acq, flags)
 
 
 @pytest.mark.parametrize("name", sorted(STAGED))

@@ -37,9 +37,12 @@ for scale in (float(v) for v in args.scales.split(",")):
     dev = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1)).cuda()
     row = {"x_extent_scale": scale, "planes": args.planes, "transmits": A}
     frames = {}
-    for name, env in (("tables_in_lds", "1"), ("uniform", None)):
+    # (the third leg: the 48-sample window config 4 itself needs, on a grid that does not need it -- what the longer window costs)
+    for name, env, shape in (("tables_in_lds", "1", None), ("uniform", None, None), ("uniform_48_sample_window", None, "6,4,48")):
         if env: os.environ["BEAMFORMER_HIP_STAGED_NOUNIFORM"] = env
         else:   os.environ.pop("BEAMFORMER_HIP_STAGED_NOUNIFORM", None)
+        if shape: os.environ["BEAMFORMER_HIP_STAGED_SHAPE"] = shape
+        else:     os.environ.pop("BEAMFORMER_HIP_STAGED_SHAPE", None)
         t = P.HipFrameTimings()
         best = 1e9
         for _ in range(4):
@@ -49,6 +52,7 @@ for scale in (float(v) for v in args.scales.split(",")):
             best = min(best, float(t.stage_ms[kinds.index(int(P.ShaderKind.DAS))]))
         row[name + "_ms"] = best
         row[name + "_path"] = int(t.das_path)
+    os.environ.pop("BEAMFORMER_HIP_STAGED_SHAPE", None)
     row["uniform_over_tables_in_lds"] = row["uniform_ms"] / row["tables_in_lds_ms"]
     rows.append(row)
     print(json.dumps(row), flush=True)
