@@ -492,7 +492,10 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			const bool uniform = allow_uniform && cplx && !cubic && u_axis == 0 && threads_shift == 10 && us == 6 && vs == 4 &&
 			                     !std::getenv("BEAMFORMER_HIP_STAGED_NOUNIFORM");
 			uint32_t window = 1u << ws;
-			if (uniform && (force_w48 || (need > 32 && need <= 48)) && (A4 * 48u + 62u) / 63u <= 64u) window = 48;
+			/* (the 48-sample window is opt-in -- BEAMFORMER_HIP_STAGED_W48, or the shape hook: at config 4 it measured 799.0 ms against
+			 * 804.5 ms for the 32 x 32 tiles with the tables in LDS, but 726 GB of HBM-side traffic per launch against 176 GB) */
+			const bool want_w48 = force_w48 || (std::getenv("BEAMFORMER_HIP_STAGED_W48") && need > 32 && need <= 48);
+			if (uniform && want_w48 && (A4 * 48u + 62u) / 63u <= 64u) window = 48;
 			else if (force_w48) continue;
 			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
 			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
