@@ -102,12 +102,23 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	f32x2 *wave_range = reinterpret_cast<f32x2 *>(rfloor + ((chunk + 1) & ~1));      /* 16 entries, 8-byte aligned */
 	const uint32_t stage_elements = (uint32_t)A4 * W;
 
-	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
+	/* depth_major bit 2 (UNI): planes in chunks of 32, so that blocks j and j + 32 of an XCD's sequence -- the two a CU holds
+	 * (dispatch is breadth first over an XCD's 32 CUs) -- are NEIGHBOURS ALONG u in one plane: they read the same 16 rows of the
+	 * global transmit table (14.6 KB at 76 transmits: the scalar cache holds 16 KB) and adjacent RF windows */
+	const bool paired = UNI && (q.depth_major & 4u);
+	const uint32_t zchunks = (q.tiles[2] + 31u) >> 5;
+	const uint32_t total = paired ? q.tiles[0] * q.tiles[1] * zchunks * 32u : q.tiles[0] * q.tiles[1] * q.tiles[2];
 	const uint32_t per   = (total + 7u) / 8u;
 	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 	if (tile >= total) return;                               /* whole block */
 	uint32_t tu, tv, zl;                                     /* walk order: das_separable.hip */
-	if (q.depth_major & 1u) {
+	if (paired) {
+		uint32_t r = tile >> 5;
+		tu = r % q.tiles[0]; r /= q.tiles[0];
+		zl = (r % zchunks) * 32u + (tile & 31u);
+		tv = r / zchunks;
+		if (zl >= q.tiles[2]) return;                        /* whole block: the last chunk's padding */
+	} else if (q.depth_major & 1u) {
 		zl = tile % q.tiles[2];
 		tu = (tile / q.tiles[2]) % q.tiles[0];
 		tv = tile / (q.tiles[2] * q.tiles[0]);
@@ -456,6 +467,7 @@ template <bool CW, int VS, int WS, int NL, bool UNI>
 static hipError_t launch_staged(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
+	if (UNI && (q->depth_major & 4u)) total = q->tiles[0] * q->tiles[1] * ((q->tiles[2] + 31u) >> 5) * 32u;   /* the paired walk pads the planes to chunks of 32 */
 	uint32_t grid  = ((total + 7u) / 8u) * 8u;
 	auto kernel = das_rca_staged_kernel<CW, VS, WS, NL, UNI>;
 	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q->lds_bytes);

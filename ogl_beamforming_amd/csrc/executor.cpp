@@ -526,7 +526,13 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			}
 		}
 	}
-	if (std::getenv("BEAMFORMER_HIP_STAGED_CHECKED")) best.depth_major |= 2u;      /* test hook: the range-checked loop for every wave */
+	if (std::getenv("BEAMFORMER_HIP_STAGED_CHECKED")) best.depth_major |= 2u;
+	/* uniform variant: the two blocks of a CU are neighbours along u in one plane (shared rows of the global transmit table);
+	 * BEAMFORMER_HIP_STAGED_WALK=column keeps the plain depth-major walk (measurement aid) */
+	{
+		const char *walk = std::getenv("BEAMFORMER_HIP_STAGED_WALK");
+		if (best.uniform && (best.depth_major & 1u) && !(walk && walk[0] == 'c')) best.depth_major |= 4u;
+	}      /* test hook: the range-checked loop for every wave */
 	if (std::getenv("BEAMFORMER_HIP_DEBUG"))
 		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u uniform %u\n",
 		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_samples, best.channel_chunk, best.lds_bytes, best.uniform);

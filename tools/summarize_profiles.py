@@ -43,6 +43,7 @@ COMPULSORY = {2: 128 * 31 * 2048 * 8 + 1024 * 1024 * 8, 3: 32 * 32 * 2048 * 4 + 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", default="r02")
+    ap.add_argument("--merge", action="store_true", help="start from the existing files: only the (configuration, kernel) entries of the given summaries are replaced")
     ap.add_argument("summaries", nargs="+")
     args = ap.parse_args()
     traffic_path = os.path.join(ROOT, "profiles", "das_traffic.json")
@@ -52,6 +53,15 @@ def main():
                            "wide reads; Infinity-Cache hits are counted, so this is an upper bound on DRAM traffic), WRITE_SIZE exact."}
     bound = {"_comment": "PMC evidence per shipping DAS kernel (tools/pmc_das.py, one counter group per rocprofv3 pass).  SQ_ACTIVE_INST_VALU is in "
                          "quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; TA_BUSY_avr is the mean over TA instances."}
+    replaced = set()
+    if args.merge:
+        for target, path in ((traffic, traffic_path), (bound, bound_path)):
+            try:
+                for k, v in json.load(open(path)).items():
+                    if not k.startswith("_"):
+                        target[k] = v
+            except (OSError, ValueError):
+                pass
     for path in args.summaries:
         s = json.load(open(path))
         c = s["counters"]
@@ -86,6 +96,9 @@ def main():
             if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
                 e["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(1.0, c["TCP_TOTAL_CACHE_ACCESSES_sum"])
             e["counters"] = c
+            if args.merge and (key, kernel) not in replaced:
+                bound.setdefault(key, {}).pop(kernel, None)             # first summary of this kernel in this call replaces the old entry
+                replaced.add((key, kernel))
             have = bound.setdefault(key, {}).get(kernel)
             if have is None:
                 bound[key][kernel] = e
