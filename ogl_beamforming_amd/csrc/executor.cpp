@@ -919,7 +919,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 							ok &= HIP_OK(bf_launch_das_staged_tables(&a, &sep, s));
 						} else {
 							BfSeparableArgs again = sep;
-							again.uniform = 0; again.table_stride = 0; again.tables = nullptr;
+							again.uniform = 0; again.table_stride = 0; again.tables = nullptr; again.depth_major &= ~4u;
 							staged = plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, again, false);
 							if (staged) sep = again;
 						}
