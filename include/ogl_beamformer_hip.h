@@ -191,6 +191,7 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
  *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
  *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernel's range-checked loop for every wave
  *   BEAMFORMER_HIP_STAGED_W48        the LDS-staged kernel may use 64 x 16 tiles with a 48-sample window where 32 samples do not hold the tile's delay spread
+ *   BEAMFORMER_HIP_STAGED_WALK=column  the uniform-table form of the LDS-staged kernel walks its tiles depth-major like the others (else: planes in chunks of 32, the two blocks of a CU neighbours along the receive axis)
  *   BEAMFORMER_HIP_STAGED_NOUNIFORM  the LDS-staged kernel keeps its transmit tables in LDS on 64 x 16 tiles too (else: a global table read through scalar loads)
  *   BEAMFORMER_HIP_HERCULES_FRACT    the HERCULES kernel reduces the demodulation phase per pair (v_fract) as before round 2's last pass
  *   BEAMFORMER_HIP_HERCULES_NOPAIRS  the HERCULES kernel gathers from the DAS input itself, not from its {sample, difference} copy

@@ -80,3 +80,18 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
         subprocess.run([compiler, std, "-x", "c" if compiler == "gcc" else "c++", "-I", os.path.join(ROOT, "include"),
                         str(src), "-o", str(exe)], check=True)
         assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """include/ogl_beamformer_hip.h lists the BEAMFORMER_HIP_* variables (measurement and test aids): every getenv in csrc/ is there"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "ogl_beamformer_hip.h")).read()
+    read = set()
+    for path in glob.glob(os.path.join(root, "ogl_beamforming_amd", "csrc", "*")):
+        if path.endswith((".cpp", ".hip", ".h", ".c")):
+            read |= set(re.findall(r'getenv\("(BEAMFORMER_HIP_[A-Z0-9_]+)"\)', open(path, errors="replace").read()))
+    assert read, "no getenv found: the pattern is stale"
+    missing = sorted(v for v in read if v not in header)
+    assert not missing, missing
