@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=4, help="BASELINE.json configs index (1-based)")
+    ap.add_argument("--config", type=str, default="4",
+                    help="BASELINE.json configs index (1-based; 4 = the metric's workload), or harness:{tpw,tpw_swapped,vls,hercules,forces}[:yz] = "
+                         "the frame the reference's own throughput harness beamforms (tests/throughput.c:443-491): then NOT the metric's workload")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU-baseline budget (DAS time summed over its three legs)")
@@ -113,7 +115,10 @@ def main():
         L.beamformer_hip_enable_frame_graphs(1)
 
     # every rank builds the parameter block (cheap, deterministic); only rank 0 owns the RF
-    acq = configs.config(args.config, args.scale)
+    harness = args.config.startswith("harness:")
+    if not harness:
+        args.config = int(args.config)
+    acq = configs.by_name(args.config, args.scale)
     bp = acq.bp
     X, Y, Z = (max(1, v) for v in bp.output_points[:3])
     voxels_total = X * Y * Z
@@ -327,12 +332,14 @@ def main():
         else:
             how = "none"
         out = {
-            "metric": "beamformed voxels/s (and %HBM-roofline), 256-ch 3D DAS 512^3, 1/2/4/8 GPUs",
+            "metric": ("beamformed voxels/s of the reference harness's 512 x 1024 view plane (tests/throughput.c) -- a profile line, not BASELINE's metric" if harness
+                       else "beamformed voxels/s (and %HBM-roofline), 256-ch 3D DAS 512^3, 1/2/4/8 GPUs"),
             "value": value, "unit": "voxels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[{args.config - 1}] ({acq.name}): {P.AcquisitionKind(bp.acquisition_kind).name} "
+                "workload": (f"reference harness frame {args.config} (tests/throughput.c:443-491; NOT the metric's workload)" if harness else f"BASELINE configs[{args.config - 1}]") +
+                            f" ({acq.name}): {P.AcquisitionKind(bp.acquisition_kind).name} "
                             f"{bp.channel_count} ch x {bp.acquisition_count} tx, {P.DataKind(bp.data_kind).name} RF {bp.sample_count} samples"
                             f" -> {' -> '.join(P.ShaderKind(v).name for v in bp.compute_stages[:bp.compute_stages_count])}"
                             f"{' + coherency weighting' if bp.coherency_weighting else ''} -> {X}x{Y}x{Z} "

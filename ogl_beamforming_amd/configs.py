@@ -34,6 +34,27 @@ def das_transform_2d_xz(lo, hi, y_off=0.0):
     return m
 
 
+def das_transform_2d_yz(lo, hi, x_off=0.0):
+    """math.c:844-870, :879-885 (normal (-1, 0, 0)): image x -> world y, image y -> world z."""
+    m = np.zeros(16, np.float32)
+    m[1] = hi[0] - lo[0]          # column 0: U = (0,1,0) * extent
+    m[6] = hi[1] - lo[1]          # column 1: V = cross(U, N) = (0,0,1) * extent
+    m[8] = -1.0                   # column 2: the normal
+    m[12], m[13], m[14], m[15] = -x_off, lo[0], lo[1], 1.0     # t = N * offset + min
+    return m
+
+
+def _voxel_transform(points, lo, hi, plane=None, plane_offset=0.0):
+    """(X, Y, 1) images are view planes with depth on image y (das_transform of math.c:906-922 gives the XZ plane;
+    plane="yz" asks for math.c:879-885's); anything with z planes is a volume."""
+    dims = sum(1 for p in points if p > 1)
+    if dims == 3 or points[2] > 1:
+        return das_transform_3d(lo, hi)
+    if plane == "yz":
+        return das_transform_2d_yz((lo[1], lo[2]), (hi[1], hi[2]), plane_offset)
+    return das_transform_2d_xz((lo[0], lo[2]), (hi[0], hi[2]), plane_offset)
+
+
 def translation(x=0.0, y=0.0, z=0.0):
     m = np.zeros(16, np.float32)
     m[0] = m[5] = m[10] = m[15] = 1.0
@@ -181,17 +202,17 @@ def _rca_delays(bp, point, angles_deg, depths, orient):
 def rca(name, C, A, S, points, lo, hi, *, seed, data_kind=P.DataKind.Int16, interp=P.InterpolationMode.Linear,
         cw=False, f_number=1.0, pitch=0.3e-3, fs=25e6, fd=6.25e6, orientation=0x22, angles=None,
         depths=None, single=False, demodulate=True, kind=P.AcquisitionKind.RCA_TPW, scatterers=None,
-        noise=True, channel_shuffle=False, raw_pad=0, contrast=False):
+        noise=True, channel_shuffle=False, raw_pad=0, contrast=False, stages=None, plane=None, plane_offset=0.0):
     """Row-column / linear array, plane or diverging waves (configs 1, 2, 4)."""
     rng = np.random.default_rng(seed)
-    dims = sum(1 for p in points if p > 1)
-    # (X, Y, 1) images put depth on image y (das_transform_2d_xz); anything with z planes is a volume
-    vt = das_transform_3d(lo, hi) if (dims == 3 or points[2] > 1) else das_transform_2d_xz((lo[0], lo[2]), (hi[0], hi[2]))
+    vt = _voxel_transform(points, lo, hi, plane, plane_offset)
     half = (C - 1) / 2 * pitch
     # world -> transducer: element `ch` sits at transducer x (and y) = ch * pitch
     xt = translation(half, half if (orientation & 0xF) == 1 or ((orientation >> 4) & 0xF) == 1 else 0.0, 0.0)
-    stages = ([P.ShaderKind.Demodulate] if demodulate else [P.ShaderKind.Decode]) + [P.ShaderKind.DAS]
-    bp = _base_parameters(C, A, S, points, kind, data_kind, stages, fs, fd, (pitch, pitch), interp, f_number, cw,
+    if stages is None:
+        stages = ([P.ShaderKind.Demodulate] if demodulate else [P.ShaderKind.Decode]) + [P.ShaderKind.DAS]
+    demodulate = P.ShaderKind.Demodulate in stages
+    bp = _base_parameters(C, A, S, points, kind, data_kind, list(stages), fs, fd, (pitch, pitch), interp, f_number, cw,
                           vt, xt, raw_pad=raw_pad, contrast=1 if contrast else 0)
     if angles is None:
         angles = np.zeros(A) if A == 1 else np.linspace(-15.0, 15.0, A)
@@ -235,11 +256,11 @@ def rca(name, C, A, S, points, lo, hi, *, seed, data_kind=P.DataKind.Int16, inte
 def hercules(name, C, A, S, points, lo, hi, *, seed, data_kind=P.DataKind.Int16, interp=P.InterpolationMode.Linear,
              cw=False, f_number=1.0, pitch=0.3e-3, fs=25e6, fd=6.25e6, orientation=0x12, focal=(0.0, np.inf),
              stages=(P.ShaderKind.Decode, P.ShaderKind.DAS), decode=1, kind=P.AcquisitionKind.HERCULES,
-             sparse=None, filters=None, noise_sigma=None):
+             sparse=None, filters=None, noise_sigma=None, plane=None, plane_offset=0.0):
     """2-D aperture: receive channel along one axis x decoded transmit element along the
     other (configs 3, 5; das.glsl:233-286)."""
     rng = np.random.default_rng(seed)
-    vt = das_transform_3d(lo, hi)
+    vt = _voxel_transform(points, lo, hi, plane, plane_offset)
     xt = translation((C - 1) / 2 * pitch, (A - 1) / 2 * pitch, 0.0)
     bp = _base_parameters(C, A, S, points, kind, data_kind, list(stages), fs, fd, (pitch, pitch), interp, f_number, cw,
                           vt, xt, decode=decode)
@@ -266,9 +287,7 @@ def forces(name, C, A, S, points, lo, hi, *, seed, data_kind=P.DataKind.Int16, i
            stages=(P.ShaderKind.Decode, P.ShaderKind.DAS), decode=1, sparse=None, readi_groups=0, readi_group=0):
     """FORCES / UFORCES / READI (das.glsl:288-366): imaging plane x-z."""
     rng = np.random.default_rng(seed)
-    dims = sum(1 for p in points if p > 1)
-    # (X, Y, 1) images put depth on image y (das_transform_2d_xz); anything with z planes is a volume
-    vt = das_transform_3d(lo, hi) if (dims == 3 or points[2] > 1) else das_transform_2d_xz((lo[0], lo[2]), (hi[0], hi[2]))
+    vt = _voxel_transform(points, lo, hi)
     xt = translation((C - 1) / 2 * pitch, (C - 1) / 2 * pitch, 0.0)
     bp = _base_parameters(C, A, S, points, kind, data_kind, list(stages), fs, fd, (pitch, pitch), interp, f_number, cw,
                           vt, xt, decode=decode)
@@ -347,3 +366,66 @@ def config(n, scale=1.0):
                      "beamformer_hip_frame_min_max -- SURVEY 8d config 5")
         return acq
     raise ValueError(n)
+
+
+# ----------------------------------------------------------------------------- the reference harness's frame
+
+HARNESS_KINDS = ("tpw", "tpw_swapped", "vls", "hercules", "forces")
+
+
+def harness(kind, scale=1.0, plane="xz"):
+    """The frame tests/throughput.c beamforms out of every dataset (`execute_study`, :443-491; globals :20-23): a
+    512 x 1024 view plane (lateral -60..60 mm, axial 10..165 mm, `das_transform` of the harness's (512, 1, 1024) points
+    = the XZ plane, math.c:906-922), cubic interpolation, F# 0.5, decimation 1, {Demodulate, Decode, DAS} with the
+    Kaiser low-pass of :463-473 -- here on synthetic Int16 RF of the size of the lab's row-column datasets: 256
+    channels x 128 transmits x 4096 samples.  20 MHz sampling, 5 MHz centre (4x sampling), 0.25 mm pitch: a
+    64 mm aperture whose recorded range (158 mm at normal incidence) covers the harness's axial extent but for the
+    deepest oblique paths.  `kind`: tpw (plane waves steered along y, received along x), tpw_swapped (steered along x,
+    received along y), vls (diverging waves), hercules (Hadamard-encoded, 2-D aperture), forces.  plane="yz": the
+    other view plane the reference offers (math.c:879-885).  scale < 1 shrinks every count for parity tests."""
+    def s(v, lo=1, mult=1):
+        r = max(lo, int(round(v * scale)))
+        return max(mult, r // mult * mult)
+
+    C, A, S = s(256, 16, 16), s(128, 8), s(4096, 512, 128)
+    A = 1 << int(math.log2(A))
+    points = (s(512, 16), s(1024, 16), 1)
+    lo, hi = (-60e-3, -60e-3, 10e-3), (60e-3, 60e-3, 165e-3)
+    fs, fd, pitch = 20e6, 5e6, 0.25e-3
+    if scale < 1.0:
+        # the same rays through a shorter record: shrink the geometry with the sample count
+        k = S / 4096.0
+        lo, hi = tuple(v * k for v in lo), tuple(v * k for v in hi)
+        pitch *= max(k, 64.0 / C * k)
+    canonical = (P.ShaderKind.Demodulate, P.ShaderKind.Decode, P.ShaderKind.DAS)
+    name = f"harness_{kind}" + ("" if plane == "xz" else f"_{plane}")
+    if kind in ("tpw", "tpw_swapped", "vls"):
+        orientation = 0x21 if kind == "tpw_swapped" else 0x12
+        angles = np.linspace(-18.0, 18.0, A)
+        depths = np.full(A, -40e-3 * (S / 4096.0)) if kind == "vls" else None
+        acq = rca(name, C, A, S, points, lo, hi, seed=71, interp=P.InterpolationMode.Cubic, f_number=0.5, pitch=pitch, fs=fs, fd=fd,
+                  orientation=orientation, angles=angles, depths=depths, stages=canonical, plane=plane,
+                  kind=P.AcquisitionKind.RCA_VLS if kind == "vls" else P.AcquisitionKind.RCA_TPW,
+                  scatterers=[(0.1 * hi[0], 0.0, lo[2] + 0.45 * (hi[2] - lo[2]))] if plane == "xz" else
+                             [(0.0, 0.1 * hi[1], lo[2] + 0.45 * (hi[2] - lo[2]))])
+    elif kind == "hercules":
+        acq = hercules(name, C, A, S, points, lo, hi, seed=72, interp=P.InterpolationMode.Cubic, f_number=0.5, pitch=pitch, fs=fs, fd=fd,
+                       stages=canonical, plane=plane)
+    elif kind == "forces":
+        if plane != "xz":
+            raise ValueError("FORCES images the x-z plane")
+        acq = forces(name, C, A, S, points, lo, hi, seed=73, interp=P.InterpolationMode.Cubic, f_number=0.5, pitch=pitch, fs=fs, fd=fd,
+                     stages=canonical)
+    else:
+        raise ValueError(kind)
+    acq.notes = ("tests/throughput.c:443-491 on synthetic RF: the harness's 512 x 1024 view plane, cubic, F# 0.5, "
+                 "{Demodulate, Decode, DAS}; Decode is dropped by the planner when the acquisition is not encoded (beamformer_core.c:627-629)")
+    return acq
+
+
+def by_name(spec, scale=1.0):
+    """`4` / `"4"`: BASELINE configs (1-based); `"harness:<kind>[:yz]"`: the reference harness's frame."""
+    if isinstance(spec, str) and spec.startswith("harness:"):
+        parts = spec.split(":")
+        return harness(parts[1], scale, parts[2] if len(parts) > 2 else "xz")
+    return config(int(spec), scale)

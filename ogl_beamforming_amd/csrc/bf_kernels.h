@@ -60,6 +60,8 @@ typedef struct {
 	uint32_t depth_major;             /* tile walk: 1 = z fastest (consecutive tiles share a lateral column), 0 = x, y, z */
 	uint32_t zero_offset;             /* factored kernel: byte offset (from rf) of >= 32 zero bytes the host keeps
 	                                     behind the DAS input, the gather target of out-of-range lanes */
+	uint32_t span_stage;              /* factored kernel, IQ + linear / cubic: 1 = wave-span staging (every wave copies the span of
+	                                     each RF row its 64 voxels touch into its own LDS slot by LDS-DMA; coarse grids) */
 } BfDasArgs;
 
 /* tile geometry of the separable-delay fast path (das_separable.hip) */

@@ -25,6 +25,21 @@
  * for any lane of the wave is skipped.  Summation order differs from the shader's (per channel
  * over transmits, then over channels): results agree to float rounding, tests state the
  * tolerance.  Channel split for small frames as in das.hip.
+ *
+ * WAVE-SPAN STAGING (template parameter SPAN, round 3; IQ samples, linear / cubic).  On a COARSE grid -- the
+ * reference harness's own 512 x 1024 view plane has 0.23 mm pixels, 1.5 samples of delay per voxel along x -- the
+ * 64 lanes of a gather instruction land in 64 different places of an RF row: the texture path serves such a wave
+ * in ~25 clocks instead of 16 and a cubic term needs two (rocprofv3: 210 clocks per wave-term per SIMD, VALU 57 %
+ * busy).  But the span a wave touches is short: for one (channel, transmit) row the indices of its 64 voxels lie
+ * within [min R + min T, max R + max T], ~30-100 samples.  So the wave copies that span -- ONE coalesced
+ * 1 KB LDS-DMA load (`buffer_load_dwordx4 ... lds`: 128 samples, no VGPR, no address arithmetic: the row and the
+ * window start are scalars) -- into its own LDS slot and every lane reads its taps from there (4 x ds_read_b64 for
+ * Catmull-Rom).  No block barrier: the slot is the wave's own; the loads of transmit a + 1 are in flight while
+ * transmit a is consumed (two buffers of CH slots, counted s_waitcnt).  The window start is exact, not estimated:
+ * per channel the wave reduces min / max of the receive index over the lanes inside the aperture, per transmit
+ * (once per wave, kept in LDS) the floor of the minimum transmit index; a chunk whose spread does not fit 128
+ * samples takes the gather loop instead, so nothing depends on a host-side bound.  Same arithmetic as the gather
+ * loop: frames are bit-identical (tests/test_gpu_parity.py).
  */
 #include "das_common.h"
 
@@ -60,11 +75,37 @@ __device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx
 	return result;
 }
 
-template <int FAMILY, int INTERP, bool CPLX, bool CW>
+/* wave-wide minimum / maximum as scalars (DPP row shifts: 4 VALU ops + 4 v_readlane, no LDS) */
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)       /* lanes with no source lane keep their own value */
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_extreme(float v)
+{
+	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+	v = pick(v, dpp_f<0x111>(v));      /* row_shr:1 */
+	v = pick(v, dpp_f<0x112>(v));      /* row_shr:2 */
+	v = pick(v, dpp_f<0x114>(v));      /* row_shr:4 */
+	v = pick(v, dpp_f<0x118>(v));      /* row_shr:8: lane 15 of every row of 16 holds the row's extreme */
+	float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+	float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+	float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
+	float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+	return pick(pick(r1, r2), pick(r3, r4));
+}
+
+constexpr uint32_t kSpanSamples = 128;                      /* one LDS-DMA wave instruction: 64 lanes x 16 bytes */
+constexpr uint32_t kSpanSlotBytes = kSpanSamples * 8;
+
+template <int FAMILY, int INTERP, bool CPLX, bool CW, bool SPAN = false>
 __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 {
 	constexpr int      CH = BF_FACTORED_CHUNK(INTERP);
 	constexpr uint32_t ES = CPLX ? 8 : 4;
+	static_assert(!SPAN || (CPLX && INTERP != BF_INTERP_NEAREST), "wave-span staging: linear or cubic interpolation of IQ samples");
+	extern __shared__ __attribute__((aligned(16))) unsigned char factored_lds[];
 
 	/* blockIdx -> tile and thread -> voxel exactly as das.hip */
 	uint32_t total = p.blocks[0] * p.blocks[1] * p.blocks[2];
@@ -94,6 +135,16 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 	uint32_t y = (by << p.tile_shift[1]) + ly;
 	uint32_t zl = (bz << p.tile_shift[2]) + lz;
 	bool inside = x < p.size[0] && y < p.size[1] && zl < p.z_count;
+	[[maybe_unused]] const bool store = inside;
+	if constexpr (SPAN) {
+		/* the LDS-DMA loads and the wave reductions need every lane: lanes outside the grid repeat its last voxel (and
+		 * store nothing); a wave with no voxel at all leaves (SPAN launches have no channel split, hence no barrier) */
+		if (__builtin_amdgcn_ballot_w64(inside) == 0) return;
+		x = x < p.size[0] ? x : p.size[0] - 1u;
+		y = y < p.size[1] ? y : p.size[1] - 1u;
+		zl = zl < p.z_count ? zl : p.z_count - 1u;
+		inside = true;
+	}
 
 	sample_t<CPLX> coherent = zero_sample<CPLX>();
 	float          incoherent = 0.f;
@@ -142,6 +193,54 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		const int ch_begin  = (int)split * per_split;
 		const int ch_end    = ch_begin + per_split < C ? ch_begin + per_split : C;
 
+		/* the transmit part of the sample index of this lane's voxel (RCA: with the time offset; FORCES: das.glsl:312) */
+		/* (the tables are read through the constant address space: with LDS-DMA stores in the loop the compiler can no longer
+		 * prove global memory unchanged and would turn these wave-uniform reads into VECTOR loads -- whose results it then
+		 * waits for with vmcnt(0), draining the DMA queue every transmit) */
+		typedef __attribute__((address_space(4))) const f32x4   const_f32x4;
+		typedef __attribute__((address_space(4))) const int16_t const_i16;
+		const_f32x4 *transmits_c = (const_f32x4 *)(uintptr_t)p.transmits;      /* BfTransmit: {sin, cos, focus x, focus z}, {flags, pad x 3} */
+		const_i16   *sparse_c    = (const_i16 *)(uintptr_t)p.sparse_elements;
+		auto transmit_index = [&](int a) -> float {
+			if constexpr (FAMILY == BF_DAS_RCA) {
+				static_assert(sizeof(BfTransmit) == 32, "two 16-byte scalar loads per transmit");
+				const f32x4 t_lo = transmits_c[2 * a], t_hi = transmits_c[2 * a + 1];
+				BfTransmit t;
+				t.sin_a = t_lo.x; t.cos_a = t_lo.y; t.focus_x = t_lo.z; t.focus_z = t_lo.w;
+				{ const float f = t_hi.x; t.flags = __builtin_bit_cast(uint32_t, f); }
+				return (div_speed_of_sound(transmit_distance(t, wx, wy, wz), p) + p.time_offset) * p.sampling_frequency;
+			} else {
+				float tx_channel = p.sparse ? (float)sparse_c[a - first_transmit] : (float)a;
+				float tdx        = xx - p.pitch[0] * tx_channel;
+				return div_speed_of_sound(hw_sqrt(transmit_yz_squared + tdx * tdx) * p.sampling_frequency, p);
+			}
+		};
+
+		/* SPAN: this wave's LDS -- 64 zero bytes (where invalid taps read), floor(min over the lanes of the transmit index) per
+		 * transmit, two buffers of CH one-KB slots */
+		[[maybe_unused]] uint32_t span_lds = 0, span_tfloor = 0, span_slots = 0;
+		[[maybe_unused]] int span_tspread = 0;
+		[[maybe_unused]] __amdgpu_buffer_rsrc_t rf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.rf), 0, (int)((uint32_t)C * (uint32_t)A * (uint32_t)S * ES), 0x00020000);
+		if constexpr (SPAN) {
+			const uint32_t A_pad = ((uint32_t)A + 15u) & ~15u;
+			const uint32_t per_wave = 64u + 4u * A_pad + 2u * CH * kSpanSlotBytes;
+			span_lds    = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)factored_lds +
+			              (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * per_wave;
+			span_tfloor = span_lds + 64u;
+			span_slots  = span_tfloor + 4u * A_pad;
+			const uint32_t lane = tid & 63u;
+			if (lane < 16u) *(__attribute__((address_space(3))) float *)(uintptr_t)(span_lds + 4u * lane) = 0.f;
+			float spread = 0.f;
+			for (int a = first_transmit; a < A; a++) {
+				const float t  = transmit_index(a);
+				const float lo = __builtin_floorf(wave_extreme<false>(t)), hi = __builtin_floorf(wave_extreme<true>(t));
+				if (lane == 0) *(__attribute__((address_space(3))) int *)(uintptr_t)(span_tfloor + 4u * (uint32_t)a) = (int)lo;
+				spread = fmaxf(spread, hi - lo);
+			}
+			span_tspread = spread < 1.0e6f ? (int)spread : 1000000;       /* (wave uniform; a NaN index never fits) */
+			if (!(spread == spread)) span_tspread = 1000000;
+		}
+
 		for (int c0 = ch_begin; c0 < ch_end; c0 += CH) {
 			ChannelFactor<CPLX, CW> R[CH];
 			bool any = false;
@@ -182,16 +281,105 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			#pragma unroll
 			for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; }
 
-			for (int a = first_transmit; a < A; a++) {
-				float t_index;
-				if constexpr (FAMILY == BF_DAS_RCA) {
-					const BfTransmit t = p.transmits[a];
-					t_index = (div_speed_of_sound(transmit_distance(t, wx, wy, wz), p) + p.time_offset) * p.sampling_frequency;
-				} else {
-					float tx_channel = p.sparse ? (float)p.sparse_elements[a - first_transmit] : (float)a;
-					float tdx        = xx - p.pitch[0] * tx_channel;
-					t_index = div_speed_of_sound(hw_sqrt(transmit_yz_squared + tdx * tdx) * p.sampling_frequency, p);   /* das.glsl:312 */
+			/* ---- wave-span staging: the taps of this chunk come out of the wave's LDS slots */
+			bool span_done = false;
+			if constexpr (SPAN) {
+				int  rfl[CH];
+				bool fits = true;
+				#pragma unroll
+				for (int k = 0; k < CH; k++) {
+					const bool  pass = R[k].index > -1.0e8f;
+					const float lo = wave_extreme<false>(pass ? R[k].index :  __builtin_inff());
+					const float hi = wave_extreme<true >(pass ? R[k].index : -__builtin_inff());
+					const bool  active = lo <= hi;                       /* some lane of the wave is inside this channel's aperture */
+					const float flo = __builtin_floorf(lo);
+					rfl[k] = active ? (int)flo : 0;
+					/* taps floor - 1 .. floor + 2 of every lane inside [window start, + 128): receive spread + the wave's largest
+					 * transmit spread + 6 (two floors, the sum's rounding, the taps) */
+					fits = fits && (!active || (__builtin_floorf(hi) - flo) + (float)span_tspread <= (float)(kSpanSamples - 7));
 				}
+				if (fits && S >= (int)kSpanSamples) {
+					const uint32_t lane16 = (tid & 63u) * 16u;
+					const uint32_t chunk_rows = ((uint32_t)c0 * (uint32_t)A) * (uint32_t)S * ES;
+					int ws[CH], ws_next[CH];
+					auto issue = [&](int a, int buf, int (&ws_out)[CH]) {
+						const int tf = __builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) int *)(uintptr_t)(span_tfloor + 4u * (uint32_t)a));
+						#pragma unroll
+						for (int k = 0; k < CH; k++) {
+							int w = rfl[k] + tf - 2;
+							w = w < 0 ? 0 : (w > S - (int)kSpanSamples ? S - (int)kSpanSamples : w);
+							ws_out[k] = w;
+							/* rows past the last channel lie behind the buffer: the DMA writes zeros, nobody reads them */
+							const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk_rows + ((uint32_t)k * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES + (uint32_t)w * ES));
+							__builtin_amdgcn_raw_ptr_buffer_load_lds(rf_rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)(span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes),
+							                                         16, lane16, soff, 0, 0);
+						}
+					};
+					issue(first_transmit, 0, ws);
+					for (int a = first_transmit; a < A; a++) {
+						const int buf = (a - first_transmit) & 1;
+						const bool more = a + 1 < A;
+						if (more) issue(a + 1, buf ^ 1, ws_next);
+						float t_index = transmit_index(a);
+						asm volatile("" : "+v"(t_index));       /* as in the gather loop: the index is a SUM of two rounded terms, not an fma */
+						const float turns = hw_fract(turns_per_sample * t_index);
+						const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
+						/* the CH loads of transmit a + 1 may stay in flight; everything older has landed */
+						if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory");
+						else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						float frac[CH]; uint32_t at[CH];
+						#pragma unroll
+						for (int k = 0; k < CH; k++) {
+							const float index = t_index + R[k].index;
+							frac[k] = hw_fract(index);
+							const uint32_t ki = (uint32_t)(cvt_floor_i32(index) - (INTERP == BF_INTERP_CUBIC ? 1 : 0));
+							const uint32_t rel = ki - (uint32_t)ws[k];
+							/* valid: 0 <= index < S - 1 (linear), 1 <= index < S - 2 (cubic); inside the staged window by construction
+							 * (the second test only keeps a violated bound from reading a neighbour's slot) */
+							const bool ok = ki < (uint32_t)(INTERP == BF_INTERP_CUBIC ? S - 3 : S - 1) && rel <= kSpanSamples - (INTERP == BF_INTERP_CUBIC ? 4u : 2u);
+							at[k] = ok ? span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes + rel * ES : span_lds;
+						}
+						typedef __attribute__((address_space(3))) f32x2 lds2;
+						if constexpr (INTERP == BF_INTERP_LINEAR) {
+							f32x2 s0[CH], s1[CH];
+							#pragma unroll
+							for (int k = 0; k < CH; k++) { s0[k] = *(lds2 *)(uintptr_t)at[k]; s1[k] = *(lds2 *)(uintptr_t)(at[k] + 8u); }
+							#pragma unroll
+							for (int k = 0; k < CH; k++) {
+								f32x2 sv = s0[k] + frac[k] * (s1[k] - s0[k]);
+								acc1[k] += sv.x * cs;
+								acc2[k] += sv.y * cs;
+								if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
+							}
+						} else {
+							f32x2 q0[CH], q1[CH], q2[CH], q3[CH];
+							#pragma unroll
+							for (int k = 0; k < CH; k++) {
+								q0[k] = *(lds2 *)(uintptr_t)at[k];          q1[k] = *(lds2 *)(uintptr_t)(at[k] + 8u);
+								q2[k] = *(lds2 *)(uintptr_t)(at[k] + 16u);  q3[k] = *(lds2 *)(uintptr_t)(at[k] + 24u);
+							}
+							#pragma unroll
+							for (int k = 0; k < CH; k++) {
+								f32x2 T1 = 0.5f * (q2[k] - q0[k]), T2 = 0.5f * (q3[k] - q1[k]), D = q2[k] - q1[k];
+								f32x2 c3 = (T1 + T2) - 2.0f * D;
+								f32x2 c2 = (D - T1) - c3;
+								float t  = frac[k];
+								f32x2 sv = q1[k] + t * (T1 + t * (c2 + t * c3));
+								acc1[k] += sv.x * cs;
+								acc2[k] += sv.y * cs;
+								if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
+							}
+						}
+						#pragma unroll
+						for (int k = 0; k < CH; k++) ws[k] = ws_next[k];
+					}
+					span_done = true;
+				}
+			}
+
+			for (int a = first_transmit; a < A && !span_done; a++) {
+				float t_index = transmit_index(a);
+				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
 				float tc = 1.f, ts = 0.f;
 				if constexpr (CPLX) {
 					float turns = hw_fract(turns_per_sample * t_index);
@@ -294,7 +482,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 
 	if (p.split_shift) {
 		/* partial sums of waves 1..K-1 go through LDS; wave 0 adds them in split order */
-		extern __shared__ float partial[];                         /* [K-1][3][64] */
+		float *partial = reinterpret_cast<float *>(factored_lds);  /* [K-1][3][64] */
 		const uint32_t lane = tid & 63u;
 		if (split) {
 			float *row = partial + (split - 1) * 192 + lane;
@@ -312,7 +500,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		}
 	}
 
-	if (inside) {
+	if (SPAN ? store : inside) {
 		uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
 		sample_t<CPLX> v = coherent;
 		if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
@@ -327,6 +515,18 @@ hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
 	uint32_t grid    = ((total + 7u) / 8u) * 8u;
 	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
 	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
+	if constexpr (CPLX && INTERP != BF_INTERP_NEAREST) {
+		if (a->span_stage && !a->split_shift) {
+			/* per wave: the zero block, one floor per transmit, two buffers of CH slots */
+			constexpr uint32_t CH = BF_FACTORED_CHUNK(INTERP);
+			const uint32_t per_wave = 64u + 4u * (((uint32_t)a->acquisition_count + 15u) & ~15u) + 2u * CH * kSpanSlotBytes;
+			auto kernel = das_factored_kernel<FAMILY, INTERP, CPLX, CW, true>;
+			hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * per_wave));
+			if (e != hipSuccess) return e;
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 4u * per_wave, s, *a);
+			return hipGetLastError();
+		}
+	}
 	hipLaunchKernelGGL((das_factored_kernel<FAMILY, INTERP, CPLX, CW>), dim3(grid), dim3(threads), lds, s, *a);
 	return hipGetLastError();
 }

@@ -561,7 +561,11 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 	}
 	auto W = [&](int row, int col) { return vox[4 * col + row]; };
 	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
-	auto moves = [&](int row, int col) {      /* does transducer coordinate `row` move with voxel axis `col`? */
+	/* does transducer coordinate `row` move with voxel axis `col`?  An axis of one voxel moves nothing, whatever its
+	 * column of the transform holds: the view planes of math.c:844-885 keep their NORMAL there (das_transform_2d_xz: voxel z
+	 * = (0, 1, 0), size 1), and the reference's own harness beamforms exactly such a plane (tests/throughput.c:20, :443-446) */
+	auto moves = [&](int row, int col) {
+		if (a.size[col] <= 1) return false;
 		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return true;
 		return false;
 	};
@@ -874,6 +878,10 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 			a.split_shift = 0;
 			while (!(c.das_path_mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
 			choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
+			if (const char *force = std::getenv("BEAMFORMER_HIP_TILE_SHAPE")) {     /* EXPERIMENT (round 3): "sx,sy,sz" log2 extents, product 256 */
+				unsigned sx = 0, sy = 0, sz = 0;
+				if (!a.split_shift && std::sscanf(force, "%u,%u,%u", &sx, &sy, &sz) == 3 && sx + sy + sz == 8) { a.tile_shift[0] = sx; a.tile_shift[1] = sy; a.tile_shift[2] = sz; }
+			}
 			for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 			{
 				const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z (measurement aid) */
@@ -954,6 +962,24 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				} else if (factored_applies(a, ps->transmit_table, c.das_path_mode & 0xF)) {
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					a.zero_offset = (uint32_t)used;             /* as for the gather kernel above */
+					/* EXPERIMENT (round 3): wave-span staging */
+					if (std::getenv("BEAMFORMER_HIP_SPAN") && plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && used < (1ull << 32)) {
+						a.span_stage = 1;
+						/* a wave = 64 voxels along the first lateral axis, the block's four waves stacked along depth */
+						uint32_t lat = a.tile_shift[0] >= a.tile_shift[1] ? 0u : 1u;
+						if (a.tile_shift[lat] > 6) {
+							uint32_t spare = a.tile_shift[lat] - 6;
+							a.tile_shift[lat] = 6;
+							for (int k = 0; k < 3 && spare; k++) {
+								if ((uint32_t)k == lat) continue;
+								uint32_t room = ceil_log2(ext[k]) - a.tile_shift[k];
+								uint32_t give = room < spare ? room : spare;
+								a.tile_shift[k] += give; spare -= give;
+							}
+							a.tile_shift[lat] += spare;
+							for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+						}
+					}
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
 					ok &= HIP_OK(bf_launch_das_factored(&a, s));
 					das_path = 3;

@@ -173,3 +173,29 @@ def tolerance(acq):
     f16_staged = base in ("int16", "float16") and (int(S.Demodulate) in stages or int(S.Filter) in stages
                                                    or (int(S.Decode) in stages and acq.bp.decode_mode))
     return 2e-3 if f16_staged else 1e-4
+
+
+# ---- view planes (round 3): the reference's everyday frame is not a volume but a plane through 3-D data -- its throughput
+# harness beamforms a 512 x 1024 XZ plane out of every dataset (tests/throughput.c:20-23, :443-446; das_transform_2d_xz /
+# _yz, math.c:844-885: image y is world depth, image z is the plane's normal, one voxel thick)
+def _plane_cases():
+    c = {}
+    for kind in cfg.HARNESS_KINDS:
+        c[f"harness_{kind}_small"] = (lambda kind=kind: cfg.harness(kind, 0.0625))
+    c["harness_tpw_yz_small"] = lambda: cfg.harness("tpw", 0.0625, "yz")
+    c["harness_hercules_yz_small"] = lambda: cfg.harness("hercules", 0.0625, "yz")
+    # wide enough along image x (>= 32 voxels, no channel split: 7 channels) for the aligned-grid HERCULES kernel to be the
+    # automatic choice on a view plane; the YZ plane puts world y along the lanes: the loop roles swap
+    c["hercules_plane_xz"] = lambda: cfg.hercules(
+        "hercules_plane_xz", 7, 16, 512, (64, 48, 1), LO3, HI3, seed=81, cw=True, f_number=0.7, interp=I.Cubic,
+        stages=(S.Demodulate, S.Decode, S.DAS), plane="xz", plane_offset=0.4e-3)
+    c["hercules_plane_yz"] = lambda: cfg.hercules(
+        "hercules_plane_yz", 7, 16, 512, (64, 40, 1), LO3, HI3, seed=82, cw=True, f_number=0.7,
+        stages=(S.Demodulate, S.Decode, S.DAS), plane="yz", plane_offset=-0.3e-3)
+    c["uhercules_plane_xz_sparse"] = lambda: cfg.hercules(
+        "uhercules_plane_xz_sparse", 6, 8, 512, (56, 33, 1), LO3, HI3, seed=83, kind=K.UHERCULES,
+        sparse=[0, 3, 5, 9, 12, 14, 15], decode=0, data_kind=D.Float32Complex, f_number=0.9, orientation=0x21, plane="xz")
+    return c
+
+
+CASES.update(_plane_cases())

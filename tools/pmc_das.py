@@ -43,7 +43,7 @@ GROUPS = [
 # the geometry-only pair-count instantiation das_kernel<FAMILY, 0, false, false, true> is not the DAS launch
 COUNT_KERNEL = re.compile(r"das_kernel<[^>]*,\s*true>")
 
-KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_hercules.hip", "bf_kernels.h"]
+KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_staged_cubic.hip", "das_hercules.hip", "bf_kernels.h"]
 
 
 def kernel_source_hash():
@@ -63,7 +63,7 @@ def kernel_source_hash():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--config", type=str, default="4")
     ap.add_argument("--planes", type=int, default=0)
     ap.add_argument("--das-path", type=int, default=0)
     ap.add_argument("--out", required=True)
