@@ -182,12 +182,17 @@ typedef enum {
 	BeamformerHipDasPath_HerculesAnyWidth = 6,    /* das_hercules.hip also on grids narrower than 32 voxels */
 	BeamformerHipDasPath_NoChannelSplit   = 0x10, /* flag: general kernel at one thread per voxel for small frames too */
 	BeamformerHipDasPath_DenseDecode      = 0x20, /* flag: Decode on the O(T^2) kernel, not the Walsh-Hadamard form */
+	BeamformerHipDasPath_SpanStaging      = 0x40, /* flag: das_factored.hip's wave-span staging (per-wave LDS-DMA copy of the RF span a wave touches)
+	                                                 wherever the kernel supports it -- automatic only on coarse grids (a voxel step along x of a
+	                                                 sample of delay or more, like the reference harness's view plane) */
+	BeamformerHipDasPath_NoSpanStaging    = 0x80, /* flag: never (the gather loop; the two give bit-identical frames) */
 } BeamformerHipDasPath;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 /* Environment variables the library reads (measurement and test aids; none is needed in production):
  *   BEAMFORMER_HIP_DEVICE            HIP ordinal of the one-device mode (else LOCAL_RANK, else 0)
  *   BEAMFORMER_HIP_FRAME_RING_BYTES  size of the beamformed-frame ring (default 4 GiB)
- *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major
+ *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major (=column: view planes walked depth
+ *                                    fastest instead of in XCD-balanced bands)
  *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
  *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernel's range-checked loop for every wave
  *   BEAMFORMER_HIP_STAGED_W48        the LDS-staged kernel may use 64 x 16 tiles with a 48-sample window where 32 samples do not hold the tile's delay spread

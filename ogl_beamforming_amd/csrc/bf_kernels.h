@@ -57,7 +57,9 @@ typedef struct {
 	uint32_t tile_shift[3];           /* log2 of the block's voxel tile extent per axis (256 voxels, or 64 with a channel split) */
 	uint32_t split_shift;             /* log2 K: K waves of a block share 64 voxels, each summing C/K channels */
 	uint32_t blocks[3];               /* blocks per axis */
-	uint32_t depth_major;             /* tile walk: 1 = z fastest (consecutive tiles share a lateral column), 0 = x, y, z */
+	uint32_t depth_major;             /* tile walk: 1 = z fastest (consecutive tiles share a lateral column), 2 = y fastest (view planes:
+	                                     depth lies along voxel y), 3 = view planes in XCD-balanced bands (bf_plane_walk), 0 = x, y, z */
+	uint32_t band_rows;               /* depth_major == 3: tile rows per band */
 	uint32_t zero_offset;             /* factored kernel: byte offset (from rf) of >= 32 zero bytes the host keeps
 	                                     behind the DAS input, the gather target of out-of-range lanes */
 	uint32_t span_stage;              /* factored kernel, IQ + linear / cubic: 1 = wave-span staging (every wave copies the span of
@@ -95,7 +97,8 @@ typedef struct {
 	uint32_t inner_coord;     /* transducer coordinate of the inner axis: 0 = x, 1 = y */
 	uint32_t inner_is_transmit;   /* inner loop walks decoded transmit elements (else receive channels) */
 	uint32_t tiles[3];        /* 64-voxel x segments, groups of 4 output rows, z planes of the shard */
-	uint32_t depth_major;     /* tile walk: 1 = z fastest, 0 = x, y, z */
+	uint32_t depth_major;     /* tile walk: 1 = z fastest, 2 = y fastest (view planes), 3 = balanced bands (bf_plane_walk), 0 = x, y, z */
+	uint32_t band_rows;       /* depth_major == 3: tile rows per band */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes behind the DAS input */
 	/* The kernel measures squared distances in units of unit_scale2 (a float within 1e-3 of 1) and converts a
 	 * distance to samples with samples_per_unit: the host picks the pair so that samples_per_unit x
@@ -147,6 +150,32 @@ typedef struct {
 	uint32_t channels, transmits;
 	int32_t  in_kind, out_kind;
 } BfFilterArgs;
+
+/* Tile walk of VIEW PLANES (depth_major == 3; depth lies along voxel y, one voxel along z -- math.c:844-885).  The work of a
+ * tile grows with its depth (the f-number test culls shallow voxels), so neither a run of depth rows per XCD (idle XCDs: the
+ * shallow bands finish early) nor a lateral column per XCD (an XCD's tiles in flight span half the RF rows: L2 misses x 3,
+ * measured) will do.  The tile rows are cut into bands of `band_rows`; XCD k (= block id mod 8: consecutive ids land on
+ * consecutive XCDs) takes bands k, 15 - k, 16 + k, 31 - k, ... -- a shallow band with a deep one -- and walks each band x
+ * fastest.  Returns the number of blocks to launch. */
+static inline uint32_t bf_plane_walk_blocks(uint32_t blocks_x, uint32_t blocks_y, uint32_t band_rows)
+{
+	uint32_t bands = (blocks_y + band_rows - 1) / band_rows;
+	uint32_t slots = 2u * ((bands + 15u) / 16u);              /* bands per XCD */
+	return 8u * slots * band_rows * blocks_x;
+}
+#ifdef __HIPCC__
+static __device__ __forceinline__ bool bf_plane_walk(uint32_t block_id, uint32_t blocks_x, uint32_t blocks_y, uint32_t band_rows,
+                                                     uint32_t &bx, uint32_t &by)
+{
+	const uint32_t xcd = block_id & 7u, j = block_id >> 3;
+	const uint32_t per_band = band_rows * blocks_x;
+	const uint32_t slot = j / per_band, r = j - slot * per_band;
+	const uint32_t band = 16u * (slot >> 1) + ((slot & 1u) ? 15u - xcd : xcd);
+	by = band * band_rows + r / blocks_x;
+	bx = r % blocks_x;
+	return by < blocks_y;
+}
+#endif
 
 #ifdef __cplusplus
 extern "C" {

@@ -287,14 +287,24 @@ __global__ __launch_bounds__(BF_DAS_MAX_THREADS) void das_kernel(const BfDasArgs
 	uint32_t bid    = blockIdx.x;
 	uint32_t per    = (total + 7u) / 8u;
 	uint32_t tile   = (bid & 7u) * per + (bid >> 3);
-	if (tile >= total) {
+	if (p.depth_major != 3u && tile >= total) {
 		/* ragged tail: ids whose run is shorter map onto the unassigned remainder */
 		return;
 	}
 	/* depth-major walk: consecutive tiles (in flight together on an XCD) are one lateral column at
 	 * consecutive depths, whose RF windows overlap almost entirely (das_separable.hip) */
 	uint32_t bx, by, bz;
-	if (p.depth_major) {
+	if (p.depth_major == 3u) {
+		bz = 0;
+		if (!bf_plane_walk(bid, p.blocks[0], p.blocks[1], p.band_rows, bx, by)) return;     /* whole block */
+	} else if (p.depth_major == 2u) {
+		/* view planes (depth on voxel y, one voxel along z): y fastest, so that each XCD's run of tiles is a lateral COLUMN
+		 * at every depth -- the work per tile grows with depth (f-number culling), a run of depth ROWS would leave the XCDs
+		 * that hold the shallow rows idle for a fifth of the launch */
+		by = tile % p.blocks[1];
+		bx = (tile / p.blocks[1]) % p.blocks[0];
+		bz = tile / (p.blocks[1] * p.blocks[0]);
+	} else if (p.depth_major) {
 		bz = tile % p.blocks[2];
 		bx = (tile / p.blocks[2]) % p.blocks[0];
 		by = tile / (p.blocks[2] * p.blocks[0]);
@@ -376,7 +386,7 @@ template <int FAMILY, int INTERP, bool CPLX, bool CW, bool COUNT>
 static hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
 {
 	uint32_t total = a->blocks[0] * a->blocks[1] * a->blocks[2];
-	uint32_t grid  = ((total + 7u) / 8u) * 8u;
+	uint32_t grid  = a->depth_major == 3u ? bf_plane_walk_blocks(a->blocks[0], a->blocks[1], a->band_rows) : ((total + 7u) / 8u) * 8u;
 	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
 	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
 	hipLaunchKernelGGL((das_kernel<FAMILY, INTERP, CPLX, CW, COUNT>), dim3(grid), dim3(threads), lds, s, *a);

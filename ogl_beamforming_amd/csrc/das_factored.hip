@@ -49,6 +49,10 @@
 #ifndef BF_FACTORED_CHUNK
 #define BF_FACTORED_CHUNK(interp) ((interp) == BF_INTERP_LINEAR ? 6 : 4)
 #endif
+/* ... and per chunk of the wave-span variant (its loop waits for LDS-DMA and LDS reads, not for gathers: occupancy counts) */
+#ifndef BF_SPAN_CHUNK
+#define BF_SPAN_CHUNK(interp) ((interp) == BF_INTERP_LINEAR ? 6 : 4)
+#endif
 
 namespace {
 
@@ -57,6 +61,7 @@ struct ChannelFactor {
 	float index;           /* receive part of the sample index; -1e9 when the channel fails the f-number test */
 	float re, im;          /* apod * e^{j phi(R)} (CPLX) -- re alone holds apod for real data */
 	float apod;            /* for the incoherent sum */
+	float spare;           /* wave-span staging, unchecked loop: the index with lanes outside the aperture parked inside the window */
 };
 
 /* das.glsl:187-202 with the per-transmit constants precomputed (same as das.hip) */
@@ -102,7 +107,7 @@ constexpr uint32_t kSpanSlotBytes = kSpanSamples * 8;
 template <int FAMILY, int INTERP, bool CPLX, bool CW, bool SPAN = false>
 __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 {
-	constexpr int      CH = BF_FACTORED_CHUNK(INTERP);
+	constexpr int      CH = SPAN ? BF_SPAN_CHUNK(INTERP) : BF_FACTORED_CHUNK(INTERP);
 	constexpr uint32_t ES = CPLX ? 8 : 4;
 	static_assert(!SPAN || (CPLX && INTERP != BF_INTERP_NEAREST), "wave-span staging: linear or cubic interpolation of IQ samples");
 	extern __shared__ __attribute__((aligned(16))) unsigned char factored_lds[];
@@ -112,11 +117,21 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 	uint32_t bid   = blockIdx.x;
 	uint32_t per   = (total + 7u) / 8u;
 	uint32_t tile  = (bid & 7u) * per + (bid >> 3);
-	if (tile >= total) return;
+	if (p.depth_major != 3u && tile >= total) return;
 	/* depth-major walk: consecutive tiles (in flight together on an XCD) are one lateral column at
 	 * consecutive depths, whose RF windows overlap almost entirely (das_separable.hip) */
 	uint32_t bx, by, bz;
-	if (p.depth_major) {
+	if (p.depth_major == 3u) {
+		bz = 0;
+		if (!bf_plane_walk(bid, p.blocks[0], p.blocks[1], p.band_rows, bx, by)) return;     /* whole block */
+	} else if (p.depth_major == 2u) {
+		/* view planes (depth on voxel y, one voxel along z): y fastest, so that each XCD's run of tiles is a lateral COLUMN
+		 * at every depth -- the work per tile grows with depth (f-number culling), a run of depth ROWS would leave the XCDs
+		 * that hold the shallow rows idle for a fifth of the launch */
+		by = tile % p.blocks[1];
+		bx = (tile / p.blocks[1]) % p.blocks[0];
+		bz = tile / (p.blocks[1] * p.blocks[0]);
+	} else if (p.depth_major) {
 		bz = tile % p.blocks[2];
 		bx = (tile / p.blocks[2]) % p.blocks[0];
 		by = tile / (p.blocks[2] * p.blocks[0]);
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		 * transmit, two buffers of CH one-KB slots */
 		[[maybe_unused]] uint32_t span_lds = 0, span_tfloor = 0, span_slots = 0;
 		[[maybe_unused]] int span_tspread = 0;
-		[[maybe_unused]] __amdgpu_buffer_rsrc_t rf_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.rf), 0, (int)((uint32_t)C * (uint32_t)A * (uint32_t)S * ES), 0x00020000);
+		[[maybe_unused]] float span_tlo = 0.f, span_thi = 0.f;       /* extremes of the transmit index over the wave's lanes and all transmits */
 		if constexpr (SPAN) {
 			const uint32_t A_pad = ((uint32_t)A + 15u) & ~15u;
 			const uint32_t per_wave = 64u + 4u * A_pad + 2u * CH * kSpanSlotBytes;
@@ -231,11 +246,14 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			const uint32_t lane = tid & 63u;
 			if (lane < 16u) *(__attribute__((address_space(3))) float *)(uintptr_t)(span_lds + 4u * lane) = 0.f;
 			float spread = 0.f;
+			span_tlo = __builtin_inff(); span_thi = -__builtin_inff();
 			for (int a = first_transmit; a < A; a++) {
 				const float t  = transmit_index(a);
-				const float lo = __builtin_floorf(wave_extreme<false>(t)), hi = __builtin_floorf(wave_extreme<true>(t));
+				const float tmin = wave_extreme<false>(t), tmax = wave_extreme<true>(t);
+				const float lo = __builtin_floorf(tmin), hi = __builtin_floorf(tmax);
 				if (lane == 0) *(__attribute__((address_space(3))) int *)(uintptr_t)(span_tfloor + 4u * (uint32_t)a) = (int)lo;
 				spread = fmaxf(spread, hi - lo);
+				span_tlo = fminf(span_tlo, tmin); span_thi = fmaxf(span_thi, tmax);
 			}
 			span_tspread = spread < 1.0e6f ? (int)spread : 1000000;       /* (wave uniform; a NaN index never fits) */
 			if (!(spread == spread)) span_tspread = 1000000;
@@ -284,62 +302,91 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			/* ---- wave-span staging: the taps of this chunk come out of the wave's LDS slots */
 			bool span_done = false;
 			if constexpr (SPAN) {
-				int  rfl[CH];
-				bool fits = true;
+				int  rfl[CH], rsp[CH];
+				bool fits = true, safe = true;
 				#pragma unroll
 				for (int k = 0; k < CH; k++) {
 					const bool  pass = R[k].index > -1.0e8f;
 					const float lo = wave_extreme<false>(pass ? R[k].index :  __builtin_inff());
 					const float hi = wave_extreme<true >(pass ? R[k].index : -__builtin_inff());
-					const bool  active = lo <= hi;                       /* some lane of the wave is inside this channel's aperture */
+					const bool  on = lo <= hi;                           /* some lane of the wave is inside this channel's aperture */
 					const float flo = __builtin_floorf(lo);
-					rfl[k] = active ? (int)flo : 0;
+					rfl[k] = on ? (int)flo : 0;
+					rsp[k] = on ? (int)(__builtin_floorf(hi) - flo) : 0;
 					/* taps floor - 1 .. floor + 2 of every lane inside [window start, + 128): receive spread + the wave's largest
 					 * transmit spread + 6 (two floors, the sum's rounding, the taps) */
-					fits = fits && (!active || (__builtin_floorf(hi) - flo) + (float)span_tspread <= (float)(kSpanSamples - 7));
+					fits = fits && (!on || (__builtin_floorf(hi) - flo) + (float)span_tspread <= (float)(kSpanSamples - 7));
+					/* no lane inside the aperture can leave the RF row for any transmit (one sample of margin for the sum's rounding):
+					 * the loop then runs without the range test of sample_rf, and lanes OUTSIDE the aperture -- their weight is zero
+					 * and stays zero -- take the index of one inside it instead of being steered to the zero block */
+					safe = safe && on && lo + span_tlo >= (INTERP == BF_INTERP_CUBIC ? 2.0f : 1.0f) &&
+					       hi + span_thi < (float)(S - (INTERP == BF_INTERP_CUBIC ? 3 : 2));      /* (a chunk with a channel NO lane uses: checked loop) */
+					if (on && !pass) R[k].spare = lo;
+					else             R[k].spare = R[k].index;
 				}
 				if (fits && S >= (int)kSpanSamples) {
 					const uint32_t lane16 = (tid & 63u) * 16u;
-					const uint32_t chunk_rows = ((uint32_t)c0 * (uint32_t)A) * (uint32_t)S * ES;
+					const uint32_t chunk_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)c0 * (uint32_t)A) * (uint32_t)S * ES));
 					int ws[CH], ws_next[CH];
+					/* lanes that load: 2 samples each.  The unchecked loop needs exactly [window start, + spread + taps): lanes beyond it are
+					 * switched off for the load (the texture path charges a wave's LDS-DMA by its bytes), and its window is not clamped into the
+					 * row -- what it may hold of a neighbouring row is never read.  The checked loop loads all 128 samples of a clamped window. */
+					unsigned long long lanes_on[CH];
+					#pragma unroll
+					for (int k = 0; k < CH; k++) {
+						int need = safe ? (rsp[k] + span_tspread + 8) / 2 : 64;
+						need = need < 1 ? 1 : (need > 64 ? 64 : need);
+						lanes_on[k] = need >= 64 ? ~0ull : ((1ull << need) - 1ull);
+					}
+					typedef int i32x4 __attribute__((ext_vector_type(4)));
+					/* buffer resource over the whole DAS input, by hand for the asm statement: base, stride 0, bytes, raw 32-bit data format */
+					const uint64_t rf_address = (uint64_t)(uintptr_t)p.rf;
+					const i32x4 rsrc_words = {__builtin_amdgcn_readfirstlane((int)(uint32_t)rf_address), __builtin_amdgcn_readfirstlane((int)((uint32_t)(rf_address >> 32) & 0xffffu)),
+					                          __builtin_amdgcn_readfirstlane((int)((uint32_t)C * (uint32_t)A * (uint32_t)S * ES)), 0x00020000};
 					auto issue = [&](int a, int buf, int (&ws_out)[CH]) {
 						const int tf = __builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) int *)(uintptr_t)(span_tfloor + 4u * (uint32_t)a));
 						#pragma unroll
 						for (int k = 0; k < CH; k++) {
 							int w = rfl[k] + tf - 2;
-							w = w < 0 ? 0 : (w > S - (int)kSpanSamples ? S - (int)kSpanSamples : w);
+							if (!safe) w = w < 0 ? 0 : (w > S - (int)kSpanSamples ? S - (int)kSpanSamples : w);
 							ws_out[k] = w;
-							/* rows past the last channel lie behind the buffer: the DMA writes zeros, nobody reads them */
-							const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(chunk_rows + ((uint32_t)k * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES + (uint32_t)w * ES));
-							__builtin_amdgcn_raw_ptr_buffer_load_lds(rf_rsrc, (__attribute__((address_space(3))) void *)(uintptr_t)(span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes),
-							                                         16, lane16, soff, 0, 0);
+							/* rows past the last channel lie behind the buffer: the DMA writes zeros, nobody reads them (a channel no lane
+							 * of the wave uses is loaded all the same: the counted wait below wants CH loads per transmit) */
+							const uint32_t soff = chunk_rows + ((uint32_t)k * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES + (uint32_t)w * ES;
+							const uint32_t dst  = span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes;
+							uint32_t keep_m0;
+							/* M0 = LDS address of the slot; EXEC = the lanes that load; both restored (the kernel runs with every lane on here) */
+							asm volatile("s_mov_b32 %0, m0\n\t"
+							             "s_mov_b32 m0, %1\n\t"
+							             "s_mov_b64 exec, %2\n\t"
+							             "s_nop 0\n\t"
+							             "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
+							             "s_mov_b64 exec, -1\n\t"
+							             "s_mov_b32 m0, %0"
+							             : "=&s"(keep_m0) : "s"(dst), "s"(lanes_on[k]), "v"(lane16), "s"(rsrc_words), "s"(soff) : "memory");
 						}
 					};
-					issue(first_transmit, 0, ws);
-					for (int a = first_transmit; a < A; a++) {
-						const int buf = (a - first_transmit) & 1;
-						const bool more = a + 1 < A;
-						if (more) issue(a + 1, buf ^ 1, ws_next);
-						float t_index = transmit_index(a);
-						asm volatile("" : "+v"(t_index));       /* as in the gather loop: the index is a SUM of two rounded terms, not an fma */
-						const float turns = hw_fract(turns_per_sample * t_index);
-						const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
-						/* the CH loads of transmit a + 1 may stay in flight; everything older has landed */
-						if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory");
-						else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					typedef __attribute__((address_space(3))) f32x2 lds2;
+					auto consume = [&](auto checked, int buf, float t_index, f32x2 cs) {
+						constexpr bool CHECK = decltype(checked)::value;
 						float frac[CH]; uint32_t at[CH];
 						#pragma unroll
 						for (int k = 0; k < CH; k++) {
-							const float index = t_index + R[k].index;
+							const float index = t_index + (CHECK ? R[k].index : R[k].spare);
 							frac[k] = hw_fract(index);
 							const uint32_t ki = (uint32_t)(cvt_floor_i32(index) - (INTERP == BF_INTERP_CUBIC ? 1 : 0));
-							const uint32_t rel = ki - (uint32_t)ws[k];
-							/* valid: 0 <= index < S - 1 (linear), 1 <= index < S - 2 (cubic); inside the staged window by construction
-							 * (the second test only keeps a violated bound from reading a neighbour's slot) */
-							const bool ok = ki < (uint32_t)(INTERP == BF_INTERP_CUBIC ? S - 3 : S - 1) && rel <= kSpanSamples - (INTERP == BF_INTERP_CUBIC ? 4u : 2u);
-							at[k] = ok ? span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes + rel * ES : span_lds;
+							const uint32_t slot = span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes;
+							if constexpr (CHECK) {
+								/* valid: 0 <= index < S - 1 (linear), 1 <= index < S - 2 (cubic); inside the staged window by construction
+								 * (the second test only keeps a violated bound from reading a neighbour's slot) */
+								const uint32_t rel = ki - (uint32_t)ws[k];
+								const bool ok = ki < (uint32_t)(INTERP == BF_INTERP_CUBIC ? S - 3 : S - 1) && rel <= kSpanSamples - (INTERP == BF_INTERP_CUBIC ? 4u : 2u);
+								at[k] = ok ? slot + rel * ES : span_lds;
+							} else {
+								at[k] = (ki << 3) + (slot - (uint32_t)ws[k] * ES);   /* one v_lshl_add_u32: the bracket is a scalar */
+							}
 						}
-						typedef __attribute__((address_space(3))) f32x2 lds2;
+						/* every read of the batch is issued before the first is consumed */
 						if constexpr (INTERP == BF_INTERP_LINEAR) {
 							f32x2 s0[CH], s1[CH];
 							#pragma unroll
@@ -370,6 +417,21 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 								if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
 							}
 						}
+					};
+					issue(first_transmit, 0, ws);
+					for (int a = first_transmit; a < A; a++) {
+						const int buf = (a - first_transmit) & 1;
+						const bool more = a + 1 < A;
+						if (more) issue(a + 1, buf ^ 1, ws_next);
+						float t_index = transmit_index(a);
+						asm volatile("" : "+v"(t_index));       /* as in the gather loop: the index is a SUM of two rounded terms, not an fma */
+						const float turns = hw_fract(turns_per_sample * t_index);
+						const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
+						/* the CH loads of transmit a + 1 may stay in flight; everything older has landed */
+						if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory");
+						else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						if (safe) consume(std::false_type{}, buf, t_index, cs);
+						else      consume(std::true_type{},  buf, t_index, cs);
 						#pragma unroll
 						for (int k = 0; k < CH; k++) ws[k] = ws_next[k];
 					}
@@ -512,13 +574,13 @@ template <int FAMILY, int INTERP, bool CPLX, bool CW>
 hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
 {
 	uint32_t total   = a->blocks[0] * a->blocks[1] * a->blocks[2];
-	uint32_t grid    = ((total + 7u) / 8u) * 8u;
+	uint32_t grid    = a->depth_major == 3u ? bf_plane_walk_blocks(a->blocks[0], a->blocks[1], a->band_rows) : ((total + 7u) / 8u) * 8u;
 	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
 	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
 	if constexpr (CPLX && INTERP != BF_INTERP_NEAREST) {
 		if (a->span_stage && !a->split_shift) {
 			/* per wave: the zero block, one floor per transmit, two buffers of CH slots */
-			constexpr uint32_t CH = BF_FACTORED_CHUNK(INTERP);
+			constexpr uint32_t CH = BF_SPAN_CHUNK(INTERP);
 			const uint32_t per_wave = 64u + 4u * (((uint32_t)a->acquisition_count + 15u) & ~15u) + 2u * CH * kSpanSlotBytes;
 			auto kernel = das_factored_kernel<FAMILY, INTERP, CPLX, CW, true>;
 			hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * per_wave));

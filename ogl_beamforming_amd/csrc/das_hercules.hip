@@ -185,11 +185,18 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	const uint32_t total = q.tiles[0] * q.tiles[1] * q.tiles[2];
 	const uint32_t per   = (total + 7u) / 8u;
 	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-	if (tile >= total) return;
+	if (q.depth_major != 3u && tile >= total) return;
 	/* depth-major walk (as das_separable.hip): the tiles an XCD has in flight together are one lateral
 	 * column at consecutive depths, whose RF windows overlap almost entirely */
 	uint32_t zl, tx_, ty_;
-	if (q.depth_major) {
+	if (q.depth_major == 3u) {                /* view planes in XCD-balanced bands (bf_kernels.h) */
+		zl = 0;
+		if (!bf_plane_walk(blockIdx.x, q.tiles[0], q.tiles[1], q.band_rows, tx_, ty_)) return;
+	} else if (q.depth_major == 2u) {                /* view planes: rows (= depth) fastest, an XCD's run is a lateral column (das.hip) */
+		ty_ = tile % q.tiles[1];
+		tx_ = (tile / q.tiles[1]) % q.tiles[0];
+		zl  = tile / (q.tiles[1] * q.tiles[0]);
+	} else if (q.depth_major) {
 		zl  = tile % q.tiles[2];
 		tx_ = (tile / q.tiles[2]) % q.tiles[0];
 		ty_ = tile / (q.tiles[2] * q.tiles[0]);
@@ -427,7 +434,7 @@ static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipSt
 			                   (const f32x2 *)a->rf, (f32x4 *)q->pairs, total, (uint32_t)a->sample_count);
 	}
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
-	uint32_t grid  = ((total + 7u) / 8u) * 8u;
+	uint32_t grid  = q->depth_major == 3u ? bf_plane_walk_blocks(q->tiles[0], q->tiles[1], q->band_rows) : ((total + 7u) / 8u) * 8u;
 	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD>), dim3(grid), dim3(256), 0, s, *a, *q);
 	return hipGetLastError();
 }

@@ -319,7 +319,7 @@ static uint32_t ceil_log2(uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s+
  * depth changes fastest gets extent 1: sample indices move ~2 samples per voxel along depth
  * but only a fraction of a sample per voxel laterally, so a depth-flat tile keeps the 64 lanes
  * of a wave within a few cache lines of every (channel, transmit) row. */
-static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3], uint32_t tile_log2 = 8)
+static int choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3], uint32_t tile_log2 = 8)
 {
 	uint32_t extent[3] = {size[0], size[1], zcount};
 	uint32_t full[3]   = {size[0], size[1], size[2]};
@@ -349,6 +349,31 @@ static void choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint3
 		shift[depth] = give; left -= give;
 	}
 	shift[0] += left;   /* fewer voxels in total than the tile: idle lanes */
+	return depth;
+}
+
+/* tile walk of the kernels that deal tiles to the XCDs in contiguous runs: the depth axis runs fastest, so that a run is a
+ * lateral column at every depth (neighbouring RF windows AND the same work on every XCD: the f-number test culls shallow
+ * voxels).  Volumes: depth = voxel z (1); the reference's view planes (math.c:844-885) put it on voxel y (2). */
+static uint32_t tile_walk(int depth_axis, uint32_t zcount, uint32_t tile_rows, uint32_t &band_rows)
+{
+	band_rows = 1;
+	const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z, "column": y fastest on view planes (measurement aids) */
+	if (walk && walk[0] == 'p') return 0u;
+	if (depth_axis != 1) return 1u;
+	if (zcount != 1 || (walk && walk[0] == 'c')) return 2u;
+	/* view plane: ~32 bands, four per XCD (bf_plane_walk) */
+	band_rows = tile_rows / 32u ? tile_rows / 32u : 1u;
+	return 3u;
+}
+
+/* Samples of delay one voxel step along x (the lane axis of the per-voxel kernels) can move a sample index: the physical
+ * length of the step times fs / c.  >= 1: a COARSE grid -- neighbouring lanes read different samples of an RF row. */
+static float lane_step_samples(const float *voxel_to_xdc, const BfDasArgs &a)
+{
+	const float n = (float)(a.size[0] > 1 ? a.size[0] - 1 : 1);
+	const float dx = voxel_to_xdc[0] / n, dy = voxel_to_xdc[1] / n, dz = voxel_to_xdc[2] / n;
+	return std::sqrt(dx * dx + dy * dy + dz * dz) * a.sampling_frequency * a.inv_speed_of_sound;
 }
 
 /* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
@@ -588,8 +613,19 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 	q.tiles[0] = (a.size[0] + 63u) / 64u;
 	q.tiles[1] = (a.size[1] + 3u) / 4u;
 	q.tiles[2] = zcount;
-	const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z (measurement aid) */
-	q.depth_major = !(walk && walk[0] == 'p');
+	{
+		/* the axis along which the transducer-space depth changes fastest (as choose_tile finds it) */
+		float m[16];
+		m4_mul(xdc, vox, m);
+		const uint32_t ext[3] = {a.size[0], a.size[1], zcount};
+		int depth = 2; float best = -1.f;
+		for (int i = 0; i < 3; i++) {
+			if (ext[i] <= 1) continue;
+			float step = std::fabs(m[4 * i + 2]) / (float)(a.size[i] > 1 ? a.size[i] - 1 : 1);
+			if (step > best) { best = step; depth = i; }
+		}
+		q.depth_major = tile_walk(depth, zcount, q.tiles[1], q.band_rows);
+	}
 	/* unit of length: among the 8193 floats nearest 1, the s2 whose k' = float(k / sqrt(s2)) reproduces
 	 * k = fs / c best as k' sqrt(s2) (errors are spread over +-3e-8, the best of 8193 lands near 1e-11).
 	 * Remembered per (fs, c): frames of one plan ask again every launch. */
@@ -877,16 +913,9 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 			uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
 			a.split_shift = 0;
 			while (!(c.das_path_mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
-			choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
-			if (const char *force = std::getenv("BEAMFORMER_HIP_TILE_SHAPE")) {     /* EXPERIMENT (round 3): "sx,sy,sz" log2 extents, product 256 */
-				unsigned sx = 0, sy = 0, sz = 0;
-				if (!a.split_shift && std::sscanf(force, "%u,%u,%u", &sx, &sy, &sz) == 3 && sx + sy + sz == 8) { a.tile_shift[0] = sx; a.tile_shift[1] = sy; a.tile_shift[2] = sz; }
-			}
+			const int depth_axis = choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
 			for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
-			{
-				const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z (measurement aid) */
-				a.depth_major = !(walk && walk[0] == 'p');
-			}
+			a.depth_major = tile_walk(depth_axis, zcount, a.blocks[1], a.band_rows);
 
 			if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
@@ -950,7 +979,11 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					 * offsets: under 4 GiB), built by the launcher; BEAMFORMER_HIP_HERCULES_NOPAIRS: measurement aid */
 					hq.pairs = nullptr;
 					const uint64_t prepared = used * (a.interpolation == 2 ? 4u : 2u);      /* cubic: four coefficients per sample, 32 bytes */
+					/* (not on coarse grids: the copy is 2-4 x the RF, and where every lane reads its own cache line the memory system
+					 * pays for the bytes -- the harness's view plane with cubic polynomials: 28.1 ms, 158 GB from beyond L2 per frame;
+					 * with the taps gathered from the RF itself 25.2 ms) */
 					if (plan.iq_pipeline && (a.interpolation == 1 || a.interpolation == 2) && prepared + 64 < (1ull << 32) &&
+					    lane_step_samples(to_xdc, a) < 1.0f &&
 					    !std::getenv("BEAMFORMER_HIP_HERCULES_NOPAIRS") && d.hercules_pairs.ensure(prepared + 64)) {
 						hq.pairs = d.hercules_pairs.ptr;
 						hq.zero_offset = (uint32_t)prepared;
@@ -962,8 +995,13 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				} else if (factored_applies(a, ps->transmit_table, c.das_path_mode & 0xF)) {
 					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
 					a.zero_offset = (uint32_t)used;             /* as for the gather kernel above */
-					/* EXPERIMENT (round 3): wave-span staging */
-					if (std::getenv("BEAMFORMER_HIP_SPAN") && plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && used < (1ull << 32)) {
+					/* wave-span staging (das_factored.hip): on COARSE grids -- a voxel step along x of a sample of delay or more, as the
+					 * reference harness's 0.23 mm pixels have (tests/throughput.c:20-23) -- the lanes of a gather land in 64 different
+					 * places and the per-wave LDS-DMA copy of the span is cheaper (harness frames: 0.90-0.93 of the gather loop's time;
+					 * on config 2's fine grid 1.13: not taken there).  das path bit 0x40 forces it wherever the kernel supports it, 0x80
+					 * keeps the gather loop (tests: the two frames are bit-identical). */
+					const bool span_ok = plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && used < (1ull << 32);
+					if (span_ok && !(c.das_path_mode & 0x80) && ((c.das_path_mode & 0x40) || lane_step_samples(to_xdc, a) >= 1.0f)) {
 						a.span_stage = 1;
 						/* a wave = 64 voxels along the first lateral axis, the block's four waves stacked along depth */
 						uint32_t lat = a.tile_shift[0] >= a.tile_shift[1] ? 0u : 1u;
@@ -978,6 +1016,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 							}
 							a.tile_shift[lat] += spare;
 							for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+							a.depth_major = tile_walk(depth_axis, zcount, a.blocks[1], a.band_rows);
 						}
 					}
 					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));

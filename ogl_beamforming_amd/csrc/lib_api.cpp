@@ -12,6 +12,7 @@
  * (the reference's "server unreachable") when there is none.
  */
 #include "context.h"
+#include <cstdlib>
 #include <cstring>
 
 using namespace bf;
@@ -416,6 +417,21 @@ uint32_t beamformer_hip_set_stream(void *hip_stream)
 	/* a stream belongs to one device: with several devices the library keeps to its own streams */
 	if (!check(beamformer_hip_get_device_count() == 1 || hip_stream == nullptr, BeamformerLibErrorKind_InvalidAccess)) return 0;
 	Device &d = c.devices[0];
+	if (hip_stream) {
+		/* a stream of another device would have every kernel of the library enqueued against buffers it cannot reach: refuse it.
+		 * The device the library runs on: the one in use, else the one asked for, else what ensure_device will pick. */
+		int wanted = c.device_ready ? d.device : (c.requested_count ? c.requested_devices[0] : -1);
+		if (wanted < 0) {
+			const char *e = std::getenv("BEAMFORMER_HIP_DEVICE");
+			if (!e) e = std::getenv("LOCAL_RANK");
+			wanted = e ? std::atoi(e) : 0;
+		}
+		int owner = -1;
+		if (!check(hipStreamGetDevice((hipStream_t)hip_stream, &owner) == hipSuccess && owner == wanted, BeamformerLibErrorKind_InvalidAccess)) {
+			(void)hipGetLastError();
+			return 0;
+		}
+	}
 	if (c.device_ready && d.stream) (void)hipStreamSynchronize(d.stream);   /* keep frames ordered across the switch */
 	d.stream = hip_stream ? (hipStream_t)hip_stream : d.own_stream;
 	return 1;

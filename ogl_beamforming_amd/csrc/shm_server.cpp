@@ -226,7 +226,7 @@ void handle_upload(Server &s, uint64_t rf_block_rf_size)
 	/* the slot about to be overwritten was read in place by the frame three uploads ago, which the
 	 * library runs asynchronously: wait for exactly that frame */
 	if (s.read_pending[slot]) { (void)hipEventSynchronize(s.read_done[slot]); s.read_pending[slot] = false; }
-	if (s.multi_device) beamformer_hip_synchronize();       /* no per-slot events without a stream of ours */
+	if (s.multi_device || !s.stream) beamformer_hip_synchronize();       /* no per-slot events without a stream of ours */
 	if (ok) ok = hipMemcpy(s.rf_ring[slot], s.payload(), size, hipMemcpyHostToDevice) == hipSuccess;
 	s.rf_active_size = size;
 	s.rf_block = block;
@@ -342,9 +342,12 @@ int main(int argc, char **argv)
 		/* a stream belongs to one device: the library keeps its own streams, and an RF slot is reused only
 		 * after beamformer_hip_synchronize (handle_upload) */
 		s.stream = nullptr;
-	} else if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess) {
-		beamformer_hip_set_stream(s.stream);
-		for (auto &e : s.read_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+	} else if (hipSetDevice(beamformer_hip_get_device() >= 0 ? beamformer_hip_get_device() : 0) == hipSuccess &&
+	           hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess) {
+		/* (the stream, the events and the RF slots of this process live on the ONE device the library was told to use --
+		 * `--devices 3` -- not on device 0; the library refuses a stream of another device) */
+		if (!beamformer_hip_set_stream(s.stream)) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
+		for (auto &e : s.read_done) if (!s.stream || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
 	} else {
 		s.stream = nullptr;
 	}

@@ -391,3 +391,29 @@ def test_pair_count_matches_oracle(bflib, oracle):
         finally:
             lib.beamformer_hip_enable_pair_counting(0)
         assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs), (name, int(t.das_pairs), pairs)
+
+
+SPAN = sorted(n for n in FACTORED
+              if cases.make(n).bp.interpolation_mode != int(P.InterpolationMode.Nearest))
+
+
+@pytest.mark.parametrize("name", SPAN)
+def test_factored_kernel_wave_span_staging(name, bflib, oracle):
+    """das_factored.hip with wave-span staging (flag 0x40: every wave copies the span of each RF row its 64 voxels touch into
+    its own LDS slot by LDS-DMA; automatic on coarse grids only) against the oracle AND bit-for-bit against the same kernel's
+    gather loop (flag 0x80): the two share every arithmetic step.  Real-sample pipelines, rows shorter than a span and frames
+    the kernel does not take keep the gather loop under either flag."""
+    acq = cases.make(name)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    try:
+        lib.beamformer_hip_set_das_path(0x14 | 0x40)
+        span = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
+        assert last_das_path(bflib) == 3
+        lib.beamformer_hip_set_das_path(0x14 | 0x80)
+        gather = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
+        assert last_das_path(bflib) == 3
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(span, ref, acq, flags)
+    assert np.array_equal(span.view(np.uint32), gather.view(np.uint32)), "wave-span staging and the gather loop differ"
