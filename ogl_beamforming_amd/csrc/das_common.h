@@ -51,6 +51,13 @@ __device__ __forceinline__ float div_speed_of_sound(float distance, const BfDasA
 	return __builtin_fmaf(e, p.inv_speed_of_sound, q);
 }
 
+__device__ __forceinline__ float div_speed_of_sound(float distance, float inv_speed_of_sound, float speed_of_sound)
+{
+	float q = distance * inv_speed_of_sound;
+	float e = __builtin_fmaf(-q, speed_of_sound, distance);
+	return __builtin_fmaf(e, inv_speed_of_sound, q);
+}
+
 /* (int)floor(x) in one instruction (hipcc emits v_floor_f32 + v_cvt_i32_f32) */
 __device__ __forceinline__ int cvt_floor_i32(float x)
 {
@@ -79,7 +86,8 @@ __device__ __forceinline__ T gather(const char *rf, uint32_t byte_offset)
 	return *reinterpret_cast<const T *>(rf + byte_offset);
 }
 
-__device__ __forceinline__ void m4_point(const float *m, float x, float y, float z, float &ox, float &oy, float &oz)
+template <typename M>      /* const float * in any address space */
+__device__ __forceinline__ void m4_point(M m, float x, float y, float z, float &ox, float &oy, float &oz)
 {
 	ox = m[0] * x + m[4] * y + m[8]  * z + m[12];
 	oy = m[1] * x + m[5] * y + m[9]  * z + m[13];

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const float phase_k = p.demodulation_frequency * p.inv_sampling_frequency;
 	const BfTransmit t0 = p.transmits[0];
 	const bool  rx_rows = (t0.flags & BF_RX_ROWS) != 0;
-	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
+	[[maybe_unused]] const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
 
 	/* UNI: the tile's slice of the global table: [A4] floors, {lo, hi} of the absolute delays, then per lateral row of the tile and
@@ -217,12 +217,22 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	}
 	__syncthreads();                                         /* the floors are read below */
 
-	uint32_t lu, lv;
-	if (u_axis == 0) { lu = tid & (U - 1); lv = tid >> q.u_shift; }
-	else             { lv = tid & (V - 1); lu = tid >> VS; }
-	const uint32_t gu = tu * U + lu, gv = tv * V + lv;
-	const uint32_t x = u_axis == 0 ? gu : gv, y = u_axis == 0 ? gv : gu;
-	const bool inside = x < p.size[0] && y < p.size[1];
+	/* the lane's voxel: needed for `inside` here and for the store at the very end -- recomputed there rather than held in two
+	 * vector registers across the channel loop (the NL = 4 instances had none to spare) */
+	auto voxel_of = [&](uint32_t thread, uint32_t &vx, uint32_t &vy, uint32_t &lane_u) {
+		uint32_t lv_;
+		if (u_axis == 0) { lane_u = thread & (U - 1); lv_ = thread >> q.u_shift; }
+		else             { lv_ = thread & (V - 1); lane_u = thread >> VS; }
+		const uint32_t gu = tu * U + lane_u, gv = tv * V + lv_;
+		vx = u_axis == 0 ? gu : gv; vy = u_axis == 0 ? gv : gu;
+	};
+	uint32_t lu;
+	bool inside;
+	{
+		uint32_t x0, y0;
+		voxel_of(tid, x0, y0, lu);
+		inside = x0 < p.size[0] && y0 < p.size[1];
+	}
 
 	f32x2 coherent   = {0.f, 0.f};
 	float incoherent = 0.f;
@@ -299,32 +309,50 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 		}
 	};
 
+	/* The receive table is rebuilt once per chunk of channels from ~50 scalars of the launch arguments (two 4 x 4 transforms, pitch,
+	 * f-number, speed of sound, ...).  Held in SGPRs across the channel loop they cost this kernel 140 scalar spills (v_writelane /
+	 * v_readlane into two of its 64 VGPRs, which in turn pushed 5 vector registers to scratch: 3.4 GiB written per 1 GiB frame).  They are
+	 * read from the kernel-argument segment instead, through a pointer the compiler cannot see through, at the top of every chunk: a
+	 * few s_load per 16 channels, dead again before the channel loop. */
+	typedef __attribute__((address_space(4))) const BfDasArgs const_args;
+	const_args *kernel_args = (const_args *)__builtin_amdgcn_kernarg_segment_ptr();
+	static_assert(__builtin_offsetof(BfDasArgs, xdc_transform) == 0, "BfDasArgs is the kernel's first argument: it sits at offset 0 of the segment");
 	for (int c0 = 0; c0 < C; c0 += chunk) {
 		const int cn = (C - c0) < chunk ? (C - c0) : chunk;
 		__syncthreads();        /* readers of the previous chunk's R / stage are done; the transmit tables are complete */
+		{
+		const_args *ka = kernel_args;
+		asm volatile("" : "+s"(ka));
+		const uint32_t k_size[3] = {ka->size[0], ka->size[1], ka->size[2]};
+		const float k_denom_u = fmaxf(1.0f, (float)k_size[u_axis] - 1.0f);
+		const float k_pz = (float)z / fmaxf(1.0f, (float)k_size[2] - 1.0f);
+		const float k_fs = ka->sampling_frequency, k_inv_c = ka->inv_speed_of_sound, k_c = ka->speed_of_sound, k_fnum = ka->f_number;
+		const float k_phase = ka->demodulation_frequency * ka->inv_sampling_frequency;
+		const float k_pitch = rx_rows ? ka->pitch[1] : ka->pitch[0];
 		for (uint32_t e = tid; e < (uint32_t)cn * U; e += nthreads) {
 			uint32_t c = (uint32_t)c0 + (e >> q.u_shift), iu = e & (U - 1);
-			float coord[3] = {0.f, 0.f, pz};
-			coord[u_axis] = (float)(tu * U + iu) / denom[u_axis];
+			float coord[3] = {0.f, 0.f, k_pz};
+			coord[u_axis] = (float)(tu * U + iu) / k_denom_u;
 			float wx, wy, wz, xx, xy, xz;
-			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
-			m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+			m4_point(ka->voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			m4_point(ka->xdc_transform, wx, wy, wz, xx, xy, xz);
 			float lateral = rx_rows ? xy : xx;
-			float dx      = lateral - (float)c * rx_pitch;
-			float a_arg   = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(xz))));
+			float dx      = lateral - (float)c * k_pitch;
+			float a_arg   = __builtin_fabsf(dx * (k_fnum * hw_rcp(__builtin_fabsf(xz))));
 			/* the delay is kept for lanes outside the aperture too: it keeps their (discarded)
 			 * LDS reads inside the window */
-			float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), p) * p.sampling_frequency;
+			float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), k_inv_c, k_c) * k_fs;
 			f32x4 entry = {r_idx, 0.f, 0.f, 0.f};
 			if (a_arg < 0.5f) {
 				float cs    = hw_cos_turns(0.5f * a_arg);
 				float apod  = cs * cs;
-				float turns = staged_phase_turns(phase_k, r_idx);
+				float turns = staged_phase_turns(k_phase, r_idx);
 				entry.y = apod * hw_cos_turns(turns);
 				entry.z = apod * hw_sin_turns(turns);
 				entry.w = apod;
 			}
 			R[e] = entry;
+		}
 		}
 		__syncthreads();
 		for (uint32_t cl = tid; cl < (uint32_t)cn; cl += nthreads) {
@@ -458,6 +486,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	}
 	if (!inside) return;
 
+	uint32_t x, y, lane_u_unused, thread = tid;
+	asm volatile("" : "+v"(thread));                      /* not the values computed before the loop */
+	voxel_of(thread, x, y, lane_u_unused);
 	uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
 	if constexpr (CW) coherent = coherent * (coherent / incoherent);   /* coherency_weighting.glsl:36 */
 	reinterpret_cast<f32x2 *>(p.out)[out_index] = coherent;
