@@ -101,6 +101,8 @@ typedef struct {
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
 	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel,
 	                              4 (retired), 5 HERCULES aligned-grid kernel */
+	uint32_t staged_window_violations;   /* LDS-staged kernels with the STAGED_CHECKED hook: (wave, channel) pairs in which a term's position
+	                                        fell outside the staged window -- the host's window bound was wrong.  Must be 0. */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
@@ -188,19 +190,22 @@ typedef enum {
 	BeamformerHipDasPath_NoSpanStaging    = 0x80, /* flag: never (the gather loop; the two give bit-identical frames) */
 } BeamformerHipDasPath;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
-/* Environment variables the library reads (measurement and test aids; none is needed in production):
+/* Environment variables the library reads (none is needed in production):
  *   BEAMFORMER_HIP_DEVICE            HIP ordinal of the one-device mode (else LOCAL_RANK, else 0)
  *   BEAMFORMER_HIP_FRAME_RING_BYTES  size of the beamformed-frame ring (default 4 GiB)
+ * and, read ONCE into the hook table (beamformer_hip_set_hook changes them at run time; measurement and test aids):
  *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major (=column: view planes walked depth
  *                                    fastest instead of in XCD-balanced bands)
  *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
- *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernel's range-checked loop for every wave
- *   BEAMFORMER_HIP_STAGED_W48        the LDS-staged kernel may use 64 x 16 tiles with a 48-sample window where 32 samples do not hold the tile's delay spread
- *   BEAMFORMER_HIP_STAGED_WALK=column  the uniform-table form of the LDS-staged kernel walks its tiles depth-major like the others (else: planes in chunks of 32, the two blocks of a CU neighbours along the receive axis)
- *   BEAMFORMER_HIP_STAGED_NOUNIFORM  the LDS-staged kernel keeps its transmit tables in LDS on 64 x 16 tiles too (else: a global table read through scalar loads)
+ *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernels' range-checked loop for every wave; it also counts window violations
+ *                                    (BeamformerHipFrameTimings::staged_window_violations)
+ *   BEAMFORMER_HIP_STAGED_NOUNIFORM  transmit tables in LDS also where the wave-uniform (global table) form applies
+ *   BEAMFORMER_HIP_STAGED_W48        the wave-uniform form's 48-sample window where 32 samples are too few
+ *   BEAMFORMER_HIP_STAGED_WALK=column  plain depth-major walk for the wave-uniform form (default: paired walk)
+ *   BEAMFORMER_HIP_STAGED_TABLE_CAP=bytes  largest global transmit table taken (default 2 GiB; 0: always the LDS-table fallback)
  *   BEAMFORMER_HIP_HERCULES_FRACT    the HERCULES kernel reduces the demodulation phase per pair (v_fract) as before round 2's last pass
- *   BEAMFORMER_HIP_HERCULES_NOPAIRS  the HERCULES kernel gathers from the DAS input itself, not from its {sample, difference} copy
- *   BEAMFORMER_HIP_DEBUG             one line per staged-kernel plan on stderr */
+ *   BEAMFORMER_HIP_HERCULES_NOPAIRS  the HERCULES kernel gathers from the DAS input itself, not from its prepared copy
+ *   BEAMFORMER_HIP_DEBUG             one line per staged plan on stderr */
 
 /* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----
  * Host only, no device needed.  The reference keeps this loader in its throughput harness;
@@ -262,6 +267,29 @@ typedef struct {
 /* The stage list the library would run for a parameter block (plan_compute_pipeline,
  * beamformer_core.c:553-1013, with the whole channel count as the chunk). */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_describe_plan(uint32_t parameter_slot, BeamformerHipPlan *out);
+
+/* Which DAS kernel the frames of a parameter block run under the current das path mode, and why each kernel ahead of it in the
+ * selection order was not taken: the library's ONE table of rules (csrc/das_select.cpp), asked instead of restated.  Needs no
+ * device.  path: BeamformerHipFrameTimings::das_path numbering; -1: the pipeline has no DAS stage; -2: an acquisition kind or
+ * interpolation mode the shader leaves at zero (the frame is cleared, no kernel). */
+typedef struct {
+	int32_t  path;
+	char     kernel[48];            /* "das_rca_staged_kernel", ... */
+	char     name[64];              /* "separable-delay LDS-staged kernel", ... */
+	char     declined[6][160];      /* by path number: why that kernel does not run ("" for the one that does) */
+	uint32_t tile_shift[3], blocks[3], split_shift;      /* per-voxel kernels (general, factored): block shape and count */
+	uint32_t tile_walk;             /* 0 x,y,z; 1 z fastest; 2 y fastest; 3 view plane in XCD-balanced bands; staged kernels: + their flag bits */
+	uint32_t span_stage;            /* factored kernel: wave-span staging */
+	uint32_t u_axis, u_shift, v_shift, window_samples, uniform_tables, lds_bytes, threads, channel_chunk;   /* separable-delay kernels: the tile is 2^u_shift voxels
+	                                   along the receive axis (voxel axis u_axis) by 2^v_shift along the transmit axis, one plane thick */
+	uint32_t hercules_prepared_copy;/* HERCULES kernel: reads the {sample, difference} / polynomial copy of the DAS input */
+} BeamformerHipDasDescription;
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDescription *out);
+
+/* Test and measurement hooks (none is needed in production; csrc/das_select.h lists what each does).  Each is read from the
+ * environment variable BEAMFORMER_HIP_<NAME> ONCE, when the library first needs it; this call changes one at run time
+ * (value NULL or "" = off) and is what the test-suite uses.  Returns 0 for an unknown name. */
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_hook(const char *name, const char *value);
 
 /* Free every device resource; the next call re-initialises. */
 BEAMFORMER_LIB_EXPORT void beamformer_hip_shutdown(void);

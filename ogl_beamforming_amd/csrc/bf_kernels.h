@@ -84,6 +84,8 @@ typedef struct {
 	uint32_t window_samples;  /* 32, 64 (= 1 << window_shift), or 48: the uniform variant's in-between window */
 	uint32_t table_stride;    /* bytes per (lateral tile row, plane) slice: 4 A4 + 16 + 16 (A4 / 4) 48, A4 = transmits rounded up to 4 */
 	void    *tables;          /* tiles[1] * tiles[2] slices */
+	uint32_t *violations;     /* staged kernels, range-checked loop: incremented once per wave and channel in which some term's window
+	                             position fell outside the staged window -- a violated host bound (plan_staged) made loud; may be null */
 } BfSeparableArgs;
 
 /* geometry of the HERCULES fast path (das_hercules.hip): lanes of a wave lie along the output's x

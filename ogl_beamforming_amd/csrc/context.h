@@ -15,6 +15,7 @@
 #include <vector>
 #include "planner.h"
 #include "bf_kernels.h"
+#include "das_select.h"
 #include "../../include/ogl_beamformer_hip.h"
 
 namespace bf {
@@ -56,6 +57,7 @@ struct TimingSlot {
 	uint32_t   das_taps = 0, das_sample_bytes = 0, das_path = 0;
 	bool       counted = false;
 	uint64_t   frame_id = 0;
+	uint64_t   violations_slot = ~0ull;   /* staged kernels: index of this frame's window-violation counter, or ~0 */
 };
 
 struct PlanState {
@@ -68,6 +70,8 @@ struct PlanState {
 	std::vector<BfTransmit>   transmit_table;
 	std::vector<uint16_t>     readi_bits;
 	std::string  error;
+	DasDecision  das;                     /* the DAS kernel and geometry of this plan's frames (das_select.cpp), reused until the plan, the shard,
+	                                         the path mode or a hook changes */
 };
 
 constexpr uint32_t kTimingSlots = 32;    /* beamformer_compute_stats.c: 32-frame table */
@@ -100,6 +104,7 @@ struct Device {
 	DeviceBuffer pair_counter, minmax_scratch, sum_scratch;
 	DeviceBuffer hercules_pairs;                               /* das_hercules.hip: {sample, difference} copy of the DAS input (IQ, linear) */
 	DeviceBuffer staged_tables;        /* das_staged.hip, wave-uniform transmit tables (bf_launch_das_staged_tables) */
+	DeviceBuffer staged_violations;    /* das_staged*.hip: one counter per timing slot of window positions outside the staged window */
 	DeviceBuffer hercules_table;                               /* das_hercules.hip: per-row lateral table, rebuilt per launch */
 	/* multi-device frames (executor.cpp push_multi): the RF of slot k landed on this device / the frame
 	 * that read slot k has finished */

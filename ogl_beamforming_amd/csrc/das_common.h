@@ -58,6 +58,38 @@ __device__ __forceinline__ float div_speed_of_sound(float distance, float inv_sp
 	return __builtin_fmaf(e, inv_speed_of_sound, q);
 }
 
+/* The LDS-staged kernels (das_staged*.hip) trust the host's bound on the delay spread of a tile (plan_staged, das_select.cpp): a
+ * position outside the staged window would read a neighbouring transmit's window -- wrong voxels, no fault.  Their range-checked loop
+ * (every wave under the STAGED_CHECKED hook) therefore tests every term; an offending wave raises a flag in the first LDS word (the
+ * kernels keep two unused window elements at LDS address 0 and have no static LDS), and at the end of the block one thread adds it to
+ * BfSeparableArgs::violations -- read through the kernel-argument segment there, so that neither flag nor pointer costs the loops a
+ * register (the headline instance sits at its 64-VGPR limit).  The staged kernels take (BfDasArgs, BfSeparableArgs) in that order. */
+__device__ __forceinline__ void staged_violation_clear(uint32_t tid)
+{
+	uint32_t at = 0;
+	asm volatile("" : "+v"(at));
+	if (tid == 0) *(__attribute__((address_space(3))) volatile uint32_t *)(uintptr_t)at = 0u;
+}
+__device__ __forceinline__ void staged_violation_raise()
+{
+	uint32_t at = 0;
+	asm volatile("" : "+v"(at));
+	*(__attribute__((address_space(3))) volatile uint32_t *)(uintptr_t)at = 1u;
+}
+/* every thread of the block calls this once, after its last channel */
+__device__ __forceinline__ void staged_violation_report(uint32_t tid)
+{
+	__syncthreads();
+	uint32_t at = 0;
+	asm volatile("" : "+v"(at));
+	if (tid == 0 && *(__attribute__((address_space(3))) volatile uint32_t *)(uintptr_t)at) {
+		typedef __attribute__((address_space(4))) const BfSeparableArgs const_sep;
+		const_sep *q = (const_sep *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(BfDasArgs) + 7u) & ~(size_t)7u));
+		uint32_t *counter = q->violations;
+		if (counter) atomicAdd(counter, 1u);
+	}
+}
+
 /* (int)floor(x) in one instruction (hipcc emits v_floor_f32 + v_cvt_i32_f32) */
 __device__ __forceinline__ int cvt_floor_i32(float x)
 {

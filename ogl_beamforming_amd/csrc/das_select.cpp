@@ -1,0 +1,650 @@
+/* das_select.cpp -- which DAS kernel a frame runs, and why (das_select.h).  Host arithmetic only.
+ *
+ * The rules, in the order they are tried (decide_das):
+ *   general     das.hip            every family; forced by path 1; the fallback
+ *   gather      das_separable.hip  row-column frames whose receive and transmit delays separate over the tile axes (plan_separable)
+ *   staged      das_staged*.hip    ... and whose delay spread provably fits an LDS window (plan_staged), from kStagedMinTransmits
+ *   hercules    das_hercules.hip   HERCULES family on array-aligned grids, volumes and view planes (plan_hercules)
+ *   factored    das_factored.hip   any frame whose index is a receive term plus a transmit term (factored_applies); with wave-span
+ *                                  staging on coarse grids
+ */
+#include "das_select.h"
+#include "host_math.h"
+#include "../../include/ogl_beamformer_lib.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace bf {
+
+const char *das_path_name(int path)
+{
+	static const char *names[] = {"general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
+	                              "(retired: LDS row-cache experiment)", "HERCULES aligned-grid kernel", "?", "none: the frame is cleared"};
+	return path >= 0 && path <= 7 ? names[path] : "?";
+}
+
+const char *das_kernel_name(int path)
+{
+	static const char *names[] = {"das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
+	                              "das_hercules_kernel", "?", "(none)"};
+	return path >= 0 && path <= 7 ? names[path] : "?";
+}
+
+/* ---------------------------------------------------------------- hooks */
+
+static Hooks g_hooks;
+static const char *const g_hook_names[] = {"STAGED_SHAPE", "STAGED_CHECKED", "STAGED_NOUNIFORM", "STAGED_W48", "STAGED_WALK", "STAGED_TABLE_CAP",
+                                           "TILE_WALK", "HERCULES_FRACT", "HERCULES_NOPAIRS", "DEBUG", nullptr};
+const char *const *hook_names() { return g_hook_names; }
+
+static bool apply_hook(Hooks &h, const char *name, const char *value)
+{
+	const bool on = value && value[0];
+	if (!std::strcmp(name, "STAGED_SHAPE")) {
+		unsigned u = 0, v = 0, w = 0;
+		h.staged_shape_set = on && std::sscanf(value, "%u,%u,%u", &u, &v, &w) == 3;
+		h.staged_shape[0] = (int)u; h.staged_shape[1] = (int)v; h.staged_shape[2] = (int)w;
+	}
+	else if (!std::strcmp(name, "STAGED_CHECKED"))   h.staged_checked = on;
+	else if (!std::strcmp(name, "STAGED_NOUNIFORM")) h.staged_nouniform = on;
+	else if (!std::strcmp(name, "STAGED_W48"))       h.staged_w48 = on;
+	else if (!std::strcmp(name, "STAGED_WALK"))      h.staged_walk_column = on && value[0] == 'c';
+	else if (!std::strcmp(name, "STAGED_TABLE_CAP")) h.staged_table_cap = on ? std::strtoull(value, nullptr, 0) : (2ull << 30);
+	else if (!std::strcmp(name, "TILE_WALK"))        h.tile_walk = on ? value[0] : 0;
+	else if (!std::strcmp(name, "HERCULES_FRACT"))   h.hercules_fract = on;
+	else if (!std::strcmp(name, "HERCULES_NOPAIRS")) h.hercules_nopairs = on;
+	else if (!std::strcmp(name, "DEBUG"))            h.debug = on;
+	else return false;
+	return true;
+}
+
+Hooks &hooks()
+{
+	if (!g_hooks.loaded) {
+		g_hooks.loaded = true;
+		for (const char *const *n = g_hook_names; *n; n++) {
+			std::string env = std::string("BEAMFORMER_HIP_") + *n;
+			if (const char *v = std::getenv(env.c_str())) apply_hook(g_hooks, *n, v);
+		}
+	}
+	return g_hooks;
+}
+
+bool set_hook(const char *name, const char *value)
+{
+	Hooks &h = hooks();
+	if (!name || !apply_hook(h, name, value)) return false;
+	h.version++;
+	return true;
+}
+
+/* ---------------------------------------------------------------- geometry rules */
+
+static uint32_t ceil_log2(uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; }
+
+/* Shape of the 2^tile_log2-voxel block of the DAS launch.  The axis along which the transducer-space
+ * depth changes fastest gets extent 1: sample indices move ~2 samples per voxel along depth
+ * but only a fraction of a sample per voxel laterally, so a depth-flat tile keeps the 64 lanes
+ * of a wave within a few cache lines of every (channel, transmit) row. */
+static int choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3], uint32_t tile_log2 = 8)
+{
+	uint32_t extent[3] = {size[0], size[1], zcount};
+	uint32_t full[3]   = {size[0], size[1], size[2]};
+	int depth = -1; float best = -1;
+	for (int i = 0; i < 3; i++) {
+		if (extent[i] <= 1) continue;
+		float step = std::fabs(voxel_to_xdc[4 * i + 2]) / (float)(full[i] > 1 ? full[i] - 1 : 1);
+		if (step > best) { best = step; depth = i; }
+	}
+	uint32_t cap[3], left = tile_log2;
+	for (int i = 0; i < 3; i++) { cap[i] = ceil_log2(extent[i]); shift[i] = 0; }
+	int lateral[2], nl = 0;
+	for (int i = 0; i < 3; i++) if (i != depth && extent[i] > 1) lateral[nl++] = i;
+	uint32_t first = nl == 2 ? tile_log2 / 2 : tile_log2;
+	for (int k = 0; k < nl; k++) {
+		uint32_t give = cap[lateral[k]] < first ? cap[lateral[k]] : first;
+		if (give > left) give = left;
+		shift[lateral[k]] = give; left -= give;
+	}
+	for (int k = 0; k < nl && left; k++) {
+		uint32_t room = cap[lateral[k]] - shift[lateral[k]];
+		uint32_t give = room < left ? room : left;
+		shift[lateral[k]] += give; left -= give;
+	}
+	if (depth >= 0 && left) {
+		uint32_t give = cap[depth] < left ? cap[depth] : left;
+		shift[depth] = give; left -= give;
+	}
+	shift[0] += left;   /* fewer voxels in total than the tile: idle lanes */
+	return depth;
+}
+
+/* tile walk of the kernels that deal tiles to the XCDs in contiguous runs: the depth axis runs fastest, so that a run is a
+ * lateral column at every depth (neighbouring RF windows AND the same work on every XCD: the f-number test culls shallow
+ * voxels).  Volumes: depth = voxel z (1); the reference's view planes (math.c:844-885) put it on voxel y (2). */
+static uint32_t tile_walk(int depth_axis, uint32_t zcount, uint32_t tile_rows, uint32_t &band_rows)
+{
+	band_rows = 1;
+	const char walk = hooks().tile_walk;      /* 'p': x -> y -> z, 'c': y fastest on view planes (measurement aids) */
+	if (walk == 'p') return 0u;
+	if (depth_axis != 1) return 1u;
+	if (zcount != 1 || walk == 'c') return 2u;
+	/* view plane: ~32 bands, four per XCD (bf_plane_walk) */
+	band_rows = tile_rows / 32u ? tile_rows / 32u : 1u;
+	return 3u;
+}
+
+/* Samples of delay one voxel step along x (the lane axis of the per-voxel kernels) can move a sample index: the physical
+ * length of the step times fs / c.  >= 1: a COARSE grid -- neighbouring lanes read different samples of an RF row. */
+static float lane_step_samples(const float *voxel_to_xdc, const BfDasArgs &a)
+{
+	const float n = (float)(a.size[0] > 1 ? a.size[0] - 1 : 1);
+	const float dx = voxel_to_xdc[0] / n, dy = voxel_to_xdc[1] / n, dz = voxel_to_xdc[2] / n;
+	return std::sqrt(dx * dx + dy * dy + dz * dz) * a.sampling_frequency * a.inv_speed_of_sound;
+}
+
+/* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
+ * receive and one transmit orientation for all transmits, on different transducer axes, a
+ * volume whose z axis alone carries depth, and voxel x / y axes that each move only one of
+ * the two lateral coordinates -- every coefficient that must vanish has to be an exact
+ * zero product, so that the tables reproduce the general kernel's per-voxel arithmetic. */
+static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
+                           uint32_t zcount, BfSeparableArgs &q)
+{
+	if (a.family != BF_DAS_RCA || tx.empty()) return false;
+	const uint32_t orient = BF_TX_ROWS | BF_RX_ROWS | BF_TX_NONE;
+	for (const BfTransmit &t : tx) if ((t.flags & orient) != (tx[0].flags & orient)) return false;
+	const bool tx_none = (tx[0].flags & BF_TX_NONE) != 0;
+	const int  r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0;      /* transducer coordinate the receive aperture uses */
+	const int  w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;      /* world coordinate the transmit uses */
+	auto W = [&](int row, int col) { return vox[4 * col + row]; };
+	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
+	/* transducer coordinate `row` must not move with voxel axis `col` */
+	auto xdc_fixed = [&](int row, int col) {
+		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return false;
+		return true;
+	};
+	if (a.size[0] < 2 || a.size[1] < 2) return false;
+	for (int col = 0; col < 2; col++) {
+		if (!xdc_fixed(2, col)) return false;                 /* transducer depth: voxel z only */
+		if (!tx_none && W(2, col) != 0.f) return false;       /* world depth: voxel z only */
+	}
+	int u_axis = -1;
+	for (int u = 0; u < 2 && u_axis < 0; u++) {
+		int v = 1 - u;
+		if (!xdc_fixed(r, v)) continue;                       /* receive lateral: not along v */
+		if (!tx_none && W(w, u) != 0.f) continue;             /* transmit lateral: not along u */
+		u_axis = u;
+	}
+	if (u_axis < 0) return false;
+
+	/* Tile (U along the receive axis, V along the transmit axis), block size and the number of
+	 * channels per receive-table chunk: maximise resident waves per CU (LDS: 160 KB per CU, 32
+	 * waves per CU), then prefer big chunks (fewer rebuilds) and square-ish tiles. */
+	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
+	const uint32_t lds_cu = 160u * 1024u;
+	uint32_t best_waves = 0, best_score = 0;
+	for (uint32_t threads_shift = 10; threads_shift >= 8; threads_shift--) {
+		for (uint32_t us = 2; us + 2 <= threads_shift; us++) {
+			uint32_t vs = threads_shift - us;
+			if ((u_axis == 0 ? us : vs) < 4) continue;        /* >= 16 lanes of a wave along x */
+			for (uint32_t chunk = 16; chunk <= 256; chunk *= 2) {
+				uint32_t cc = chunk < C ? chunk : C;
+				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A << vs));
+				if (lds > lds_cu) continue;
+				uint32_t blocks = (uint32_t)(lds_cu / lds);
+				uint32_t by_waves = 2048u >> threads_shift;
+				if (blocks > by_waves) blocks = by_waves;
+				uint32_t waves = blocks << (threads_shift - 6);
+				uint32_t balance = us > vs ? us - vs : vs - us;
+				uint32_t score = (cc << 4) + (16 - balance);
+				if (waves > best_waves || (waves == best_waves && score > best_score)) {
+					best_waves = waves; best_score = score;
+					q.u_shift = us; q.v_shift = vs; q.threads = 1u << threads_shift;
+					q.channel_chunk = cc; q.lds_bytes = (uint32_t)lds;
+				}
+				if (cc == C) break;
+			}
+		}
+	}
+	if (!best_waves) return false;
+	q.u_axis = (uint32_t)u_axis;
+	q.depth_major = hooks().tile_walk == 'p' ? 0u : 1u;        /* TILE_WALK=plane restores the x -> y -> z walk (measurement aid) */
+	const uint32_t best_u = q.u_shift, best_v = q.v_shift;
+	uint32_t nu = a.size[u_axis], nv = a.size[1 - u_axis];
+	q.tiles[0] = (nu + (1u << best_u) - 1) >> best_u;
+	q.tiles[1] = (nv + (1u << best_v) - 1) >> best_v;
+	q.tiles[2] = zcount;
+	return true;
+}
+
+/* Upgrade a separable plan to the LDS-staged kernel (das_staged.hip) when the delay spread of a
+ * tile provably fits the staging window.  The receive delay is a distance, so it changes by at
+ * most one lateral voxel step (in samples) per voxel along u; the transmit delay likewise along
+ * v, scaled by max|sin(angle)| when every transmit is a plane wave. */
+static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
+                        uint32_t zcount, BfSeparableArgs &q, bool allow_uniform = true)
+{
+	const Hooks &hk = hooks();
+	const bool cplx = a.complex_data != 0;                       /* das_staged.hip / das_staged_real.hip */
+	const bool cubic = a.interpolation == 2;                     /* das_staged_cubic.hip: complex samples only */
+	if (a.interpolation != 1 && !(cubic && cplx)) return false;
+	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
+	/* the kernels stage through 32-bit buffer offsets and park their padding loads at 2^31 */
+	if ((uint64_t)C * A * (uint64_t)a.sample_count * (cplx ? 8u : 4u) >= (1ull << 31)) return false;
+	const uint32_t A4 = (A + 3u) & ~3u;                          /* the kernel pads the transmit table to whole batches of 4 */
+	const int u_axis = (int)q.u_axis, v_axis = 1 - u_axis;
+	const int r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0, w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;
+	float m[16];
+	m4_mul(xdc, vox, m);
+	const float samples_per_metre = a.sampling_frequency * a.inv_speed_of_sound;
+	float step_u = std::fabs(m[4 * u_axis + r]) / (float)(a.size[u_axis] > 1 ? a.size[u_axis] - 1 : 1) * samples_per_metre;
+	float step_v = std::fabs(vox[4 * v_axis + w]) / (float)(a.size[v_axis] > 1 ? a.size[v_axis] - 1 : 1) * samples_per_metre;
+	bool all_plane = true; float max_sin = 0.f;
+	for (const BfTransmit &t : tx) {
+		all_plane &= (t.flags & BF_TX_PLANE) != 0;
+		max_sin = std::fmax(max_sin, std::fabs(t.sin_a));
+	}
+	if (tx[0].flags & BF_TX_NONE) step_v = 0.f;
+	else if (all_plane)           step_v *= max_sin;
+
+	const uint32_t lds_cu = 160u * 1024u;
+	uint32_t best_waves = 0, best_score = 0;
+	BfSeparableArgs best = q;
+	for (uint32_t threads_shift = 10; threads_shift >= 9; threads_shift--) {
+		for (uint32_t vs = 4; vs <= 6; vs++) {
+			if (vs + 4 > threads_shift) continue;
+			uint32_t us = threads_shift - vs;
+			if (us > 6) continue;
+			if ((u_axis == 0 ? us : vs) < 4) continue;
+			float spread = step_u * (float)((1u << us) - 1) + step_v * (float)((1u << vs) - 1);
+			if (!(spread >= 0.f && spread <= 60.f)) continue;                /* also a NaN / infinite spread (wild parameters) */
+			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + (cubic ? 6 : 4);   /* + taps (k - 1 .. k + 2 for cubic), floors, rounding slack */
+			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
+			if (!ws) continue;
+			/* BEAMFORMER_HIP_STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
+			 * a window larger than needed is legal, a smaller one is not taken; ws = 48: the uniform variant's 48-sample window) */
+			bool force_w48 = false;
+			if (hk.staged_shape_set) {
+				const unsigned fu = (unsigned)hk.staged_shape[0], fv = (unsigned)hk.staged_shape[1], fw = (unsigned)hk.staged_shape[2];
+				if (fu != us || fv != vs) continue;
+				if (fw == 48) { if (need > 48) continue; force_w48 = true; }
+				else { if (fw < ws || fw > 6) continue; ws = fw; }
+			}
+			/* complex samples, linear interpolation, x along the receive axis and a 64 x 16 tile: a wave's lanes share one row of the
+			 * transmit axis, the transmit tables leave the LDS for a global table read through scalar loads (das_staged.hip, UNI).
+			 * Measured faster than every other shape, so it is preferred wherever its window fits -- with a
+			 * 48-sample window where 32 samples are too few (64-sample windows of 64 and more transmits leave no room for two
+			 * blocks per CU): 63 elements per wave and pass, at most 4 passes of the 16 waves */
+			const bool uniform = allow_uniform && cplx && !cubic && u_axis == 0 && threads_shift == 10 && us == 6 && vs == 4 &&
+			                     !hk.staged_nouniform;
+			uint32_t window = 1u << ws;
+			/* (the 48-sample window is opt-in -- BEAMFORMER_HIP_STAGED_W48, or the shape hook: at config 4 it measured 799.0 ms against
+			 * 804.5 ms for the 32 x 32 tiles with the tables in LDS, but 726 GB of HBM-side traffic per launch against 176 GB) */
+			const bool want_w48 = force_w48 || (hk.staged_w48 && need > 32 && need <= 48);
+			if (uniform && want_w48 && (A4 * 48u + 62u) / 63u <= 64u) window = 48;
+			else if (force_w48) continue;
+			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
+			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
+			if (window != 48 && ((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
+			const uint64_t stage_elements = (uint64_t)A4 * window;
+			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
+				uint32_t cc = chunk < C ? chunk : C;
+				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
+				uint64_t lds = cubic ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 32ull * (stage_elements + 3) + 4ull * (A4 + cc + 1) + 128
+				             : cplx ? (uniform ? 0ull : 12ull * ((uint64_t)A4 << vs)) + 16ull * ((uint64_t)cc << us) + 16ull * (stage_elements + 3) + 4ull * (A4 + cc + 1) + 128
+				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (stage_elements + 4) + 4ull * (A4 + cc + 1) + 128;
+				lds = (lds + 15) & ~15ull;
+				if (lds > lds_cu) continue;
+				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = (cubic ? 1024u : 2048u) >> threads_shift;   /* (cubic: 128 VGPRs per lane) */
+				if (blocks > by_waves) blocks = by_waves;
+				uint32_t waves = blocks << (threads_shift - 6);
+				uint32_t balance = us > vs ? us - vs : vs - us;
+				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (window == 32 ? 500u : 0u) +
+				                 (uniform && window == 32 ? 2000u : uniform && window == 48 ? 1500u : 0u);
+				if (waves > best_waves || (waves == best_waves && score > best_score)) {
+					best_waves = waves; best_score = score;
+					best.u_shift = us; best.v_shift = vs; best.threads = 1u << threads_shift;
+					best.channel_chunk = cc; best.lds_bytes = (uint32_t)lds; best.window_shift = ws; best.window_samples = window;
+					best.uniform = uniform ? 1u : 0u;
+					best.table_stride = uniform ? 4u * A4 + 16u + 16u * (A4 / 4u) * 48u : 0u;
+				}
+				if (cc == C) break;
+			}
+		}
+	}
+	if (hk.staged_checked) best.depth_major |= 2u;       /* test hook: the range-checked loop for every wave */
+	/* uniform variant: the two blocks of a CU are neighbours along u in one plane (shared rows of the global transmit table);
+	 * STAGED_WALK=column keeps the plain depth-major walk (measurement aid) */
+	if (best.uniform && (best.depth_major & 1u) && !hk.staged_walk_column) best.depth_major |= 4u;
+	if (hk.debug)
+		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u uniform %u\n",
+		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_samples, best.channel_chunk, best.lds_bytes, best.uniform);
+	if (!best_waves) return false;
+	q = best;
+	uint32_t nu = a.size[u_axis], nv = a.size[v_axis];
+	q.tiles[0] = (nu + (1u << q.u_shift) - 1) >> q.u_shift;
+	q.tiles[1] = (nv + (1u << q.v_shift) - 1) >> q.v_shift;
+	q.tiles[2] = zcount;
+	return true;
+}
+
+/* Can this HERCULES-family frame use the aligned fast path (das_hercules.hip)?  The kernel lays
+ * the 64 lanes of a wave along the output's x axis and reads the squared lateral distance along
+ * the OTHER array axis from a per-output-row table, so one transducer lateral coordinate has to
+ * be a function of the output row y alone: every product that would let voxel x or voxel z move
+ * it must be an exact zero (then the table entry is bit-identical to the per-voxel value).
+ * Everything else -- depth, the transmit distance, the coordinate along x -- stays per voxel. */
+static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
+                          uint32_t zcount, bool forced, BfHerculesArgs &q)
+{
+	if (a.family != BF_DAS_HERCULES || tx.empty()) return false;
+	if (!forced) {
+		if (a.size[0] < 32 || a.split_shift) return false;       /* thin or tiny frames: the general kernel's channel split */
+		if (((a.size[0] + 63u) & ~63u) > a.size[0] + a.size[0] / 3u) return false;   /* > 25 % idle lanes */
+	}
+	auto W = [&](int row, int col) { return vox[4 * col + row]; };
+	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
+	/* does transducer coordinate `row` move with voxel axis `col`?  An axis of one voxel moves nothing, whatever its
+	 * column of the transform holds: the view planes of math.c:844-885 keep their NORMAL there (das_transform_2d_xz: voxel z
+	 * = (0, 1, 0), size 1), and the reference's own harness beamforms exactly such a plane (tests/throughput.c:20, :443-446) */
+	auto moves = [&](int row, int col) {
+		if (a.size[col] <= 1) return false;
+		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return true;
+		return false;
+	};
+	int inner = -1;
+	for (int coord = 0; coord < 2 && inner < 0; coord++)
+		if (!moves(coord, 0) && !moves(coord, 2)) inner = coord;
+	/* prefer the coordinate that does move with y when both qualify (a degenerate grid) */
+	if (inner == 0 && !moves(1, 0) && !moves(1, 2) && !moves(0, 1) && moves(1, 1)) inner = 1;
+	if (inner < 0) return false;
+	const bool rx_cols = (tx[0].flags & BF_RX_COLUMNS) != 0;
+	const int  tx_coord = rx_cols ? 1 : 0;                        /* das.glsl:238-247: transmit elements run along the other axis */
+	const uint32_t A = (uint32_t)a.acquisition_count, C = (uint32_t)a.channel_count;
+	const uint32_t transmits = A - (a.sparse ? 1u : 0u);
+	if (!transmits || !C) return false;
+	q.inner_coord       = (uint32_t)inner;
+	q.inner_is_transmit = inner == tx_coord;
+	q.inner_count       = q.inner_is_transmit ? transmits : C;
+	q.outer_count       = q.inner_is_transmit ? C : transmits;
+	q.table_pitch       = (q.inner_count + 8u + 3u) & ~3u;      /* the kernel prefetches one batch of 4 past the end */
+	q.tiles[0] = (a.size[0] + 63u) / 64u;
+	q.tiles[1] = (a.size[1] + 3u) / 4u;
+	q.tiles[2] = zcount;
+	{
+		/* the axis along which the transducer-space depth changes fastest (as choose_tile finds it) */
+		float m[16];
+		m4_mul(xdc, vox, m);
+		const uint32_t ext[3] = {a.size[0], a.size[1], zcount};
+		int depth = 2; float best = -1.f;
+		for (int i = 0; i < 3; i++) {
+			if (ext[i] <= 1) continue;
+			float step = std::fabs(m[4 * i + 2]) / (float)(a.size[i] > 1 ? a.size[i] - 1 : 1);
+			if (step > best) { best = step; depth = i; }
+		}
+		q.depth_major = tile_walk(depth, zcount, q.tiles[1], q.band_rows);
+	}
+	/* unit of length: among the 8193 floats nearest 1, the s2 whose k' = float(k / sqrt(s2)) reproduces
+	 * k = fs / c best as k' sqrt(s2) (errors are spread over +-3e-8, the best of 8193 lands near 1e-11).
+	 * Remembered per (fs, c): frames of one plan ask again every launch. */
+	{
+		static float cached_fs = 0.f, cached_c = 0.f, cached_s2 = 1.f, cached_k = 0.f;
+		if (cached_fs != a.sampling_frequency || cached_c != a.speed_of_sound) {
+			const double k_exact = (double)a.sampling_frequency / (double)a.speed_of_sound;
+			double best = 1e9;
+			for (int i = -4096; i <= 4096; i++) {
+				uint32_t bits = 0x3F800000u + (uint32_t)i;              /* floats around 1.0f in ulp steps */
+				float s2; std::memcpy(&s2, &bits, sizeof s2);
+				double s  = std::sqrt((double)s2);
+				float  kk = (float)(k_exact / s);
+				double err = std::fabs((double)kk * s / k_exact - 1.0);
+				if (err < best) { best = err; cached_s2 = s2; cached_k = kk; }
+			}
+			cached_fs = a.sampling_frequency; cached_c = a.speed_of_sound;
+		}
+		q.unit_scale2 = cached_s2; q.samples_per_unit = cached_k;
+	}
+	{
+		/* distances to two elements of the inner axis differ by at most their separation: at most 255 pitches (dense or
+		 * sparse element indices alike), i.e. this many turns of demodulation phase inside one inner loop */
+		const float span_turns = std::fabs(a.turns_per_sample) * 255.0f * std::fabs(a.pitch[inner]) * a.sampling_frequency * a.inv_speed_of_sound;
+		q.phase_local = a.complex_data && span_turns < 400.0f &&       /* (false for a NaN) */
+		                !hooks().hercules_fract;                         /* measurement aid: v_fract per pair */
+	}
+	return true;
+}
+
+/* Can the per-voxel factored kernel (das_factored.hip) take this frame?  It needs the sample
+ * index to be a receive term plus a transmit term: RCA-family frames whose transmits all share
+ * one receive orientation, and FORCES/UFORCES.  With fewer than three transmits per channel
+ * chunk the receive factors are not amortised and the general kernel is as fast. */
+static bool factored_applies(const BfDasArgs &a, const std::vector<BfTransmit> &tx, uint32_t mode)
+{
+	if (mode == 1) return false;
+	int transmits = a.acquisition_count - (a.family == BF_DAS_FORCES && a.sparse ? 1 : 0);
+	if (transmits < 3 && mode != 4) return false;
+	if (a.family == BF_DAS_FORCES) return true;
+	if (a.family != BF_DAS_RCA || tx.empty()) return false;
+	for (const BfTransmit &t : tx)
+		if ((t.flags & BF_RX_ROWS) != (tx[0].flags & BF_RX_ROWS)) return false;
+	return true;
+}
+
+
+/* ---------------------------------------------------------------- the decision */
+
+std::vector<BfTransmit> build_transmit_table(const ParameterBlock &pb)
+{
+	const BeamformerParameters &bp = pb.parameters;
+	const uint32_t A = bp.acquisition_count;
+	std::vector<BfTransmit> table(A, BfTransmit{});
+	for (uint32_t a = 0; a < A; a++) {
+		uint32_t txrx  = bp.single_orientation ? (bp.transmit_receive_orientation & 0xFFu) : pb.transmit_receive_orientations[a];
+		float    angle = bp.single_focus ? bp.focal_vector[0] : pb.focal_vectors[a][0];
+		float    depth = bp.single_focus ? bp.focal_vector[1] : pb.focal_vectors[a][1];
+		uint32_t tx = (txrx >> 4) & 0xF, rx = txrx & 0xF;
+		BfTransmit &t = table[a];
+		float rad = angle * 0.017453292519943295f;               /* GLSL radians() */
+		t.sin_a = sinf(rad); t.cos_a = cosf(rad);
+		t.flags = 0;
+		if (tx == BeamformerRCAOrientation_None)    t.flags |= BF_TX_NONE;
+		if (tx == BeamformerRCAOrientation_Rows)    t.flags |= BF_TX_ROWS;
+		if (rx == BeamformerRCAOrientation_Rows)    t.flags |= BF_RX_ROWS;
+		if (rx == BeamformerRCAOrientation_Columns) t.flags |= BF_RX_COLUMNS;
+		if (std::isinf(depth)) { t.flags |= BF_TX_PLANE; t.focus_x = t.focus_z = 0; }
+		else                   { t.focus_x = depth * t.sin_a; t.focus_z = depth * t.cos_a; }
+	}
+	return table;
+}
+
+void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<BfTransmit> &tx,
+                uint32_t zfirst, uint32_t zcount, uint32_t mode, DasDecision &out)
+{
+	const BeamformerParameters &bp = pb.parameters;
+	out = DasDecision{};
+	out.z_first = zfirst; out.z_count = zcount; out.mode = mode; out.hooks_version = hooks().version;
+	const uint32_t C = plan.channels, A = plan.acquisitions, Sd = plan.das_samples;
+
+	BfDasArgs &a = out.a;
+	std::memcpy(a.xdc_transform,   bp.xdc_transform,         sizeof(a.xdc_transform));
+	std::memcpy(a.voxel_transform, plan.das_voxel_transform, sizeof(a.voxel_transform));
+	a.pitch[0] = bp.xdc_element_pitch[0]; a.pitch[1] = bp.xdc_element_pitch[1];
+	switch (bp.acquisition_kind) {                                          /* das.glsl:381-400 */
+	case BeamformerAcquisitionKind_FORCES:
+	case BeamformerAcquisitionKind_UFORCES:
+		a.family = bp.readi_group_count > 1 ? BF_DAS_READI : BF_DAS_FORCES; break;
+	case BeamformerAcquisitionKind_HERCULES:
+	case BeamformerAcquisitionKind_UHERCULES:
+	case BeamformerAcquisitionKind_HERO_PA:
+		a.family = BF_DAS_HERCULES; break;
+	case BeamformerAcquisitionKind_Flash:
+	case BeamformerAcquisitionKind_RCA_TPW:
+	case BeamformerAcquisitionKind_RCA_VLS:
+		a.family = BF_DAS_RCA; break;
+	default: a.family = -1; break;      /* the shader leaves the voxel at zero */
+	}
+	a.interpolation = (int32_t)bp.interpolation_mode;
+	a.complex_data  = plan.iq_pipeline;
+	a.coherency_weighting = bp.coherency_weighting != 0;
+	a.acquisition_count = (int32_t)A; a.channel_count = (int32_t)C; a.sample_count = (int32_t)Sd;
+	a.sparse = plan.das_sparse;
+	a.sampling_frequency     = plan.das_sampling_frequency;
+	a.inv_sampling_frequency = 1.0f / plan.das_sampling_frequency;
+	a.demodulation_frequency = bp.demodulation_frequency;
+	a.inv_speed_of_sound     = 1.0f / bp.speed_of_sound;
+	a.speed_of_sound         = bp.speed_of_sound;
+	a.turns_per_sample       = bp.demodulation_frequency * a.inv_sampling_frequency;
+	a.first_transmit_weight  = 1.0f / sqrtf((float)A);
+	a.time_offset = plan.das_time_offset;
+	a.f_number    = bp.f_number;
+	a.size[0] = plan.output_points[0]; a.size[1] = plan.output_points[1]; a.size[2] = plan.output_points[2];
+	a.z_first = zfirst; a.z_count = zcount;
+	a.readi_group_count = bp.readi_group_count; a.readi_group = bp.readi_group;
+	out.das_input_bytes = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
+
+	float to_xdc[16];
+	if (a.family == BF_DAS_FORCES || a.family == BF_DAS_READI) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
+	else m4_mul(bp.xdc_transform, plan.das_voxel_transform, to_xdc);
+	const uint32_t ext[3] = {a.size[0], a.size[1], zcount};
+	/* Small frames (real-time 2-D imaging) do not fill 256 CUs with one thread per voxel:
+	 * split the channel loop over K waves of a block (wave-level partial sums, combined
+	 * through LDS in split order) until the launch has ~16 waves per CU (config 1, us per
+	 * frame by target wave count: 2048 -> 19.9, 4096 -> 15.2, 8192 -> 15.1, 16384 -> 17.1). */
+	const uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
+	a.split_shift = 0;
+	while (!(mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
+	out.depth_axis = choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
+	for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+	a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
+
+	if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
+		out.path = DasPath_Zero;
+		for (auto &w : out.why) w = "acquisition kind or interpolation mode the shader leaves at zero";
+		out.valid = true;
+		return;
+	}
+	const uint32_t das_mode = mode & 0xF;
+	const bool factored = factored_applies(a, tx, das_mode);
+	auto &why = out.why;
+	if (das_mode == 1) {
+		why[DasPath_Gather] = why[DasPath_Staged] = why[DasPath_Hercules] = why[DasPath_Factored] = "das path 1: the general kernel was asked for";
+	}
+	if (!factored && why[DasPath_Factored].empty())
+		why[DasPath_Factored] = a.family == BF_DAS_HERCULES || a.family == BF_DAS_READI ? "the sample index is not a receive term plus a transmit term (HERCULES / READI)"
+		                      : "fewer than 3 transmits per channel chunk, or transmits with different receive orientations";
+
+	/* The LDS-table kernels' hand-scheduled loop exists for linear interpolation; for cubic and nearest the gather kernel's
+	 * generic loop loses to the factored kernel (200 ch x 33 tx -> 129 x 333 x 21, cubic: 7.6 ms against 4.8 ms; nearest 2.6
+	 * against 2.1), which then goes first -- except for cubic IQ frames with enough transmits, which try the staged cubic kernel
+	 * (it declines, and the factored kernel runs, when the geometry is not separable or the spread does not fit a window). */
+	const bool want_staged  = das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits);
+	const bool staged_cubic = a.interpolation == 2 && plan.iq_pipeline && want_staged;
+	bool tables_first = a.interpolation == 1 || das_mode == 3 || staged_cubic || !factored;
+	BfSeparableArgs sep{};
+	bool separable = false, staged = false;
+	if (das_mode != 1 && das_mode != 4) {
+		separable = plan_separable(a, tx, bp.xdc_transform, plan.das_voxel_transform, zcount, sep);
+		if (!separable) why[DasPath_Gather] = why[DasPath_Staged] = "not a row-column frame whose receive and transmit delays separate over the voxel x / y axes with depth on z";
+	} else if (das_mode == 4) {
+		why[DasPath_Gather] = why[DasPath_Staged] = "das path 4: the factored kernel was asked for";
+	}
+	BfSeparableArgs gather = sep;
+	if (separable) {
+		sep.zero_offset = gather.zero_offset = (uint32_t)out.das_input_bytes;       /* 64 zero bytes right behind the DAS input */
+		if (!want_staged) {
+			why[DasPath_Staged] = das_mode == 2 ? "das path 2: no LDS staging" : "fewer than 6 transmits per channel: two barriers and a window copy per channel are not amortised";
+		} else {
+			staged = plan_staged(a, tx, bp.xdc_transform, plan.das_voxel_transform, zcount, sep);
+			if (!staged) {
+				sep = gather;
+				why[DasPath_Staged] = a.interpolation == 0 ? "nearest interpolation" : (a.interpolation == 2 && !plan.iq_pipeline) ? "cubic interpolation of real samples"
+				                    : out.das_input_bytes >= (1ull << 31) ? "DAS input of 2 GiB or more (32-bit staging offsets)"
+				                    : "the delay spread of no tile shape fits a 32- / 64-sample window (or the windows do not fit the LDS)";
+			}
+		}
+		if (!staged && staged_cubic && das_mode != 3 && factored) tables_first = false;          /* cubic: the factored kernel, not the gather kernel's generic loop */
+		if (!staged && !tables_first) why[DasPath_Gather] = "cubic / nearest interpolation: its generic loop loses to the factored kernel";
+	}
+	if (separable && tables_first) {
+		out.sep = sep; out.sep_gather = gather;
+		out.path = staged ? DasPath_Staged : DasPath_Gather;
+		if (staged && sep.uniform) {
+			/* the wave-uniform transmit tables live in global memory (a few MB to 244 MB at 512^3 with 75 transmits); too big or no
+			 * memory at launch: the shape with the tables in LDS, planned here */
+			BfSeparableArgs again = gather;
+			out.has_lds_tables = plan_staged(a, tx, bp.xdc_transform, plan.das_voxel_transform, zcount, again, false);
+			if (out.has_lds_tables) out.sep_lds_tables = again;
+			const uint64_t table_bytes = (uint64_t)sep.table_stride * sep.tiles[1] * sep.tiles[2];
+			if (table_bytes > hooks().staged_table_cap) {
+				if (out.has_lds_tables) out.sep = again;
+				else { out.sep = gather; out.path = DasPath_Gather; why[DasPath_Staged] = "global transmit table too large and no LDS-table shape fits"; }
+			}
+		}
+		if (out.path == DasPath_Staged) why[DasPath_Gather] = "superseded by the LDS-staged kernel";
+		why[DasPath_Hercules] = "not a HERCULES-family acquisition";
+		if (why[DasPath_Factored].empty()) why[DasPath_Factored] = "superseded by the separable-delay kernels";
+		why[DasPath_General] = "a specialised kernel applies";
+		out.valid = true;
+		return;
+	}
+	if (das_mode != 1) {
+		BfHerculesArgs hq{};
+		if (plan_hercules(a, tx, bp.xdc_transform, plan.das_voxel_transform, zcount, das_mode == 6, hq)) {
+			hq.zero_offset = (uint32_t)out.das_input_bytes;
+			/* linear / cubic interpolation of IQ samples may read a prepared copy of the input ({sample, difference}, 16 bytes; cubic: the
+			 * four polynomial coefficients of every segment, 32 bytes; 32-bit byte offsets: under 4 GiB).  Not on coarse grids: the copy
+			 * is 2-4 x the RF, and where every lane reads its own cache line the memory system pays for the bytes -- the harness's view
+			 * plane with cubic polynomials: 28.1 ms, 158 GB from beyond L2 per frame; with the taps gathered from the RF itself 25.2 ms */
+			const uint64_t prepared = out.das_input_bytes * (a.interpolation == 2 ? 4u : 2u);
+			out.hercules_prepared = plan.iq_pipeline && (a.interpolation == 1 || a.interpolation == 2) && prepared + 64 < (1ull << 32) &&
+			                        lane_step_samples(to_xdc, a) < 1.0f && !hooks().hercules_nopairs;
+			out.herc = hq;
+			out.path = DasPath_Hercules;
+			why[DasPath_General] = "a specialised kernel applies";
+			if (why[DasPath_Factored].empty()) why[DasPath_Factored] = "the sample index is not a receive term plus a transmit term (HERCULES)";
+			out.valid = true;
+			return;
+		}
+		why[DasPath_Hercules] = a.family != BF_DAS_HERCULES ? "not a HERCULES-family acquisition"
+		                      : a.split_shift ? "a small frame: the general kernel's channel split fills the chip better"
+		                      : "grid narrower than 32 voxels along x / more than 25 % idle lanes, or no transducer axis is a function of the output row alone";
+	}
+	if (factored) {
+		a.zero_offset = (uint32_t)out.das_input_bytes;
+		/* wave-span staging (das_factored.hip): on COARSE grids -- a voxel step along x of a sample of delay or more, as the
+		 * reference harness's 0.23 mm pixels have (tests/throughput.c:20-23) -- the lanes of a gather land in 64 different
+		 * places and the per-wave LDS-DMA copy of the span is cheaper (harness frames: 0.90-0.93 of the gather loop's time;
+		 * on config 2's fine grid 1.13: not taken there).  das path bit 0x40 forces it wherever the kernel supports it, 0x80
+		 * keeps the gather loop (tests: the two frames are bit-identical). */
+		const bool span_ok = plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && out.das_input_bytes < (1ull << 32);
+		if (span_ok && !(mode & 0x80) && ((mode & 0x40) || lane_step_samples(to_xdc, a) >= 1.0f)) {
+			a.span_stage = 1;
+			/* a wave = 64 voxels along the first lateral axis, the block's four waves stacked along depth */
+			uint32_t lat = a.tile_shift[0] >= a.tile_shift[1] ? 0u : 1u;
+			if (a.tile_shift[lat] > 6) {
+				uint32_t spare = a.tile_shift[lat] - 6;
+				a.tile_shift[lat] = 6;
+				for (int k = 0; k < 3 && spare; k++) {
+					if ((uint32_t)k == lat) continue;
+					uint32_t room = ceil_log2(ext[k]) - a.tile_shift[k];
+					uint32_t give = room < spare ? room : spare;
+					a.tile_shift[k] += give; spare -= give;
+				}
+				a.tile_shift[lat] += spare;
+				for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+				a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
+			}
+		}
+		out.path = DasPath_Factored;
+		why[DasPath_General] = "a specialised kernel applies";
+		out.valid = true;
+		return;
+	}
+	out.path = DasPath_General;
+	out.valid = true;
+}
+
+} // namespace bf

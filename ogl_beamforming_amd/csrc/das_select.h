@@ -1,0 +1,75 @@
+/* das_select.h -- which DAS kernel a frame runs, and why: ONE table of rules, host only (no HIP call), shared by the executor
+ * (which launches what it says), beamformer_hip_describe_das (which reports it, also without a device) and the tests (which ask
+ * instead of restating the rules).  Also the library's test / measurement hooks: the former BEAMFORMER_HIP_* environment reads,
+ * now one table filled from the environment ONCE and settable through beamformer_hip_set_hook. */
+#ifndef BF_DAS_SELECT_H
+#define BF_DAS_SELECT_H
+
+#include "planner.h"
+#include "bf_kernels.h"
+#include <string>
+#include <vector>
+
+namespace bf {
+
+/* BeamformerHipFrameTimings::das_path */
+enum DasPath {
+	DasPath_General = 0, DasPath_Gather = 1, DasPath_Staged = 2, DasPath_Factored = 3, DasPath_Retired = 4, DasPath_Hercules = 5,
+	DasPath_Count = 6,
+	DasPath_Zero = 7,             /* a family / interpolation the shader leaves at zero: the frame is cleared, no kernel */
+};
+const char *das_path_name(int path);      /* "LDS-staged kernel", ... */
+const char *das_kernel_name(int path);    /* "das_rca_staged_kernel", ... */
+
+constexpr uint32_t kStagedMinTransmits = 6;      /* das_staged.hip by default from this many transmits per channel (tools/staged_threshold.py,
+                                                    profiles/r02_staged_threshold.json: 1.15 of the gather kernel's time at 4 transmits, 0.91 at 8,
+                                                    0.84 at 12, 0.75 at 16, 0.69-0.71 at 32-75) */
+
+/* Test and measurement hooks (none is needed in production).  Read from the environment (BEAMFORMER_HIP_<NAME>) when first
+ * needed and never again; beamformer_hip_set_hook changes one at run time.  `version` counts changes: cached decisions carry it. */
+struct Hooks {
+	bool        loaded = false;
+	uint64_t    version = 1;
+	int         staged_shape[3] = {0, 0, 0};   /* STAGED_SHAPE="u,v,w": only 2^u x 2^v tiles with 2^w-sample windows (w = 48: the 48-sample window) */
+	bool        staged_shape_set = false;
+	bool        staged_checked = false;        /* STAGED_CHECKED: the range-checked loop for every wave (it also counts window violations) */
+	bool        staged_nouniform = false;      /* STAGED_NOUNIFORM: transmit tables in LDS also where the wave-uniform form applies */
+	bool        staged_w48 = false;            /* STAGED_W48: the wave-uniform form's 48-sample window where 32 samples are too few */
+	bool        staged_walk_column = false;    /* STAGED_WALK=column: plain depth-major walk for the wave-uniform form */
+	uint64_t    staged_table_cap = 2ull << 30; /* STAGED_TABLE_CAP=bytes: largest global transmit table taken (test: 0 forces the fallback) */
+	char        tile_walk = 0;                 /* TILE_WALK=plane / column: 'p' x, y, z; 'c' view planes walked depth fastest */
+	bool        hercules_fract = false;        /* HERCULES_FRACT: v_fract per pair instead of the per-lane phase reduction */
+	bool        hercules_nopairs = false;      /* HERCULES_NOPAIRS: never read the prepared copy of the DAS input */
+	bool        debug = false;                 /* DEBUG: one line per staged plan on stderr */
+};
+Hooks &hooks();
+bool   set_hook(const char *name, const char *value);       /* name without the BEAMFORMER_HIP_ prefix; value null or "" = unset; false: unknown name */
+const char *const *hook_names();                             /* null-terminated */
+
+struct DasDecision {
+	bool     valid = false;
+	uint64_t generation = 0, hooks_version = 0;              /* what it was computed for */
+	uint32_t z_first = 0, z_count = 0, mode = 0;
+	BfDasArgs a{};                      /* everything but the device pointers */
+	int      path = DasPath_General;
+	int      depth_axis = 2;
+	BfSeparableArgs sep{};              /* Gather: its geometry; Staged: the staged kernel's */
+	BfSeparableArgs sep_gather{};       /* Staged: what the gather kernel would run with -- the fallback when the staged kernel cannot be launched */
+	bool            has_lds_tables = false;
+	BfSeparableArgs sep_lds_tables{};   /* Staged with wave-uniform (global) tables: the shape with the tables in LDS, used when the table cannot be allocated */
+	BfHerculesArgs  herc{};
+	bool     hercules_prepared = false; /* Hercules: read the {sample, difference} / polynomial copy of the DAS input */
+	uint64_t das_input_bytes = 0;
+	std::string why[DasPath_Count];     /* why each kernel was not taken ("" for the one that runs and for kernels not considered) */
+};
+
+/* per-transmit constants of das.glsl:172-202 (host side; the executor uploads them) */
+std::vector<BfTransmit> build_transmit_table(const ParameterBlock &pb);
+
+/* Fills `out` for one DAS launch over planes [z_first, z_first + z_count) of the block's grid under das path `mode`
+ * (beamformer_hip_set_das_path).  Pure host arithmetic. */
+void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<BfTransmit> &transmits,
+                uint32_t z_first, uint32_t z_count, uint32_t mode, DasDecision &out);
+
+} // namespace bf
+#endif

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const bool  rx_rows = (t0.flags & BF_RX_ROWS) != 0;
 	[[maybe_unused]] const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+	if (q.depth_major & 2u) staged_violation_clear(tid);       /* STAGED_CHECKED: das_common.h */
 
 	/* UNI: the tile's slice of the global table: [A4] floors, {lo, hi} of the absolute delays, then per lateral row of the tile and
 	 * batch of 4 transmits 48 bytes: {T'' x 4}, {cos, sin} x 4 */
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 				 * 32-bit shift -- itself half rate, as it turned out -- instead of the 24-bit multiply: 0.721 of the gather kernel's
 				 * time against 0.710.  The multiply before the 16-bit shift: 0.701 against 0.700.) */
 				uint32_t m_bits = 0x4B000002u;
+				[[maybe_unused]] bool window_left = false;    /* range-checked loop: some term selected an element outside its window */
 				const f32x2 rr = {r_rel, r_rel};
 				/* UNI: the wave's row of the global table (lv = tid >> 6 for a 64-wide tile), read through the constant address
 				 * space so that the uniform reads become s_load_dwordx8 + s_load_dwordx4 per batch */
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 						if constexpr (CHECK) {
 							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfloor[cl] + tfl[a + k]);      /* yb - m_bits = round(p) */
 							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 16u : (stage_elements + 2u) * 16u;
+							window_left |= __builtin_amdgcn_ballot_w64((yb - m_bits) > W - 2u) != 0ull;      /* (wave uniform: a scalar) never, unless plan_staged's bound is wrong */
 						}
 					}
 					#pragma unroll
@@ -472,6 +475,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 					const float q3 = term(f32x2{cs23.z, cs23.w}, p23.y, tap[3]);
 					if constexpr (CW) { mag2 += f32x2{q0, q1}; mag2 += f32x2{q2, q3}; }
 				}
+				if constexpr (CHECK) { if (window_left) staged_violation_raise(); }
 			};
 			if (wave_safe) batches(std::false_type{});
 			else           batches(std::true_type{});
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			if constexpr (CW) incoherent = __builtin_fmaf(__builtin_fabsf(r.w), mag2.x + mag2.y, incoherent);
 		}
 	}
+	if (q.depth_major & 2u) staged_violation_report(tid);      /* (block uniform: every thread reaches it) */
 	if (!inside) return;
 
 	uint32_t x, y, lane_u_unused, thread = tid;

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 	const float phase_k = p.demodulation_frequency * p.inv_sampling_frequency;
 	const BfTransmit t0 = p.transmits[0];
 	const bool  rx_rows = (t0.flags & BF_RX_ROWS) != 0;
-	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
+	[[maybe_unused]] const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+	if (q.depth_major & 2u) staged_violation_clear(tid);       /* STAGED_CHECKED: das_common.h */
 
 	/* ---- transmit tables (absolute delays first) */
 	for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
@@ -226,29 +227,41 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 	for (int c0 = 0; c0 < C; c0 += chunk) {
 		const int cn = (C - c0) < chunk ? (C - c0) : chunk;
 		__syncthreads();        /* readers of the previous chunk's R / stage are done; the transmit tables are complete */
+		{
+		/* the ~45 scalars of the receive-table build come from the kernel-argument segment at the top of every chunk instead of
+		 * living in SGPRs across the channel loop (das_staged.hip) */
+		typedef __attribute__((address_space(4))) const BfDasArgs const_args;
+		const_args *ka = (const_args *)__builtin_amdgcn_kernarg_segment_ptr();
+		asm volatile("" : "+s"(ka));
+		const float k_denom_u = fmaxf(1.0f, (float)ka->size[u_axis] - 1.0f);
+		const float k_pz = (float)z / fmaxf(1.0f, (float)ka->size[2] - 1.0f);
+		const float k_fs = ka->sampling_frequency, k_inv_c = ka->inv_speed_of_sound, k_c = ka->speed_of_sound, k_fnum = ka->f_number;
+		const float k_phase = ka->demodulation_frequency * ka->inv_sampling_frequency;
+		const float k_pitch = rx_rows ? ka->pitch[1] : ka->pitch[0];
 		for (uint32_t e = tid; e < (uint32_t)cn * U; e += nthreads) {
 			uint32_t c = (uint32_t)c0 + (e >> q.u_shift), iu = e & (U - 1);
-			float coord[3] = {0.f, 0.f, pz};
-			coord[u_axis] = (float)(tu * U + iu) / denom[u_axis];
+			float coord[3] = {0.f, 0.f, k_pz};
+			coord[u_axis] = (float)(tu * U + iu) / k_denom_u;
 			float wx, wy, wz, xx, xy, xz;
-			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
-			m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+			m4_point(ka->voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			m4_point(ka->xdc_transform, wx, wy, wz, xx, xy, xz);
 			float lateral = rx_rows ? xy : xx;
-			float dx      = lateral - (float)c * rx_pitch;
-			float a_arg   = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(xz))));
+			float dx      = lateral - (float)c * k_pitch;
+			float a_arg   = __builtin_fabsf(dx * (k_fnum * hw_rcp(__builtin_fabsf(xz))));
 			/* the delay is kept for lanes outside the aperture too: it keeps their (discarded)
 			 * LDS reads inside the window */
-			float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), p) * p.sampling_frequency;
+			float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), k_inv_c, k_c) * k_fs;
 			f32x4 entry = {r_idx, 0.f, 0.f, 0.f};
 			if (a_arg < 0.5f) {
 				float cs    = hw_cos_turns(0.5f * a_arg);
 				float apod  = cs * cs;
-				float turns = cubic_phase_turns(phase_k, r_idx);
+				float turns = cubic_phase_turns(k_phase, r_idx);
 				entry.y = apod * hw_cos_turns(turns);
 				entry.z = apod * hw_sin_turns(turns);
 				entry.w = apod;
 			}
 			R[e] = entry;
+		}
 		}
 		__syncthreads();
 		for (uint32_t cl = tid; cl < (uint32_t)cn; cl += nthreads) {
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 				/* y = p + M, M = 2^23 + 2 + a*W: the element index 2 + a*W + round(p) in the low mantissa bits (das_staged.hip
 				 * explains the bias and the ties); the element's LDS byte address is (bits(y) & 0xFFFFFF) * 32; g = p - (y - M). */
 				uint32_t m_bits = 0x4B000002u;
+				[[maybe_unused]] bool window_left = false;    /* range-checked loop: some term selected an element outside its window */
 				const f32x2 rr = {r_rel, r_rel};
 				for (int a = 0; a < A4; a += 4, tcs_at += 2u * V * 16u, tz_at += 2u * V * 8u, m_bits += 4u * W) {
 					uint32_t at[4]; f32x4 lo[4], hi[4];
@@ -332,6 +346,7 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 							/* segment n = round(p) is window sample n: absolute tap k = n - 1 + the two floors; valid for 1 <= k < S - 2 */
 							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) - 1 + rfloor[cl] + tfl[a + k]);
 							at[k] = (k_abs - 1u) < (uint32_t)(S - 3) ? at[k] + (uint32_t)k * W * 32u : (stage_elements + 2u) * 32u;
+							window_left |= __builtin_amdgcn_ballot_w64((yb - m_bits) - 1u > W - 4u) != 0ull;      /* (wave uniform: a scalar) never, unless plan_staged's bound is wrong */
 						}
 					}
 					#pragma unroll
@@ -346,6 +361,7 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 					const float q3 = term(f32x2{cs23.z, cs23.w}, g23.y, lo[3], hi[3]);
 					if constexpr (CW) { mag2 += f32x2{q0, q1}; mag2 += f32x2{q2, q3}; }
 				}
+				if constexpr (CHECK) { if (window_left) staged_violation_raise(); }
 			};
 			if (wave_safe) batches(std::false_type{});
 			else           batches(std::true_type{});
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 			if constexpr (CW) incoherent = __builtin_fmaf(__builtin_fabsf(r.w), mag2.x + mag2.y, incoherent);
 		}
 	}
+	if (q.depth_major & 2u) staged_violation_report(tid);      /* (block uniform: every thread reaches it) */
 	if (!inside) return;
 
 	uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;

@@ -63,8 +63,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 	const float pz = (float)z / denom[2];
 	const BfTransmit t0 = p.transmits[0];
 	const bool  rx_rows = (t0.flags & BF_RX_ROWS) != 0;
-	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
+	[[maybe_unused]] const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
 	const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+	if (q.depth_major & 2u) staged_violation_clear(tid);       /* STAGED_CHECKED: das_common.h */
 
 	/* ---- transmit delays (absolute first) */
 	for (uint32_t e = tid; e < (uint32_t)A4 * V; e += nthreads) {
@@ -170,20 +171,31 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 	for (int c0 = 0; c0 < C; c0 += chunk) {
 		const int cn = (C - c0) < chunk ? (C - c0) : chunk;
 		__syncthreads();
+		{
+		/* the ~45 scalars of the receive-table build come from the kernel-argument segment at the top of every chunk instead of
+		 * living in SGPRs across the channel loop (das_staged.hip) */
+		typedef __attribute__((address_space(4))) const BfDasArgs const_args;
+		const_args *ka = (const_args *)__builtin_amdgcn_kernarg_segment_ptr();
+		asm volatile("" : "+s"(ka));
+		const float k_denom_u = fmaxf(1.0f, (float)ka->size[u_axis] - 1.0f);
+		const float k_pz = (float)z / fmaxf(1.0f, (float)ka->size[2] - 1.0f);
+		const float k_fs = ka->sampling_frequency, k_inv_c = ka->inv_speed_of_sound, k_c = ka->speed_of_sound, k_fnum = ka->f_number;
+		const float k_pitch = rx_rows ? ka->pitch[1] : ka->pitch[0];
 		for (uint32_t e = tid; e < (uint32_t)cn * U; e += nthreads) {
 			uint32_t c = (uint32_t)c0 + (e >> q.u_shift), iu = e & (U - 1);
-			float coord[3] = {0.f, 0.f, pz};
-			coord[u_axis] = (float)(tu * U + iu) / denom[u_axis];
+			float coord[3] = {0.f, 0.f, k_pz};
+			coord[u_axis] = (float)(tu * U + iu) / k_denom_u;
 			float wx, wy, wz, xx, xy, xz;
-			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
-			m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+			m4_point(ka->voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			m4_point(ka->xdc_transform, wx, wy, wz, xx, xy, xz);
 			float lateral = rx_rows ? xy : xx;
-			float dx      = lateral - (float)c * rx_pitch;
-			float a_arg   = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(xz))));
-			float r_idx   = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), p) * p.sampling_frequency;
+			float dx      = lateral - (float)c * k_pitch;
+			float a_arg   = __builtin_fabsf(dx * (k_fnum * hw_rcp(__builtin_fabsf(xz))));
+			float r_idx   = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), k_inv_c, k_c) * k_fs;
 			float apod    = 0.f;
 			if (a_arg < 0.5f) { float cs = hw_cos_turns(0.5f * a_arg); apod = cs * cs; }
 			R[e] = f32x2{r_idx, apod};
+		}
 		}
 		__syncthreads();
 		for (uint32_t cl = tid; cl < (uint32_t)cn; cl += nthreads) {
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 				const uint32_t lane_v = u_axis == 0 ? lane_id >> q.u_shift : lane_id & (V - 1);
 				uint32_t tz_at = tz_base + (lane_v << 3);
 				uint32_t m_bits = 0x4B000002u;               /* 2^23 + 2: das_staged.hip explains the rounding and the bias */
+				[[maybe_unused]] bool window_left = false;    /* range-checked loop: some term selected an element outside its window */
 				const f32x2 rr = {r_rel, r_rel};
 				for (int a = 0; a < A4; a += 4, tz_at += 2u * V * 8u, m_bits += 4u * W) {
 					uint32_t at[4]; f32x2 tap[4];
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 						if constexpr (CHECK) {
 							uint32_t k_abs = (uint32_t)((int)(yb - m_bits) + rfloor[cl] + tfl[a + k]);      /* yb - m_bits = round(p) */
 							at[k] = k_abs < ulast ? at[k] + (uint32_t)k * W * 8u : (stage_elements + 2u) * 8u;
+							window_left |= __builtin_amdgcn_ballot_w64((yb - m_bits) > W - 2u) != 0ull;      /* (wave uniform: a scalar) never, unless plan_staged's bound is wrong */
 						}
 					}
 					#pragma unroll
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 						mag2 += f32x2{__builtin_fabsf(sv[2]), __builtin_fabsf(sv[3])};
 					}
 				}
+				if constexpr (CHECK) { if (window_left) staged_violation_raise(); }
 			};
 			if (wave_safe) batches(std::false_type{});
 			else           batches(std::true_type{});
@@ -269,6 +284,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_real_kernel(const BfDa
 			if constexpr (CW) incoherent = __builtin_fmaf(mag2.x + mag2.y, apod, incoherent);
 		}
 	}
+	if (q.depth_major & 2u) staged_violation_report(tid);      /* (block uniform: every thread reaches it) */
 	if (!inside) return;
 
 	uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;

@@ -164,7 +164,7 @@ static void release_one_device(Device &d)
 	for (auto &b : d.rf) b.release();
 	for (auto &b : d.scratch) b.release();
 	d.ring.release(); d.pair_counter.release(); d.minmax_scratch.release(); d.sum_scratch.release();
-	d.hercules_table.release(); d.hercules_pairs.release(); d.staged_tables.release();
+	d.hercules_table.release(); d.hercules_pairs.release(); d.staged_tables.release(); d.staged_violations.release();
 	for (auto &g : d.frame_exec) { if (g) (void)hipGraphExecDestroy(g); g = nullptr; }
 	for (auto &g : d.graph_generation) g = 0;
 	for (auto &t : d.timing) {
@@ -228,23 +228,7 @@ static PlanState *commit_block(uint32_t block)
 
 	/* per-transmit constants (das.glsl:172-202) */
 	uint32_t A = bp.acquisition_count;
-	ps.transmit_table.assign(A, BfTransmit{});
-	for (uint32_t a = 0; a < A; a++) {
-		uint32_t txrx  = bp.single_orientation ? (bp.transmit_receive_orientation & 0xFFu) : pb.transmit_receive_orientations[a];
-		float    angle = bp.single_focus ? bp.focal_vector[0] : pb.focal_vectors[a][0];
-		float    depth = bp.single_focus ? bp.focal_vector[1] : pb.focal_vectors[a][1];
-		uint32_t tx = (txrx >> 4) & 0xF, rx = txrx & 0xF;
-		BfTransmit &t = ps.transmit_table[a];
-		float rad = angle * 0.017453292519943295f;               /* GLSL radians() */
-		t.sin_a = sinf(rad); t.cos_a = cosf(rad);
-		t.flags = 0;
-		if (tx == BeamformerRCAOrientation_None)    t.flags |= BF_TX_NONE;
-		if (tx == BeamformerRCAOrientation_Rows)    t.flags |= BF_TX_ROWS;
-		if (rx == BeamformerRCAOrientation_Rows)    t.flags |= BF_RX_ROWS;
-		if (rx == BeamformerRCAOrientation_Columns) t.flags |= BF_RX_COLUMNS;
-		if (std::isinf(depth)) { t.flags |= BF_TX_PLANE; t.focus_x = t.focus_z = 0; }
-		else                   { t.focus_x = depth * t.sin_a; t.focus_z = depth * t.cos_a; }
-	}
+	ps.transmit_table = build_transmit_table(pb);
 	ok &= upload(ps.transmits, ps.transmit_table.data(), sizeof(BfTransmit) * A, s);
 
 	if (!ps.plan.hadamard_t.empty())
@@ -289,6 +273,7 @@ static PlanState *commit_block(uint32_t block)
 	if (clears_dirty) pb.dirty = 0;
 	ps.valid = true;
 	ps.generation++;
+	ps.das.valid = false;
 	return &ps;
 }
 
@@ -313,372 +298,12 @@ static FrameRecord *next_frame(const uint32_t points[3], bool complex_frame, uin
 	return f;
 }
 
-static uint32_t ceil_log2(uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; }
-
-/* Shape of the 2^tile_log2-voxel block of the DAS launch.  The axis along which the transducer-space
- * depth changes fastest gets extent 1: sample indices move ~2 samples per voxel along depth
- * but only a fraction of a sample per voxel laterally, so a depth-flat tile keeps the 64 lanes
- * of a wave within a few cache lines of every (channel, transmit) row. */
-static int choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32_t zcount, uint32_t shift[3], uint32_t tile_log2 = 8)
-{
-	uint32_t extent[3] = {size[0], size[1], zcount};
-	uint32_t full[3]   = {size[0], size[1], size[2]};
-	int depth = -1; float best = -1;
-	for (int i = 0; i < 3; i++) {
-		if (extent[i] <= 1) continue;
-		float step = std::fabs(voxel_to_xdc[4 * i + 2]) / (float)(full[i] > 1 ? full[i] - 1 : 1);
-		if (step > best) { best = step; depth = i; }
-	}
-	uint32_t cap[3], left = tile_log2;
-	for (int i = 0; i < 3; i++) { cap[i] = ceil_log2(extent[i]); shift[i] = 0; }
-	int lateral[2], nl = 0;
-	for (int i = 0; i < 3; i++) if (i != depth && extent[i] > 1) lateral[nl++] = i;
-	uint32_t first = nl == 2 ? tile_log2 / 2 : tile_log2;
-	for (int k = 0; k < nl; k++) {
-		uint32_t give = cap[lateral[k]] < first ? cap[lateral[k]] : first;
-		if (give > left) give = left;
-		shift[lateral[k]] = give; left -= give;
-	}
-	for (int k = 0; k < nl && left; k++) {
-		uint32_t room = cap[lateral[k]] - shift[lateral[k]];
-		uint32_t give = room < left ? room : left;
-		shift[lateral[k]] += give; left -= give;
-	}
-	if (depth >= 0 && left) {
-		uint32_t give = cap[depth] < left ? cap[depth] : left;
-		shift[depth] = give; left -= give;
-	}
-	shift[0] += left;   /* fewer voxels in total than the tile: idle lanes */
-	return depth;
-}
-
-/* tile walk of the kernels that deal tiles to the XCDs in contiguous runs: the depth axis runs fastest, so that a run is a
- * lateral column at every depth (neighbouring RF windows AND the same work on every XCD: the f-number test culls shallow
- * voxels).  Volumes: depth = voxel z (1); the reference's view planes (math.c:844-885) put it on voxel y (2). */
-static uint32_t tile_walk(int depth_axis, uint32_t zcount, uint32_t tile_rows, uint32_t &band_rows)
-{
-	band_rows = 1;
-	const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");     /* "plane": x -> y -> z, "column": y fastest on view planes (measurement aids) */
-	if (walk && walk[0] == 'p') return 0u;
-	if (depth_axis != 1) return 1u;
-	if (zcount != 1 || (walk && walk[0] == 'c')) return 2u;
-	/* view plane: ~32 bands, four per XCD (bf_plane_walk) */
-	band_rows = tile_rows / 32u ? tile_rows / 32u : 1u;
-	return 3u;
-}
-
-/* Samples of delay one voxel step along x (the lane axis of the per-voxel kernels) can move a sample index: the physical
- * length of the step times fs / c.  >= 1: a COARSE grid -- neighbouring lanes read different samples of an RF row. */
-static float lane_step_samples(const float *voxel_to_xdc, const BfDasArgs &a)
-{
-	const float n = (float)(a.size[0] > 1 ? a.size[0] - 1 : 1);
-	const float dx = voxel_to_xdc[0] / n, dy = voxel_to_xdc[1] / n, dz = voxel_to_xdc[2] / n;
-	return std::sqrt(dx * dx + dy * dy + dz * dz) * a.sampling_frequency * a.inv_speed_of_sound;
-}
-
-/* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
- * receive and one transmit orientation for all transmits, on different transducer axes, a
- * volume whose z axis alone carries depth, and voxel x / y axes that each move only one of
- * the two lateral coordinates -- every coefficient that must vanish has to be an exact
- * zero product, so that the tables reproduce the general kernel's per-voxel arithmetic. */
-static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
-                           uint32_t zcount, BfSeparableArgs &q)
-{
-	if (a.family != BF_DAS_RCA || tx.empty()) return false;
-	const uint32_t orient = BF_TX_ROWS | BF_RX_ROWS | BF_TX_NONE;
-	for (const BfTransmit &t : tx) if ((t.flags & orient) != (tx[0].flags & orient)) return false;
-	const bool tx_none = (tx[0].flags & BF_TX_NONE) != 0;
-	const int  r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0;      /* transducer coordinate the receive aperture uses */
-	const int  w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;      /* world coordinate the transmit uses */
-	auto W = [&](int row, int col) { return vox[4 * col + row]; };
-	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
-	/* transducer coordinate `row` must not move with voxel axis `col` */
-	auto xdc_fixed = [&](int row, int col) {
-		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return false;
-		return true;
-	};
-	if (a.size[0] < 2 || a.size[1] < 2) return false;
-	for (int col = 0; col < 2; col++) {
-		if (!xdc_fixed(2, col)) return false;                 /* transducer depth: voxel z only */
-		if (!tx_none && W(2, col) != 0.f) return false;       /* world depth: voxel z only */
-	}
-	int u_axis = -1;
-	for (int u = 0; u < 2 && u_axis < 0; u++) {
-		int v = 1 - u;
-		if (!xdc_fixed(r, v)) continue;                       /* receive lateral: not along v */
-		if (!tx_none && W(w, u) != 0.f) continue;             /* transmit lateral: not along u */
-		u_axis = u;
-	}
-	if (u_axis < 0) return false;
-
-	/* Tile (U along the receive axis, V along the transmit axis), block size and the number of
-	 * channels per receive-table chunk: maximise resident waves per CU (LDS: 160 KB per CU, 32
-	 * waves per CU), then prefer big chunks (fewer rebuilds) and square-ish tiles. */
-	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
-	const uint32_t lds_cu = 160u * 1024u;
-	uint32_t best_waves = 0, best_score = 0;
-	for (uint32_t threads_shift = 10; threads_shift >= 8; threads_shift--) {
-		for (uint32_t us = 2; us + 2 <= threads_shift; us++) {
-			uint32_t vs = threads_shift - us;
-			if ((u_axis == 0 ? us : vs) < 4) continue;        /* >= 16 lanes of a wave along x */
-			for (uint32_t chunk = 16; chunk <= 256; chunk *= 2) {
-				uint32_t cc = chunk < C ? chunk : C;
-				uint64_t lds = 16ull * (((uint64_t)cc << us) + ((uint64_t)A << vs));
-				if (lds > lds_cu) continue;
-				uint32_t blocks = (uint32_t)(lds_cu / lds);
-				uint32_t by_waves = 2048u >> threads_shift;
-				if (blocks > by_waves) blocks = by_waves;
-				uint32_t waves = blocks << (threads_shift - 6);
-				uint32_t balance = us > vs ? us - vs : vs - us;
-				uint32_t score = (cc << 4) + (16 - balance);
-				if (waves > best_waves || (waves == best_waves && score > best_score)) {
-					best_waves = waves; best_score = score;
-					q.u_shift = us; q.v_shift = vs; q.threads = 1u << threads_shift;
-					q.channel_chunk = cc; q.lds_bytes = (uint32_t)lds;
-				}
-				if (cc == C) break;
-			}
-		}
-	}
-	if (!best_waves) return false;
-	q.u_axis = (uint32_t)u_axis;
-	{
-		/* BEAMFORMER_HIP_TILE_WALK=plane restores the x -> y -> z walk (measurement aid) */
-		const char *walk = std::getenv("BEAMFORMER_HIP_TILE_WALK");
-		q.depth_major = !(walk && walk[0] == 'p');
-	}
-	const uint32_t best_u = q.u_shift, best_v = q.v_shift;
-	uint32_t nu = a.size[u_axis], nv = a.size[1 - u_axis];
-	q.tiles[0] = (nu + (1u << best_u) - 1) >> best_u;
-	q.tiles[1] = (nv + (1u << best_v) - 1) >> best_v;
-	q.tiles[2] = zcount;
-	return true;
-}
-
-/* Upgrade a separable plan to the LDS-staged kernel (das_staged.hip) when the delay spread of a
- * tile provably fits the staging window.  The receive delay is a distance, so it changes by at
- * most one lateral voxel step (in samples) per voxel along u; the transmit delay likewise along
- * v, scaled by max|sin(angle)| when every transmit is a plane wave. */
-static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
-                        uint32_t zcount, BfSeparableArgs &q, bool allow_uniform = true)
-{
-	const bool cplx = a.complex_data != 0;                       /* das_staged.hip / das_staged_real.hip */
-	const bool cubic = a.interpolation == 2;                     /* das_staged_cubic.hip: complex samples only */
-	if (a.interpolation != 1 && !(cubic && cplx)) return false;
-	const uint32_t C = (uint32_t)a.channel_count, A = (uint32_t)a.acquisition_count;
-	/* the kernels stage through 32-bit buffer offsets and park their padding loads at 2^31 */
-	if ((uint64_t)C * A * (uint64_t)a.sample_count * (cplx ? 8u : 4u) >= (1ull << 31)) return false;
-	const uint32_t A4 = (A + 3u) & ~3u;                          /* the kernel pads the transmit table to whole batches of 4 */
-	const int u_axis = (int)q.u_axis, v_axis = 1 - u_axis;
-	const int r = (tx[0].flags & BF_RX_ROWS) ? 1 : 0, w = (tx[0].flags & BF_TX_ROWS) ? 1 : 0;
-	float m[16];
-	m4_mul(xdc, vox, m);
-	const float samples_per_metre = a.sampling_frequency * a.inv_speed_of_sound;
-	float step_u = std::fabs(m[4 * u_axis + r]) / (float)(a.size[u_axis] > 1 ? a.size[u_axis] - 1 : 1) * samples_per_metre;
-	float step_v = std::fabs(vox[4 * v_axis + w]) / (float)(a.size[v_axis] > 1 ? a.size[v_axis] - 1 : 1) * samples_per_metre;
-	bool all_plane = true; float max_sin = 0.f;
-	for (const BfTransmit &t : tx) {
-		all_plane &= (t.flags & BF_TX_PLANE) != 0;
-		max_sin = std::fmax(max_sin, std::fabs(t.sin_a));
-	}
-	if (tx[0].flags & BF_TX_NONE) step_v = 0.f;
-	else if (all_plane)           step_v *= max_sin;
-
-	const uint32_t lds_cu = 160u * 1024u;
-	uint32_t best_waves = 0, best_score = 0;
-	BfSeparableArgs best = q;
-	for (uint32_t threads_shift = 10; threads_shift >= 9; threads_shift--) {
-		for (uint32_t vs = 4; vs <= 6; vs++) {
-			if (vs + 4 > threads_shift) continue;
-			uint32_t us = threads_shift - vs;
-			if (us > 6) continue;
-			if ((u_axis == 0 ? us : vs) < 4) continue;
-			float spread = step_u * (float)((1u << us) - 1) + step_v * (float)((1u << vs) - 1);
-			if (!(spread >= 0.f && spread <= 60.f)) continue;                /* also a NaN / infinite spread (wild parameters) */
-			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + (cubic ? 6 : 4);   /* + taps (k - 1 .. k + 2 for cubic), floors, rounding slack */
-			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
-			if (!ws) continue;
-			/* BEAMFORMER_HIP_STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
-			 * a window larger than needed is legal, a smaller one is not taken; ws = 48: the uniform variant's 48-sample window) */
-			bool force_w48 = false;
-			if (const char *force = std::getenv("BEAMFORMER_HIP_STAGED_SHAPE")) {
-				unsigned fu = 0, fv = 0, fw = 0;
-				if (std::sscanf(force, "%u,%u,%u", &fu, &fv, &fw) == 3) {
-					if (fu != us || fv != vs) continue;
-					if (fw == 48) { if (need > 48) continue; force_w48 = true; }
-					else { if (fw < ws || fw > 6) continue; ws = fw; }
-				}
-			}
-			/* complex samples, linear interpolation, x along the receive axis and a 64 x 16 tile: a wave's lanes share one row of the
-			 * transmit axis, the transmit tables leave the LDS for a global table read through scalar loads (das_staged.hip, UNI).
-			 * Measured faster than every other shape, so it is preferred wherever its window fits -- with a
-			 * 48-sample window where 32 samples are too few (64-sample windows of 64 and more transmits leave no room for two
-			 * blocks per CU): 63 elements per wave and pass, at most 4 passes of the 16 waves */
-			const bool uniform = allow_uniform && cplx && !cubic && u_axis == 0 && threads_shift == 10 && us == 6 && vs == 4 &&
-			                     !std::getenv("BEAMFORMER_HIP_STAGED_NOUNIFORM");
-			uint32_t window = 1u << ws;
-			/* (the 48-sample window is opt-in -- BEAMFORMER_HIP_STAGED_W48, or the shape hook: at config 4 it measured 799.0 ms against
-			 * 804.5 ms for the 32 x 32 tiles with the tables in LDS, but 726 GB of HBM-side traffic per launch against 176 GB) */
-			const bool want_w48 = force_w48 || (std::getenv("BEAMFORMER_HIP_STAGED_W48") && need > 32 && need <= 48);
-			if (uniform && want_w48 && (A4 * 48u + 62u) / 63u <= 64u) window = 48;
-			else if (force_w48) continue;
-			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
-			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
-			if (window != 48 && ((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
-			const uint64_t stage_elements = (uint64_t)A4 * window;
-			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
-				uint32_t cc = chunk < C ? chunk : C;
-				/* transmit tables 12 B per (transmit, v), receive table, {sample, difference} windows + a zero element, floors */
-				uint64_t lds = cubic ? 12ull * ((uint64_t)A4 << vs) + 16ull * ((uint64_t)cc << us) + 32ull * (stage_elements + 3) + 4ull * (A4 + cc + 1) + 128
-				             : cplx ? (uniform ? 0ull : 12ull * ((uint64_t)A4 << vs)) + 16ull * ((uint64_t)cc << us) + 16ull * (stage_elements + 3) + 4ull * (A4 + cc + 1) + 128
-				                    :  4ull * ((uint64_t)A4 << vs) +  8ull * ((uint64_t)cc << us) +  8ull * (stage_elements + 4) + 4ull * (A4 + cc + 1) + 128;
-				lds = (lds + 15) & ~15ull;
-				if (lds > lds_cu) continue;
-				uint32_t blocks = (uint32_t)(lds_cu / lds), by_waves = (cubic ? 1024u : 2048u) >> threads_shift;   /* (cubic: 128 VGPRs per lane) */
-				if (blocks > by_waves) blocks = by_waves;
-				uint32_t waves = blocks << (threads_shift - 6);
-				uint32_t balance = us > vs ? us - vs : vs - us;
-				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (window == 32 ? 500u : 0u) +
-				                 (uniform && window == 32 ? 2000u : uniform && window == 48 ? 1500u : 0u);
-				if (waves > best_waves || (waves == best_waves && score > best_score)) {
-					best_waves = waves; best_score = score;
-					best.u_shift = us; best.v_shift = vs; best.threads = 1u << threads_shift;
-					best.channel_chunk = cc; best.lds_bytes = (uint32_t)lds; best.window_shift = ws; best.window_samples = window;
-					best.uniform = uniform ? 1u : 0u;
-					best.table_stride = uniform ? 4u * A4 + 16u + 16u * (A4 / 4u) * 48u : 0u;
-				}
-				if (cc == C) break;
-			}
-		}
-	}
-	if (std::getenv("BEAMFORMER_HIP_STAGED_CHECKED")) best.depth_major |= 2u;
-	/* uniform variant: the two blocks of a CU are neighbours along u in one plane (shared rows of the global transmit table);
-	 * BEAMFORMER_HIP_STAGED_WALK=column keeps the plain depth-major walk (measurement aid) */
-	{
-		const char *walk = std::getenv("BEAMFORMER_HIP_STAGED_WALK");
-		if (best.uniform && (best.depth_major & 1u) && !(walk && walk[0] == 'c')) best.depth_major |= 4u;
-	}      /* test hook: the range-checked loop for every wave */
-	if (std::getenv("BEAMFORMER_HIP_DEBUG"))
-		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u uniform %u\n",
-		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_samples, best.channel_chunk, best.lds_bytes, best.uniform);
-	if (!best_waves) return false;
-	q = best;
-	uint32_t nu = a.size[u_axis], nv = a.size[v_axis];
-	q.tiles[0] = (nu + (1u << q.u_shift) - 1) >> q.u_shift;
-	q.tiles[1] = (nv + (1u << q.v_shift) - 1) >> q.v_shift;
-	q.tiles[2] = zcount;
-	return true;
-}
-
-/* Can this HERCULES-family frame use the aligned fast path (das_hercules.hip)?  The kernel lays
- * the 64 lanes of a wave along the output's x axis and reads the squared lateral distance along
- * the OTHER array axis from a per-output-row table, so one transducer lateral coordinate has to
- * be a function of the output row y alone: every product that would let voxel x or voxel z move
- * it must be an exact zero (then the table entry is bit-identical to the per-voxel value).
- * Everything else -- depth, the transmit distance, the coordinate along x -- stays per voxel. */
-static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *xdc, const float *vox,
-                          uint32_t zcount, bool forced, BfHerculesArgs &q)
-{
-	if (a.family != BF_DAS_HERCULES || tx.empty()) return false;
-	if (!forced) {
-		if (a.size[0] < 32 || a.split_shift) return false;       /* thin or tiny frames: the general kernel's channel split */
-		if (((a.size[0] + 63u) & ~63u) > a.size[0] + a.size[0] / 3u) return false;   /* > 25 % idle lanes */
-	}
-	auto W = [&](int row, int col) { return vox[4 * col + row]; };
-	auto X = [&](int row, int col) { return xdc[4 * col + row]; };
-	/* does transducer coordinate `row` move with voxel axis `col`?  An axis of one voxel moves nothing, whatever its
-	 * column of the transform holds: the view planes of math.c:844-885 keep their NORMAL there (das_transform_2d_xz: voxel z
-	 * = (0, 1, 0), size 1), and the reference's own harness beamforms exactly such a plane (tests/throughput.c:20, :443-446) */
-	auto moves = [&](int row, int col) {
-		if (a.size[col] <= 1) return false;
-		for (int k = 0; k < 3; k++) if (X(row, k) != 0.f && W(k, col) != 0.f) return true;
-		return false;
-	};
-	int inner = -1;
-	for (int coord = 0; coord < 2 && inner < 0; coord++)
-		if (!moves(coord, 0) && !moves(coord, 2)) inner = coord;
-	/* prefer the coordinate that does move with y when both qualify (a degenerate grid) */
-	if (inner == 0 && !moves(1, 0) && !moves(1, 2) && !moves(0, 1) && moves(1, 1)) inner = 1;
-	if (inner < 0) return false;
-	const bool rx_cols = (tx[0].flags & BF_RX_COLUMNS) != 0;
-	const int  tx_coord = rx_cols ? 1 : 0;                        /* das.glsl:238-247: transmit elements run along the other axis */
-	const uint32_t A = (uint32_t)a.acquisition_count, C = (uint32_t)a.channel_count;
-	const uint32_t transmits = A - (a.sparse ? 1u : 0u);
-	if (!transmits || !C) return false;
-	q.inner_coord       = (uint32_t)inner;
-	q.inner_is_transmit = inner == tx_coord;
-	q.inner_count       = q.inner_is_transmit ? transmits : C;
-	q.outer_count       = q.inner_is_transmit ? C : transmits;
-	q.table_pitch       = (q.inner_count + 8u + 3u) & ~3u;      /* the kernel prefetches one batch of 4 past the end */
-	q.tiles[0] = (a.size[0] + 63u) / 64u;
-	q.tiles[1] = (a.size[1] + 3u) / 4u;
-	q.tiles[2] = zcount;
-	{
-		/* the axis along which the transducer-space depth changes fastest (as choose_tile finds it) */
-		float m[16];
-		m4_mul(xdc, vox, m);
-		const uint32_t ext[3] = {a.size[0], a.size[1], zcount};
-		int depth = 2; float best = -1.f;
-		for (int i = 0; i < 3; i++) {
-			if (ext[i] <= 1) continue;
-			float step = std::fabs(m[4 * i + 2]) / (float)(a.size[i] > 1 ? a.size[i] - 1 : 1);
-			if (step > best) { best = step; depth = i; }
-		}
-		q.depth_major = tile_walk(depth, zcount, q.tiles[1], q.band_rows);
-	}
-	/* unit of length: among the 8193 floats nearest 1, the s2 whose k' = float(k / sqrt(s2)) reproduces
-	 * k = fs / c best as k' sqrt(s2) (errors are spread over +-3e-8, the best of 8193 lands near 1e-11).
-	 * Remembered per (fs, c): frames of one plan ask again every launch. */
-	{
-		static float cached_fs = 0.f, cached_c = 0.f, cached_s2 = 1.f, cached_k = 0.f;
-		if (cached_fs != a.sampling_frequency || cached_c != a.speed_of_sound) {
-			const double k_exact = (double)a.sampling_frequency / (double)a.speed_of_sound;
-			double best = 1e9;
-			for (int i = -4096; i <= 4096; i++) {
-				uint32_t bits = 0x3F800000u + (uint32_t)i;              /* floats around 1.0f in ulp steps */
-				float s2; std::memcpy(&s2, &bits, sizeof s2);
-				double s  = std::sqrt((double)s2);
-				float  kk = (float)(k_exact / s);
-				double err = std::fabs((double)kk * s / k_exact - 1.0);
-				if (err < best) { best = err; cached_s2 = s2; cached_k = kk; }
-			}
-			cached_fs = a.sampling_frequency; cached_c = a.speed_of_sound;
-		}
-		q.unit_scale2 = cached_s2; q.samples_per_unit = cached_k;
-	}
-	{
-		/* distances to two elements of the inner axis differ by at most their separation: at most 255 pitches (dense or
-		 * sparse element indices alike), i.e. this many turns of demodulation phase inside one inner loop */
-		const float span_turns = std::fabs(a.turns_per_sample) * 255.0f * std::fabs(a.pitch[inner]) * a.sampling_frequency * a.inv_speed_of_sound;
-		q.phase_local = a.complex_data && span_turns < 400.0f &&       /* (false for a NaN) */
-		                !std::getenv("BEAMFORMER_HIP_HERCULES_FRACT");  /* measurement aid: v_fract per pair */
-	}
-	return true;
-}
-
-/* Can the per-voxel factored kernel (das_factored.hip) take this frame?  It needs the sample
- * index to be a receive term plus a transmit term: RCA-family frames whose transmits all share
- * one receive orientation, and FORCES/UFORCES.  With fewer than three transmits per channel
- * chunk the receive factors are not amortised and the general kernel is as fast. */
-static bool factored_applies(const BfDasArgs &a, const std::vector<BfTransmit> &tx, uint32_t mode)
-{
-	if (mode == 1) return false;
-	int transmits = a.acquisition_count - (a.family == BF_DAS_FORCES && a.sparse ? 1 : 0);
-	if (transmits < 3 && mode != 4) return false;
-	if (a.family == BF_DAS_FORCES) return true;
-	if (a.family != BF_DAS_RCA || tx.empty()) return false;
-	for (const BfTransmit &t : tx)
-		if ((t.flags & BF_RX_ROWS) != (tx[0].flags & BF_RX_ROWS)) return false;
-	return true;
-}
-
 /* A timed HIP event costs ~4 us of stream time on this runtime (measured: a 0.26 MB / 256 x 256
  * frame takes 36.5 us with its five records and 15.7 us without), nothing next to a 3-D volume
  * and more than the kernels of a real-time 2-D frame.  Small frames therefore record their
  * per-stage events on one frame in kTimingSamplePeriod; the frames in between run with no event
  * at all and report the newest sampled timings in the stats table. */
 constexpr uint64_t kTimingSamplePeriod = 8;
-constexpr uint32_t kStagedMinTransmits = 6;      /* das_staged.hip by default from this many transmits per channel (tools/staged_threshold.py: 1.17 of the gather kernel's time at 4 transmits, 0.93 at 6-8, 0.85 at 10-12, 0.74 at 16, 0.68-0.71 at 32-75) */
 constexpr uint64_t kSmallFrameBytes    = 8ull << 20;
 
 static bool record(TimingSlot &t, uint32_t index, hipStream_t s)
@@ -861,169 +486,88 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				break;
 			}
 
-			BfDasArgs a{};
-			std::memcpy(a.xdc_transform,   bp.xdc_transform,         sizeof(a.xdc_transform));
-			std::memcpy(a.voxel_transform, plan.das_voxel_transform, sizeof(a.voxel_transform));
-			a.pitch[0] = bp.xdc_element_pitch[0]; a.pitch[1] = bp.xdc_element_pitch[1];
+			/* which kernel, with which geometry: one table of rules (das_select.cpp), computed once per plan / shard / path mode / hook
+			 * change and reused by every frame after it */
+			DasDecision &dd = ps->das;
+			if (!dd.valid || dd.generation != ps->generation || dd.z_first != zfirst || dd.z_count != zcount || dd.mode != c.das_path_mode ||
+			    dd.hooks_version != hooks().version) {
+				decide_das(pb, plan, ps->transmit_table, zfirst, zcount, c.das_path_mode, dd);
+				dd.generation = ps->generation;
+			}
+			BfDasArgs a = dd.a;
 			a.rf  = cur;
 			a.out = (char *)d.ring.ptr + f->offset;
 			a.transmits       = (const BfTransmit *)ps->transmits.ptr;
 			a.sparse_elements = (const int16_t *)ps->sparse.ptr;
 			a.readi_hadamard  = (const uint16_t *)ps->readi_hadamard.ptr;
-			switch (bp.acquisition_kind) {                                          /* das.glsl:381-400 */
-			case BeamformerAcquisitionKind_FORCES:
-			case BeamformerAcquisitionKind_UFORCES:
-				a.family = bp.readi_group_count > 1 ? BF_DAS_READI : BF_DAS_FORCES; break;
-			case BeamformerAcquisitionKind_HERCULES:
-			case BeamformerAcquisitionKind_UHERCULES:
-			case BeamformerAcquisitionKind_HERO_PA:
-				a.family = BF_DAS_HERCULES; break;
-			case BeamformerAcquisitionKind_Flash:
-			case BeamformerAcquisitionKind_RCA_TPW:
-			case BeamformerAcquisitionKind_RCA_VLS:
-				a.family = BF_DAS_RCA; break;
-			default: a.family = -1; break;      /* the shader leaves the voxel at zero */
-			}
-			a.interpolation = (int32_t)bp.interpolation_mode;
-			a.complex_data  = plan.iq_pipeline;
-			a.coherency_weighting = bp.coherency_weighting != 0;
-			a.acquisition_count = (int32_t)A; a.channel_count = (int32_t)C; a.sample_count = (int32_t)Sd;
-			a.sparse = plan.das_sparse;
-			a.sampling_frequency     = plan.das_sampling_frequency;
-			a.inv_sampling_frequency = 1.0f / plan.das_sampling_frequency;
-			a.demodulation_frequency = bp.demodulation_frequency;
-			a.inv_speed_of_sound     = 1.0f / bp.speed_of_sound;
-			a.speed_of_sound         = bp.speed_of_sound;
-			a.turns_per_sample       = bp.demodulation_frequency * a.inv_sampling_frequency;
-			a.first_transmit_weight  = 1.0f / sqrtf((float)A);
-			a.time_offset = plan.das_time_offset;
-			a.f_number    = bp.f_number;
-			a.size[0] = plan.output_points[0]; a.size[1] = plan.output_points[1]; a.size[2] = plan.output_points[2];
-			a.z_first = zfirst; a.z_count = zcount;
-			a.readi_group_count = bp.readi_group_count; a.readi_group = bp.readi_group;
+			const uint32_t ext[3] = {a.size[0], a.size[1], zcount};
+			das_path = (uint32_t)(dd.path == DasPath_Zero ? DasPath_General : dd.path);
+			uint64_t violations_slot = ~0ull;
 
-			float to_xdc[16];
-			if (a.family == BF_DAS_FORCES || a.family == BF_DAS_READI) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
-			else m4_mul(bp.xdc_transform, plan.das_voxel_transform, to_xdc);
-			uint32_t ext[3] = {a.size[0], a.size[1], zcount};
-			/* Small frames (real-time 2-D imaging) do not fill 256 CUs with one thread per voxel:
-			 * split the channel loop over K waves of a block (wave-level partial sums, combined
-			 * through LDS in split order) until the launch has ~16 waves per CU (config 1, us per
-			 * frame by target wave count: 2048 -> 19.9, 4096 -> 15.2, 8192 -> 15.1, 16384 -> 17.1). */
-			uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
-			a.split_shift = 0;
-			while (!(c.das_path_mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
-			const int depth_axis = choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
-			for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
-			a.depth_major = tile_walk(depth_axis, zcount, a.blocks[1], a.band_rows);
-
-			if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
+			if (dd.path == DasPath_Zero) {
 				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
 			} else {
-				BfSeparableArgs sep{};
-				/* The LDS-table kernel's hand-scheduled loop exists for linear interpolation; for cubic
-				 * and nearest its generic loop loses to the factored kernel (200 ch x 33 tx -> 129 x 333 x 21,
-				 * cubic: 7.6 ms against 4.8 ms; nearest 2.6 against 2.1), which then goes first. */
-				const uint32_t das_mode = c.das_path_mode & 0xF;
-				/* (cubic IQ frames with enough transmits try the staged cubic kernel first: it declines -- and the factored
-				 * kernel runs -- when the geometry is not separable or the delay spread does not fit a window) */
-				const bool staged_cubic = a.interpolation == 2 && plan.iq_pipeline && (das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits));
-				bool tables_first = a.interpolation == 1 || das_mode == 3 || staged_cubic ||
-				                    !factored_applies(a, ps->transmit_table, das_mode);
-				if (staged_cubic && das_mode != 3 && tables_first && a.interpolation == 2) {
-					BfSeparableArgs probe{};
-					if (!(plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, probe) &&
-					      plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, probe)))
-						tables_first = !factored_applies(a, ps->transmit_table, das_mode);
-				}
-				if (das_mode != 1 && das_mode != 4 && tables_first &&
-				    plan_separable(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep)) {
-					/* 64 zero bytes right behind the DAS input (every buffer it can live in is
-					 * allocated with that much slack): the gather target of out-of-range lanes */
-					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
-					sep.zero_offset = (uint32_t)used;
-					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					/* the LDS-staged kernel pays two block barriers and a window copy per channel: it wins once a channel
-					 * carries enough transmits to amortise them (kStagedMinTransmits, measured: tools/staged_threshold.py) */
-					const bool want_staged = das_mode == 3 || (das_mode == 0 && A >= kStagedMinTransmits);
-					bool staged = want_staged && plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, sep);
+				/* 64 zero bytes right behind the DAS input (every buffer it can live in is allocated with that much slack): the
+				 * gather target of out-of-range lanes */
+				const uint64_t used = dd.das_input_bytes;
+				if (dd.path != DasPath_General) ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
+				switch (dd.path) {
+				case DasPath_Staged:
+				case DasPath_Gather:{
+					BfSeparableArgs sep = dd.sep;
+					bool staged = dd.path == DasPath_Staged;
 					if (staged && sep.uniform) {
-						/* the wave-uniform transmit tables live in global memory: one slice per (lateral tile row, plane), written per frame
-						 * (a few MB to 244 MB at 512^3 with 75 transmits; too big or no memory: the shapes with the tables in LDS) */
+						/* the wave-uniform transmit tables live in global memory: one slice per (lateral tile row, plane), written per frame;
+						 * no memory: the shape with the tables in LDS, else the gather kernel with its own geometry */
 						const uint64_t table_bytes = (uint64_t)sep.table_stride * sep.tiles[1] * sep.tiles[2];
-						if (table_bytes <= (2ull << 30) && d.staged_tables.ensure(table_bytes)) {
+						if (d.staged_tables.ensure(table_bytes)) {
 							sep.tables = d.staged_tables.ptr;
 							ok &= HIP_OK(bf_launch_das_staged_tables(&a, &sep, s));
+						} else if (dd.has_lds_tables) {
+							sep = dd.sep_lds_tables;
 						} else {
-							BfSeparableArgs again = sep;
-							again.uniform = 0; again.table_stride = 0; again.tables = nullptr; again.depth_major &= ~4u;
-							staged = plan_staged(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, again, false);
-							if (staged) sep = again;
+							sep = dd.sep_gather; staged = false;
 						}
 					}
 					if (staged) {
+						/* window positions outside the staged window are counted (range-checked loop only: STAGED_CHECKED) */
+						ok &= d.staged_violations.ensure(sizeof(uint32_t) * kTimingSlots);
+						if (ok) {
+							sep.violations = (uint32_t *)d.staged_violations.ptr + (f->id % kTimingSlots);
+							ok &= HIP_OK(hipMemsetAsync(sep.violations, 0, sizeof(uint32_t), s));
+							violations_slot = f->id % kTimingSlots;
+						}
 						ok &= HIP_OK(!plan.iq_pipeline ? bf_launch_das_staged_real(&a, &sep, s) :
 						             a.interpolation == 2 ? bf_launch_das_staged_cubic(&a, &sep, s) : bf_launch_das_staged(&a, &sep, s));
-						das_path = 2;
+						das_path = DasPath_Staged;
 					} else {
 						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
-						das_path = 1;
+						das_path = DasPath_Gather;
 					}
-				} else if (BfHerculesArgs hq{}; das_mode != 1 &&
-				           plan_hercules(a, ps->transmit_table, bp.xdc_transform, plan.das_voxel_transform, zcount, das_mode == 6, hq) &&
-				           d.hercules_table.ensure(((size_t)hq.table_pitch + 2) * a.size[1] * sizeof(float))) {
-					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
-					hq.zero_offset = (uint32_t)used;            /* as for the gather kernel above */
-					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
-					/* linear interpolation of IQ samples reads a {sample, difference} copy of the input (16 bytes per sample, 32-bit byte
-					 * offsets: under 4 GiB), built by the launcher; BEAMFORMER_HIP_HERCULES_NOPAIRS: measurement aid */
-					hq.pairs = nullptr;
-					const uint64_t prepared = used * (a.interpolation == 2 ? 4u : 2u);      /* cubic: four coefficients per sample, 32 bytes */
-					/* (not on coarse grids: the copy is 2-4 x the RF, and where every lane reads its own cache line the memory system
-					 * pays for the bytes -- the harness's view plane with cubic polynomials: 28.1 ms, 158 GB from beyond L2 per frame;
-					 * with the taps gathered from the RF itself 25.2 ms) */
-					if (plan.iq_pipeline && (a.interpolation == 1 || a.interpolation == 2) && prepared + 64 < (1ull << 32) &&
-					    lane_step_samples(to_xdc, a) < 1.0f &&
-					    !std::getenv("BEAMFORMER_HIP_HERCULES_NOPAIRS") && d.hercules_pairs.ensure(prepared + 64)) {
-						hq.pairs = d.hercules_pairs.ptr;
-						hq.zero_offset = (uint32_t)prepared;
-					}
-					hq.table    = (float *)d.hercules_table.ptr;
-					hq.extremes = hq.table + (size_t)hq.table_pitch * a.size[1];
-					ok &= HIP_OK(bf_launch_das_hercules(&a, &hq, s));
-					das_path = 5;
-				} else if (factored_applies(a, ps->transmit_table, c.das_path_mode & 0xF)) {
-					uint64_t used = (uint64_t)C * A * Sd * (plan.iq_pipeline ? 8u : 4u);
-					a.zero_offset = (uint32_t)used;             /* as for the gather kernel above */
-					/* wave-span staging (das_factored.hip): on COARSE grids -- a voxel step along x of a sample of delay or more, as the
-					 * reference harness's 0.23 mm pixels have (tests/throughput.c:20-23) -- the lanes of a gather land in 64 different
-					 * places and the per-wave LDS-DMA copy of the span is cheaper (harness frames: 0.90-0.93 of the gather loop's time;
-					 * on config 2's fine grid 1.13: not taken there).  das path bit 0x40 forces it wherever the kernel supports it, 0x80
-					 * keeps the gather loop (tests: the two frames are bit-identical). */
-					const bool span_ok = plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && used < (1ull << 32);
-					if (span_ok && !(c.das_path_mode & 0x80) && ((c.das_path_mode & 0x40) || lane_step_samples(to_xdc, a) >= 1.0f)) {
-						a.span_stage = 1;
-						/* a wave = 64 voxels along the first lateral axis, the block's four waves stacked along depth */
-						uint32_t lat = a.tile_shift[0] >= a.tile_shift[1] ? 0u : 1u;
-						if (a.tile_shift[lat] > 6) {
-							uint32_t spare = a.tile_shift[lat] - 6;
-							a.tile_shift[lat] = 6;
-							for (int k = 0; k < 3 && spare; k++) {
-								if ((uint32_t)k == lat) continue;
-								uint32_t room = ceil_log2(ext[k]) - a.tile_shift[k];
-								uint32_t give = room < spare ? room : spare;
-								a.tile_shift[k] += give; spare -= give;
-							}
-							a.tile_shift[lat] += spare;
-							for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
-							a.depth_major = tile_walk(depth_axis, zcount, a.blocks[1], a.band_rows);
+				}break;
+				case DasPath_Hercules:{
+					BfHerculesArgs hq = dd.herc;
+					if (d.hercules_table.ensure(((size_t)hq.table_pitch + 2) * a.size[1] * sizeof(float))) {
+						hq.pairs = nullptr;
+						const uint64_t prepared = used * (a.interpolation == 2 ? 4u : 2u);      /* cubic: four coefficients per sample, 32 bytes */
+						if (dd.hercules_prepared && d.hercules_pairs.ensure(prepared + 64)) {
+							hq.pairs = d.hercules_pairs.ptr;
+							hq.zero_offset = (uint32_t)prepared;
 						}
+						hq.table    = (float *)d.hercules_table.ptr;
+						hq.extremes = hq.table + (size_t)hq.table_pitch * a.size[1];
+						ok &= HIP_OK(bf_launch_das_hercules(&a, &hq, s));
+					} else {
+						ok &= HIP_OK(bf_launch_das(&a, s));                                     /* no memory for the row table: the general kernel */
+						das_path = DasPath_General;
 					}
-					ok &= HIP_OK(hipMemsetAsync((char *)const_cast<void *>(cur) + used, 0, 64, s));
+				}break;
+				case DasPath_Factored:
 					ok &= HIP_OK(bf_launch_das_factored(&a, s));
-					das_path = 3;
-				} else {
+					break;
+				default:
 					ok &= HIP_OK(bf_launch_das(&a, s));
+					break;
 				}
 				if (c.count_pairs) {
 					/* geometry-only recount of the apodization test; its own segment so that it
@@ -1042,6 +586,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 			t.das_taps = a.interpolation == 0 ? 1 : a.interpolation == 1 ? 2 : 4;
 			t.das_sample_bytes = plan.iq_pipeline ? 8 : 4;
 			t.das_path = das_path; t.frame_id = f->id;
+			t.violations_slot = violations_slot;
 		}break;
 		case BeamformerShaderKind_CoherencyWeighting:
 			/* fused into the DAS epilogue (das.hip); kept in the plan so that the stage list a
@@ -1397,6 +942,11 @@ static bool timings_of(Device &d, BeamformerHipFrameTimings *out)
 	if (t.count && HIP_OK(hipEventElapsedTime(&total, e.events[0], e.events[t.count]))) out->frame_ms = total;
 	out->das_voxels = t.das_voxels; out->das_taps = t.das_taps;
 	out->das_sample_bytes = t.das_sample_bytes; out->das_path = t.das_path;
+	if (t.violations_slot != ~0ull && d.staged_violations.ptr) {
+		uint32_t n = 0;
+		(void)hipMemcpy(&n, (uint32_t *)d.staged_violations.ptr + t.violations_slot, sizeof(n), hipMemcpyDeviceToHost);
+		out->staged_window_violations = n;
+	}
 	if (t.counted && d.pair_counter.ptr) {
 		unsigned long long n = 0;
 		(void)hipMemcpy(&n, (unsigned long long *)d.pair_counter.ptr + ((d.frame_counter - 1) % kTimingSlots),
@@ -1429,6 +979,7 @@ bool last_frame_timings(BeamformerHipFrameTimings *out)
 		BeamformerHipFrameTimings peer;
 		if (!timings_of(c.devices[i], &peer)) { (void)hipSetDevice(c.devices[0].device); return false; }
 		out->das_voxels += peer.das_voxels; out->das_pairs += peer.das_pairs;
+		out->staged_window_violations += peer.staged_window_violations;
 		if (peer.frame_ms > out->frame_ms) out->frame_ms = peer.frame_ms;
 	}
 	(void)hipSetDevice(c.devices[0].device);

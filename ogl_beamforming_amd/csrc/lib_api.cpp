@@ -12,6 +12,7 @@
  * (the reference's "server unreachable") when there is none.
  */
 #include "context.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -563,6 +564,40 @@ uint32_t beamformer_hip_describe_plan(uint32_t parameter_slot, BeamformerHipPlan
 	out->das_samples = plan.das_samples; out->iq_pipeline = plan.iq_pipeline;
 	out->das_sampling_frequency = plan.das_sampling_frequency; out->das_time_offset = plan.das_time_offset;
 	std::memcpy(out->das_voxel_transform, plan.das_voxel_transform, sizeof(out->das_voxel_transform));
+	return 1;
+}
+
+uint32_t beamformer_hip_set_hook(const char *name, const char *value)
+{
+	return check(set_hook(name, value), BeamformerLibErrorKind_InvalidAccess);
+}
+
+uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDescription *out)
+{
+	if (!valid_parameter_block(parameter_slot) || !check(out != nullptr, BeamformerLibErrorKind_InvalidAccess)) return 0;
+	Context &c = ctx();
+	const ParameterBlock &pb = c.blocks[parameter_slot];
+	Plan plan;
+	std::string error;
+	if (!build_plan(pb, plan, error, c.hilbert_enabled)) return check(false, BeamformerLibErrorKind_InvalidComputeStage);
+	std::memset(out, 0, sizeof(*out));
+	if (plan.das_index < 0) { out->path = -1; return 1; }
+	uint32_t zfirst = 0, zcount = plan.output_points[2];
+	if (pb.shard_z_count) { zfirst = pb.shard_z_first; zcount = pb.shard_z_count; }
+	DasDecision d;
+	decide_das(pb, plan, build_transmit_table(pb), zfirst, zcount, c.das_path_mode, d);
+	out->path = d.path == DasPath_Zero ? -2 : d.path;
+	std::snprintf(out->kernel, sizeof(out->kernel), "%s", das_kernel_name(d.path));
+	std::snprintf(out->name, sizeof(out->name), "%s", das_path_name(d.path));
+	for (int k = 0; k < DasPath_Count && k < 6; k++) std::snprintf(out->declined[k], sizeof(out->declined[k]), "%s", d.why[k].c_str());
+	for (int k = 0; k < 3; k++) { out->tile_shift[k] = d.a.tile_shift[k]; out->blocks[k] = d.a.blocks[k]; }
+	out->split_shift = d.a.split_shift; out->tile_walk = d.path == DasPath_Hercules ? d.herc.depth_major : (d.path == DasPath_Gather || d.path == DasPath_Staged) ? d.sep.depth_major : d.a.depth_major;
+	out->span_stage = d.a.span_stage;
+	if (d.path == DasPath_Gather || d.path == DasPath_Staged) {
+		out->u_axis = d.sep.u_axis; out->u_shift = d.sep.u_shift; out->v_shift = d.sep.v_shift; out->window_samples = d.path == DasPath_Staged ? d.sep.window_samples : 0;
+		out->uniform_tables = d.sep.uniform; out->lds_bytes = d.sep.lds_bytes; out->threads = d.sep.threads; out->channel_chunk = d.sep.channel_chunk;
+	}
+	out->hercules_prepared_copy = d.hercules_prepared;
 	return 1;
 }
 

@@ -121,6 +121,8 @@ def _load():
         "beamformer_hip_host_filter": (i32, [C.POINTER(P.FilterParameters), C.POINTER(C.c_float), u32,
                                         C.POINTER(C.c_float), C.POINTER(u32)]),
         "beamformer_hip_describe_plan": (u32, [u32, C.POINTER(P.HipPlan)]),
+        "beamformer_hip_describe_das": (u32, [u32, C.POINTER(P.HipDasDescription)]),
+        "beamformer_hip_set_hook": (u32, [C.c_char_p, C.c_char_p]),
         "beamformer_hip_shutdown": (None, []),
     }
     for name, (restype, argtypes) in sig.items():
@@ -215,3 +217,22 @@ def load_zbp(path, frame_number=0):
     finally:
         lib.beamformer_hip_zbp_free(rf)
     return bp, data
+
+
+def set_hook(name, value=None):
+    """beamformer_hip_set_hook: a test / measurement hook of the library (name without the BEAMFORMER_HIP_ prefix; None = off)"""
+    ok = library().beamformer_hip_set_hook(name.encode(), None if value is None else str(value).encode())
+    assert ok, f"unknown hook {name}"
+
+
+def describe_das(bp, filters=(), slot=0):
+    """The DAS kernel the library would run for these parameters under the current das path mode, and why the others
+    were declined (beamformer_hip_describe_das): (path, kernel, name, {path number: reason}, description struct).  Needs no device."""
+    L = library()
+    for i, fp in enumerate(filters):
+        assert L.beamformer_create_filter(C.byref(fp), i, slot), last_error()
+    assert L.beamformer_push_simple_parameters_at(C.byref(bp), slot), last_error()
+    d = P.HipDasDescription()
+    assert L.beamformer_hip_describe_das(slot, C.byref(d)), last_error()
+    reasons = {k: bytes(d.declined[k]).split(b"\0")[0].decode() for k in range(6)}
+    return int(d.path), d.kernel.decode(), d.name.decode(), reasons, d

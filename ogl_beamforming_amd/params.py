@@ -211,8 +211,16 @@ class HipFrameTimings(C.Structure):
         ("stage_count", C.c_uint32), ("stage_kind", C.c_uint32 * HIP_MAX_TIMED_STAGES),
         ("stage_ms", C.c_float * HIP_MAX_TIMED_STAGES), ("frame_ms", C.c_float),
         ("das_pairs", C.c_uint64), ("das_voxels", C.c_uint64), ("das_taps", C.c_uint32),
-        ("das_sample_bytes", C.c_uint32), ("das_path", C.c_uint32),
+        ("das_sample_bytes", C.c_uint32), ("das_path", C.c_uint32), ("staged_window_violations", C.c_uint32),
     ]
+
+
+class HipDasDescription(C.Structure):
+    _fields_ = [("path", C.c_int32), ("kernel", C.c_char * 48), ("name", C.c_char * 64), ("declined", (C.c_char * 160) * 6),
+                ("tile_shift", C.c_uint32 * 3), ("blocks", C.c_uint32 * 3), ("split_shift", C.c_uint32), ("tile_walk", C.c_uint32),
+                ("span_stage", C.c_uint32), ("u_axis", C.c_uint32), ("u_shift", C.c_uint32), ("v_shift", C.c_uint32), ("window_samples", C.c_uint32),
+                ("uniform_tables", C.c_uint32), ("lds_bytes", C.c_uint32), ("threads", C.c_uint32), ("channel_chunk", C.c_uint32),
+                ("hercules_prepared_copy", C.c_uint32)]
 
 
 class HipPlanStage(C.Structure):

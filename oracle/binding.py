@@ -71,6 +71,8 @@ def library():
         lib.oracle_set_nearest_ambiguity_buffer.argtypes = [C.c_void_p]
         lib.oracle_set_subgrid_stride.restype = None
         lib.oracle_set_subgrid_stride.argtypes = [C.c_uint32, C.c_uint32]
+        lib.oracle_set_rows_outermost.restype = None
+        lib.oracle_set_rows_outermost.argtypes = [C.c_int]
         lib.oracle_plan.restype = C.c_int
         lib.oracle_plan.argtypes = [C.POINTER(OracleParameterBlock), C.POINTER(OraclePlan)]
         lib.oracle_hadamard_transpose.argtypes = [C.c_int, fp]

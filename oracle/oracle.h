@@ -165,12 +165,21 @@ typedef struct {
 	uint32_t y_first, y_count;    /* likewise rows (whole when y_count == 0); output holds only the sub-grid */
 	uint32_t z_stride, y_stride;  /* sub-grid sampling: plane z_first + k z_stride, row y_first + k y_stride (0 = 1) */
 	int32_t  threads;             /* OpenMP threads, 0 = default */
+	/* build extension: only rows [row_first, row_first + row_count) of the sub-grid's z x y rows (all when row_count == 0):
+	 * oracle_beamform's rows-outermost schedule hands every thread its own rows and walks the channel chunks inside */
+	int64_t  row_first, row_count;
 } OracleDAS;
 /* das.glsl:368-407: output[...] += sum, incoherent[...] += |.| sums.
  * rf: elements (float or float pair); output: float or float pair per voxel.
  * Returns the number of (voxel, channel, transmit) triples that passed the
  * apodization test (G of BASELINE.md section 4). */
 uint64_t oracle_das(const OracleDAS *p, const float *rf, float *output, float *incoherent);
+/* Schedule of oracle_beamform's DAS (test infrastructure; the frames are bit-identical either way, tests/test_oracle.py):
+ * 0 = the reference's literal order -- per 16-channel chunk one pass over the image (beamformer_core.c:1604-1614), the rows of a
+ * pass shared out to the threads; 1 (default) = rows outermost: every chunk's DAS input is kept, each thread takes rows of the image
+ * and walks the chunks in the same order inside -- the same additions per voxel in the same order, one parallel region instead of
+ * C / 16 short ones (a 256-thread host scales; bench.py's cpu_baseline) */
+void oracle_set_rows_outermost(int enable);
 /* float64 twin of the same loops (truth for tolerance budgeting); outputs double */
 uint64_t oracle_das_f64(const OracleDAS *p, const float *rf, double *output, double *incoherent);
 

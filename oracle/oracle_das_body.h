@@ -309,9 +309,11 @@ static uint64_t FN(das_run)(const OracleDAS *p, const float *rf, REAL *output, R
 	int      elements = p->complex_data ? 2 : 1;
 	uint64_t pairs = 0;
 	int64_t  rows  = (int64_t)zn * yn;
+	int64_t  row_begin = 0, row_end = rows;
+	if (p->row_count > 0) { row_begin = p->row_first; row_end = p->row_first + p->row_count < rows ? p->row_first + p->row_count : rows; }
 
 	#pragma omp parallel for schedule(dynamic, 1) reduction(+:pairs) num_threads(oracle_thread_count(p->threads))
-	for (int64_t row = 0; row < rows; row++) {
+	for (int64_t row = row_begin; row < row_end; row++) {
 		uint32_t zl = (uint32_t)(row / yn), yl = (uint32_t)(row % yn);
 		uint32_t z = z0 + zl * (p->z_stride ? p->z_stride : 1u), y = y0 + yl * (p->y_stride ? p->y_stride : 1u);
 		for (uint32_t x = 0; x < X; x++) {

@@ -4,6 +4,11 @@
  * the pre-image stages, ping-pong slots 0/1 with slot 2 feeding DAS, DAS accumulating into
  * a cleared frame, then the post-image stages.  PARITY UNPINNED by the reference. */
 #include "oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static int omp_get_max_threads(void) { return 1; }
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -212,7 +217,15 @@ typedef struct {
 	int      chunk_channels;  /* channels in the chunk being run (Q5: the last chunk is clamped) */
 	uint32_t z_first, z_count, y_first, y_count;   /* sub-grid (build extension), 0 counts = whole */
 	double   das_seconds;
+	/* rows-outermost schedule: the DAS stage of every chunk is recorded (parameters + a copy of its input) instead of run */
+	int        defer_das;
+	OracleDAS *deferred;          /* one per chunk */
+	uint8_t   *deferred_inputs;   /* chunk k's DAS input at k * slot_bytes */
+	int        deferred_count;
 } Exec;
+
+static int rows_outermost = 1;
+void oracle_set_rows_outermost(int enable) { rows_outermost = enable != 0; }
 
 static uint32_t subgrid_z_stride = 1, subgrid_y_stride = 1;   /* oracle_set_subgrid_stride */
 
@@ -323,6 +336,11 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		d.threads = e->threads;
 		d.z_first = e->z_first; d.z_count = e->z_count; d.y_first = e->y_first; d.y_count = e->y_count;
 		d.z_stride = subgrid_z_stride; d.y_stride = subgrid_y_stride;
+		if (e->defer_das) {
+			memcpy(e->deferred_inputs + (size_t)e->deferred_count * e->slot_bytes, pp_das, e->slot_bytes);
+			e->deferred[e->deferred_count++] = d;
+			break;
+		}
 		double t0 = oracle_now();
 		e->pairs += oracle_das(&d, (const float *)pp_das, e->frame, e->incoherent);
 		e->das_seconds += oracle_now() - t0;
@@ -391,6 +409,13 @@ int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, flo
 		oracle_hadamard_transpose(G, e.readi_hadamard);
 	}
 
+	uint32_t chunk_total = (bp->channel_count + BeamformerChunkChannelCount - 1) / BeamformerChunkChannelCount;
+	if (rows_outermost && das_stage < plan.first_image_stage) {
+		e.deferred        = (OracleDAS *)calloc(chunk_total, sizeof(OracleDAS));
+		e.deferred_inputs = (uint8_t *)malloc((size_t)chunk_total * e.slot_bytes);
+		e.defer_das       = e.deferred && e.deferred_inputs;
+	}
+
 	size_t raw_channel_byte_stride = bytes * bp->sample_count * bp->acquisition_count;   /* :574 */
 	for (uint32_t channel_offset = 0; channel_offset < bp->channel_count;
 	     channel_offset += BeamformerChunkChannelCount)                                   /* :1604-1614 */
@@ -405,6 +430,25 @@ int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, flo
 		for (int i = 0; i < plan.first_image_stage; i++)
 			run_stage(&e, i, (int)channel_offset, rf_pointer, left);
 	}
+	if (e.defer_das && e.deferred_count) {
+		/* every thread takes rows of the (sub-)grid and, per row, walks the chunks in the order the reference runs them: each voxel
+		 * receives exactly the additions of the chunk-by-chunk schedule, in the same order */
+		uint32_t zn = z_count ? z_count : (uint32_t)plan.output_points[2], yn = y_count ? y_count : (uint32_t)plan.output_points[1];
+		int64_t  rows = (int64_t)zn * yn;
+		uint64_t pairs = 0;
+		double   t0 = oracle_now();
+		#pragma omp parallel for schedule(dynamic, 1) reduction(+:pairs) num_threads(threads > 0 ? threads : omp_get_max_threads())
+		for (int64_t row = 0; row < rows; row++) {
+			for (int k = 0; k < e.deferred_count; k++) {
+				OracleDAS d = e.deferred[k];
+				d.threads = 1; d.row_first = row; d.row_count = 1;
+				pairs += oracle_das(&d, (const float *)(e.deferred_inputs + (size_t)k * e.slot_bytes), e.frame, e.incoherent);
+			}
+		}
+		e.pairs += pairs;
+		e.das_seconds += oracle_now() - t0;
+	}
+	free(e.deferred); free(e.deferred_inputs);
 	for (int i = plan.first_image_stage; i < plan.stage_count; i++)                       /* :1616-1619 */
 		run_stage(&e, i, 0, 0, 0);
 

@@ -24,3 +24,21 @@ def bflib():
     """The product library through its C ABI; GPU tests fail loudly when it cannot compute."""
     from ogl_beamforming_amd import lib
     return lib
+
+
+@pytest.fixture
+def hooks(bflib):
+    """Test / measurement hooks of the library (beamformer_hip_set_hook), all switched off again after the test."""
+    used = []
+
+    class Setter:
+        def set(self, name, value="1"):
+            bflib.set_hook(name, value)
+            used.append(name)
+
+        def clear(self, name):
+            bflib.set_hook(name, None)
+
+    yield Setter()
+    for name in used:
+        bflib.set_hook(name, None)

@@ -83,7 +83,8 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
 
 
 def test_every_environment_variable_the_library_reads_is_documented():
-    """include/ogl_beamformer_hip.h lists the BEAMFORMER_HIP_* variables (measurement and test aids): every getenv in csrc/ is there"""
+    """include/ogl_beamformer_hip.h lists the BEAMFORMER_HIP_* variables: every getenv in csrc/ and every name of the hook table
+    (csrc/das_select.cpp, read from the environment once) is there"""
     import glob
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,5 +94,18 @@ def test_every_environment_variable_the_library_reads_is_documented():
         if path.endswith((".cpp", ".hip", ".h", ".c")):
             read |= set(re.findall(r'getenv\("(BEAMFORMER_HIP_[A-Z0-9_]+)"\)', open(path, errors="replace").read()))
     assert read, "no getenv found: the pattern is stale"
+    select = open(os.path.join(root, "ogl_beamforming_amd", "csrc", "das_select.cpp")).read()
+    table = re.search(r"g_hook_names\[\] = \{(.*?)nullptr\}", select, flags=re.S)
+    hooks = re.findall(r'"([A-Z0-9_]+)"', table.group(1))
+    assert len(hooks) >= 8
+    read |= {"BEAMFORMER_HIP_" + h for h in hooks}
     missing = sorted(v for v in read if v not in header)
     assert not missing, missing
+
+
+def test_hooks_are_set_through_the_api_and_unknown_names_refused():
+    from ogl_beamforming_amd import lib
+    L = lib.library()
+    assert L.beamformer_hip_set_hook(b"STAGED_CHECKED", b"1")
+    assert L.beamformer_hip_set_hook(b"STAGED_CHECKED", None)
+    assert not L.beamformer_hip_set_hook(b"NO_SUCH_HOOK", b"1")

@@ -91,6 +91,17 @@ def test_full_size_frame_properties(bflib, oracle, config4):
     assert np.array_equal(np.isnan(fast), np.isnan(gathered))
     assert np.abs(fast[ok] - gathered[ok]).max() / np.abs(fast[ok]).max() < 1e-4
 
+    # (7) the WHOLE frame with every term range-checked (STAGED_CHECKED): no term of the 2.5e12 leaves its staged window
+    # (a violated host bound would read a neighbouring transmit's window -- wrong voxels, no fault), and the frame is the same
+    bflib.set_hook("STAGED_CHECKED", "1")
+    try:
+        checked = run(bflib, acq)
+        assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 2
+        assert int(t.staged_window_violations) == 0
+    finally:
+        bflib.set_hook("STAGED_CHECKED", None)
+    assert np.array_equal(checked.view(np.uint32), whole.view(np.uint32))
+
 
 def test_full_size_linearity(bflib, config4):
     """B(a x + b y) = a B(x) + b B(y) for the whole pipeline without coherency weighting
@@ -321,8 +332,81 @@ def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits,
         assert int(t.das_path) == 3
         return
     assert int(t.das_path) == 2
+    bflib.set_hook("STAGED_CHECKED", "1")
+    try:
+        checked = run(bflib, acq, shard=(120, 4))
+        assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 2 and int(t.staged_window_violations) == 0
+    finally:
+        bflib.set_hook("STAGED_CHECKED", None)
+    assert np.array_equal(checked.view(np.uint32), staged.view(np.uint32))
     gathered = run(bflib, acq, shard=(120, 4), path=2)          # cubic: the factored kernel
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == (3 if interp == P.InterpolationMode.Cubic else 1)
     assert np.array_equal(np.isnan(staged), np.isnan(gathered))
     ok = ~np.isnan(gathered)
     assert ok.any() and np.abs(staged[ok] - gathered[ok]).max() / np.abs(gathered[ok]).max() < 1e-4
+
+
+
+def test_config1_at_full_size_against_the_whole_oracle_frame(bflib, oracle):
+    """BASELINE configs[0] at its own (small) size: 64 channels x 2048 samples x 1 plane wave -> 256 x 256, every voxel against
+    the oracle on the automatic path (general kernel with the channel split) and without the split"""
+    from tests import cases
+    from tests.test_gpu_parity import compare
+    acq = cfg.config(1)
+    ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=16)
+    for mode in (0, 0x11):
+        gpu = run(bflib, acq, path=mode)
+        compare(gpu, ref, acq)
+
+
+def test_config5_rows_at_the_edges_of_the_volume(bflib, oracle):
+    """Config 5 (HERCULES 256 ch x 128 tx -> 512^3, Demodulate -> Decode -> DAS, coherency weighting) as a WHOLE frame on the
+    aligned-grid kernel: oracle rows at z in {0, 255, 510} x y in {0, 255, 510} (first and last planes and rows: the kernel's
+    range-checked loop at full width, the tail of the tile walk) -- one strided oracle pass, 9 rows of 512 voxels."""
+    from tests import cases
+    acq = cfg.config(5)
+    frame = run(bflib, acq)
+    t = P.HipFrameTimings()
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 5
+    ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=16, z=(0, 3), y=(0, 3), stride=(255, 255))
+    got = frame[0:511:255, 0:511:255]
+    assert got.shape == ref.shape == (3, 3, 512)
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    ok = ~np.isnan(ref)
+    assert ok.any() and np.abs(ref[ok]).max() > 0
+    peak = np.abs(frame[~np.isnan(frame)]).max()
+    # binary16 staging (fp16 RF through Demodulate and Decode): 2e-3 of the frame's peak, and of the compared rows' own maximum
+    # with the factor incoherent noise sums carry (tests/test_gpu_full_size.py _rows_against_oracle)
+    delta = np.abs(got[ok] - ref[ok]).max()
+    assert delta / peak <= cases.tolerance(acq), delta / peak
+    assert delta / np.abs(ref[ok]).max() <= 4 * cases.tolerance(acq), delta / np.abs(ref[ok]).max()
+
+
+@pytest.mark.parametrize("kind, path, span", [("tpw", 3, 1), ("forces", 3, 1), ("hercules", 5, 0), ("vls", 3, 1)])
+def test_reference_harness_frame_at_full_size(kind, path, span, bflib, oracle):
+    """The frame the reference's own throughput harness beamforms (tests/throughput.c:20-23, :443-491): 256 channels x 128
+    transmits x 4096 samples -> the 512 x 1024 XZ view plane, cubic, F# 0.5, {Demodulate, Decode, DAS}.  The automatic path
+    (factored kernel with wave-span staging on this coarse grid; HERCULES: the aligned-grid kernel reading raw taps) against
+    oracle rows at the first, a middle and the last depths, and -- RCA / FORCES -- bit-for-bit against the gather loop."""
+    from tests import cases
+    acq = cfg.harness(kind)
+    p, kernel, _, reasons, d = bflib.describe_das(acq.bp, acq.filters)
+    assert p == path and int(d.span_stage) == span, (kernel, reasons)
+    if kind == "hercules":
+        assert int(d.hercules_prepared_copy) == 0
+    frame = run(bflib, acq)
+    t = P.HipFrameTimings()
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == path
+    assert frame.shape == (1, 1024, 512)
+    ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=16, y=(0, 4), stride=(1, 341))
+    got = frame[:, 0:1024:341]
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    ok = ~np.isnan(ref)
+    peak = np.abs(frame[~np.isnan(frame)]).max()
+    delta = np.abs(got[ok] - ref[ok]).max()
+    assert delta / peak <= cases.tolerance(acq), delta / peak
+    assert delta / np.abs(ref[ok]).max() <= 4 * cases.tolerance(acq), delta / np.abs(ref[ok]).max()
+    if span:
+        gather = run(bflib, acq, path=0x80)
+        assert np.array_equal(gather.view(np.uint32), frame.view(np.uint32)), "wave-span staging and the gather loop differ"

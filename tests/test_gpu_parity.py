@@ -49,11 +49,15 @@ def compare(gpu, ref, acq, flags=None):
     return float(err.max())
 
 
-def last_das_path(bflib):
+def last_timings(bflib):
     import ctypes as C
     t = P.HipFrameTimings()
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
-    return int(t.das_path)
+    return t
+
+
+def last_das_path(bflib):
+    return int(last_timings(bflib).das_path)
 
 
 # geometries whose receive and transmit axes differ: the separable-delay fast path must pick
@@ -70,17 +74,15 @@ STAGED = {"config4_small", "rca_staged_w64", "rca_staged_ragged", "rca_staged_au
 STAGED_MIN_TRANSMITS = 6
 
 
-def factored_applies(bp):
-    """host rule of executor.cpp: the sample index splits into a receive and a transmit term"""
-    kind = P.AcquisitionKind(bp.acquisition_kind)
-    if kind in (P.AcquisitionKind.FORCES, P.AcquisitionKind.UFORCES):
-        return bp.readi_group_count <= 1
-    if kind in (P.AcquisitionKind.RCA_TPW, P.AcquisitionKind.RCA_VLS, P.AcquisitionKind.Flash):
-        if bp.single_orientation:
-            return True
-        rx = {int(o) & 0xF for o in bp.transmit_receive_orientations[: bp.acquisition_count]}
-        return len(rx) == 1
-    return False
+def factored_applies(acq):
+    """whether das_factored.hip takes the frame when asked for (das path 4): the library says (beamformer_hip_describe_das)"""
+    from ogl_beamforming_amd import lib
+    L = lib.library()
+    L.beamformer_hip_set_das_path(0x14)
+    try:
+        return lib.describe_das(acq.bp, acq.filters)[0] == 3
+    finally:
+        L.beamformer_hip_set_das_path(0)
 
 
 def hercules_family(bp):
@@ -88,28 +90,7 @@ def hercules_family(bp):
                                                       P.AcquisitionKind.HERO_PA)
 
 
-def hercules_fast_auto(bp):
-    """host rule of executor.cpp plan_hercules for the axis-aligned grids of tests/cases.py: >= 32 voxels
-    along x, no channel split (>= 4096 waves of voxels or few channels), <= 25 % idle lanes"""
-    X, Y, Z = (max(1, v) for v in bp.output_points[:3])
-    waves, split, C = (X * Y * Z + 63) // 64, 0, bp.channel_count
-    while split < 4 and (waves << split) < 4096 and (C >> (split + 1)) >= 4:
-        split += 1
-    return hercules_family(bp) and X >= 32 and split == 0 and ((X + 63) & ~63) <= X + X // 3
-
-
-def expected_path(name, bp):
-    if hercules_fast_auto(bp):
-        return 5
-    # the LDS-table kernel goes first for linear interpolation; for cubic and nearest the
-    # factored kernel does where it applies (executor.cpp), the table kernel otherwise
-    if name in STAGED and bp.acquisition_count >= STAGED_MIN_TRANSMITS:
-        return 2                                 # linear (IQ or real) and cubic IQ frames: the staged kernels go first
-    if name in SEPARABLE and (bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp)
-                              or bp.acquisition_count < 3):
-        return 1
-    transmits = bp.acquisition_count - (1 if P.AcquisitionKind(bp.acquisition_kind) == P.AcquisitionKind.UFORCES else 0)
-    return 3 if factored_applies(bp) and transmits >= 3 else 0
+EXPECTED_AUTOMATIC = cases.EXPECTED_AUTOMATIC
 
 
 @pytest.mark.parametrize("name", sorted(cases.CASES))
@@ -119,7 +100,11 @@ def test_frame_parity(name, bflib, oracle):
     ref, pairs, flags = reference(oracle, acq)
     bflib.library().beamformer_hip_set_das_path(0)
     gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-    assert last_das_path(bflib) == expected_path(name, acq.bp)
+    path, kernel, _, reasons, _ = bflib.describe_das(acq.bp, acq.filters)
+    assert last_das_path(bflib) == path, (kernel, reasons)
+    if name in EXPECTED_AUTOMATIC:
+        assert path == EXPECTED_AUTOMATIC[name], (name, kernel, reasons)
+    assert all(reasons[k] for k in (1, 2, 3, 5) if k != path), reasons          # every kernel not taken says why
     compare(gpu, ref, acq, flags)
 
 
@@ -148,9 +133,10 @@ def test_gather_kernel_where_the_staged_kernel_applies(name, bflib, oracle):
     lib.beamformer_hip_set_das_path(2)
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-        bp = acq.bp
-        gather = bp.interpolation_mode == int(P.InterpolationMode.Linear) or not factored_applies(bp) or bp.acquisition_count < 3
-        assert last_das_path(bflib) == (1 if gather else 3)
+        path = bflib.describe_das(acq.bp, acq.filters)[0]
+        assert path in (1, 3) and last_das_path(bflib) == path
+        if acq.bp.interpolation_mode == int(P.InterpolationMode.Linear):
+            assert path == 1
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)
@@ -174,19 +160,21 @@ def test_lds_staged_kernel(name, bflib, oracle):
 
 @pytest.mark.parametrize("shape", ["5,4,5", "4,5,5", "6,4,5", "5,5,5", "4,6,5", "5,4,6", "4,5,6", "6,4,6", "5,5,6", "4,6,6"])
 @pytest.mark.parametrize("name", ["rca_staged_auto", "rca_staged_ragged"])
-def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracle, monkeypatch):
+def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracle, hooks):
     """BEAMFORMER_HIP_STAGED_SHAPE = "log2 U, log2 V, log2 W": each instantiation of the staged kernel (tile extents along
     the receive / transmit axes, 32- or 64-sample windows, 512- and 1024-thread blocks) instead of the shape the host would
     pick; a shape whose window cannot hold the tile's delay spread is declined and the gather kernel runs"""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
-    monkeypatch.setenv("BEAMFORMER_HIP_STAGED_SHAPE", shape)
+    hooks.set("STAGED_SHAPE", shape)
+    hooks.set("STAGED_CHECKED")                  # every term range-checked: window violations are counted
     lib.beamformer_hip_set_das_path(3)
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
         path = last_das_path(bflib)
         assert path in (1, 2)
+        assert last_timings(bflib).staged_window_violations == 0
         if shape in ("5,4,6", "4,5,6", "5,5,6", "4,6,6") and name == "rca_staged_auto":
             assert path == 2                     # a 64-sample window holds this case's spread for tiles up to 32 voxels along the receive axis
     finally:
@@ -196,7 +184,7 @@ def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracl
 
 @pytest.mark.parametrize("shape", ["6,4,5", "6,4,48", "6,4,6"])
 @pytest.mark.parametrize("name", ["rca_staged_fine", "rca_staged_fine_vls_short_rows", "rca_staged_auto"])
-def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, monkeypatch, capfd):
+def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, hooks, capfd):
     """64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are uniform and come from a global
     table (written per frame by a pre-pass) through scalar loads instead of from LDS.  Same arithmetic: the frame is
     BIT-IDENTICAL to the one the same tile shape gives with the tables in LDS (BEAMFORMER_HIP_STAGED_NOUNIFORM), and both
@@ -204,15 +192,15 @@ def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, monkeypatc
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
-    monkeypatch.setenv("BEAMFORMER_HIP_STAGED_SHAPE", shape)
-    monkeypatch.setenv("BEAMFORMER_HIP_DEBUG", "1")
+    hooks.set("STAGED_SHAPE", shape)
+    hooks.set("DEBUG")
     lib.beamformer_hip_set_das_path(3)
     try:
         capfd.readouterr()
         uniform = bflib.beamform(acq.bp, acq.rf, acq.filters)
         path_uniform = last_das_path(bflib)
         log = capfd.readouterr().err
-        monkeypatch.setenv("BEAMFORMER_HIP_STAGED_NOUNIFORM", "1")
+        hooks.set("STAGED_NOUNIFORM")
         tables_in_lds = bflib.beamform(acq.bp, acq.rf, acq.filters)
         path_lds = last_das_path(bflib)
         log_lds = capfd.readouterr().err
@@ -235,17 +223,18 @@ def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, monkeypatc
 
 
 @pytest.mark.parametrize("name", sorted(STAGED))
-def test_lds_staged_kernel_checked_loop_everywhere(name, bflib, oracle, monkeypatch):
+def test_lds_staged_kernel_checked_loop_everywhere(name, bflib, oracle, hooks):
     """BEAMFORMER_HIP_STAGED_CHECKED: every wave of the staged kernel runs the range-checked loop (normally only the
     waves that can leave the RF row do): the oracle's frame either way"""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
-    monkeypatch.setenv("BEAMFORMER_HIP_STAGED_CHECKED", "1")
+    hooks.set("STAGED_CHECKED")
     lib.beamformer_hip_set_das_path(3)
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert last_das_path(bflib) == 2
+        assert last_timings(bflib).staged_window_violations == 0, "a term left its staged window: plan_staged's bound is wrong"
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)
@@ -329,7 +318,7 @@ def test_hercules_coherent_peak_at_long_delays(bflib, oracle):
         assert err <= 1e-4, (mode, err)
 
 
-FACTORED = sorted(n for n in cases.CASES if factored_applies(cases.make(n).bp))
+FACTORED = sorted(n for n in cases.CASES if factored_applies(cases.make(n)))
 
 
 @pytest.mark.parametrize("split", [True, False])

@@ -8,7 +8,7 @@ import pytest
 
 from ogl_beamforming_amd import configs as cfg, params as P
 from tests import cases
-from tests.test_gpu_parity import compare, last_das_path, reference
+from tests.test_gpu_parity import compare, last_das_path, last_timings, reference
 
 pytestmark = pytest.mark.gpu
 S, D, I, K = P.ShaderKind, P.DataKind, P.InterpolationMode, P.AcquisitionKind
@@ -68,8 +68,11 @@ def draw(seed):
                       data_kind=kind, stages=stages, kind=akind, sparse=sparse, **common)
 
 
+STAGED_DRAWS = []          # seeds whose forced-staged pass ran the LDS-staged kernel (reported by the last test of this module)
+
+
 @pytest.mark.parametrize("seed", range(72))
-def test_random_acquisition(seed, bflib, oracle):
+def test_random_acquisition(seed, bflib, oracle, hooks):
     acq = draw(seed)
     ref, pairs, flags = reference(oracle, acq)
     ok = ~np.isnan(ref)
@@ -89,12 +92,18 @@ def test_random_acquisition(seed, bflib, oracle):
         compare(gpu, ref, acq, flags)
     # row-column draws the gather kernel took also go through the LDS-staged kernel (path 3; it declines -- and the gather
     # kernel runs again -- when the interpolation is not linear, the data real or the delay spread too wide for a window)
-    if first_path == 1:
+    if first_path in (1, 2):
         bflib.library().beamformer_hip_set_das_path(3)
+        hooks.set("STAGED_CHECKED")          # every term range-checked: a position outside its staged window is counted
         try:
             gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-            assert last_das_path(bflib) in (1, 2)
+            t = last_timings(bflib)
+            assert int(t.das_path) in (1, 2)
+            assert int(t.staged_window_violations) == 0, "a term left its staged window: plan_staged's bound is wrong"
+            if int(t.das_path) == 2:
+                STAGED_DRAWS.append(seed)
         finally:
+            hooks.clear("STAGED_CHECKED")
             bflib.library().beamformer_hip_set_das_path(0)
         compare(gpu, ref, acq, flags)
     # HERCULES-family draws also go through the aligned-grid kernel (forced: these grids are narrower than
@@ -107,3 +116,55 @@ def test_random_acquisition(seed, bflib, oracle):
         finally:
             bflib.library().beamformer_hip_set_das_path(0)
         compare(gpu, ref, acq, flags)
+
+
+
+def draw_separable(seed):
+    """a row-column acquisition the LDS-staged kernels can take: receive and transmit on different axes, 6-20 transmits, plane or
+    focused / diverging waves, ragged grids, linear / cubic interpolation, IQ or real samples (the generator of the CPU property
+    test tests/test_das_select.py, with RF)"""
+    rng = np.random.default_rng(2000 + seed)
+    C = int(rng.choice([16, 32, 48]))
+    A = int(rng.integers(6, 20))
+    focused = bool(rng.integers(0, 2))
+    mode = int(rng.integers(0, 4))                       # 0, 1: IQ linear; 2: IQ cubic; 3: real linear
+    pitch = float(rng.choice([0.15e-3, 0.2e-3, 0.3e-3]))
+    half = (C - 1) / 2 * pitch * float(rng.uniform(0.6, 2.0))
+    z0 = float(rng.uniform(3e-3, 10e-3))
+    z1 = z0 + float(rng.uniform(2e-3, 8e-3))
+    points = (int(rng.integers(20, 110)), int(rng.integers(20, 70)), int(rng.integers(1, 3)) + 1)
+    depths = rng.choice([-30e-3, -12e-3, 25e-3, 60e-3, np.inf], A) if focused else None
+    return cfg.rca(f"staged{seed}", C, A, int(rng.choice([512, 1024, 2048])), points, (-half, -half * float(rng.uniform(0.5, 1.2)), z0), (half, half, z1),
+                   seed=seed, orientation=int(rng.choice([0x12, 0x21])), cw=bool(rng.integers(0, 2)), f_number=float(rng.uniform(0.3, 1.5)),
+                   pitch=pitch, angles=np.linspace(-float(rng.uniform(2, 20)), float(rng.uniform(2, 20)), A), depths=depths,
+                   kind=K.RCA_VLS if focused else K.RCA_TPW, interp=I.Cubic if mode == 2 else I.Linear,
+                   demodulate=mode != 3, data_kind=P.DataKind.Int16)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_separable_acquisition_on_the_staged_kernels(seed, bflib, oracle, hooks):
+    """32 draws aimed at the LDS-staged kernels (the 72 general draws above reach them once): automatic path, every term
+    range-checked with the window-violation count on, against the oracle"""
+    acq = draw_separable(seed)
+    ref, pairs, flags = reference(oracle, acq)
+    ok = ~np.isnan(ref)
+    if not ok.any() or np.max(np.abs(ref[ok])) == 0:
+        pytest.skip("empty image")
+    bflib.library().beamformer_hip_set_das_path(0)
+    path = bflib.describe_das(acq.bp, acq.filters)[0]
+    gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    assert last_das_path(bflib) == path
+    compare(gpu, ref, acq, flags)
+    if path == 2:
+        hooks.set("STAGED_CHECKED")
+        checked = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        t = last_timings(bflib)
+        assert int(t.das_path) == 2 and int(t.staged_window_violations) == 0, "a term left its staged window: plan_staged's bound is wrong"
+        compare(checked, ref, acq, flags)
+        STAGED_DRAWS.append(100 + seed)
+
+
+def test_random_draws_reach_the_staged_kernel():
+    """how many draws exercised the LDS-staged kernels with the window-violation count on (none may be zero by luck)"""
+    print(f"staged draws: {len(STAGED_DRAWS)}: {STAGED_DRAWS}")
+    assert len(STAGED_DRAWS) >= 12, STAGED_DRAWS

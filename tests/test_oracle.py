@@ -104,7 +104,8 @@ def test_float64_twin_bounds_the_float_oracle(oracle):
                     ("readi_group", C.c_uint32), ("focal_vectors", fp), ("sparse_elements", C.POINTER(C.c_int16)),
                     ("transmit_receive_orientations", C.POINTER(C.c_uint8)), ("readi_hadamard", fp),
                     ("z_first", C.c_uint32), ("z_count", C.c_uint32), ("y_first", C.c_uint32), ("y_count", C.c_uint32),
-                    ("threads", C.c_int32)]
+                    ("z_stride", C.c_uint32), ("y_stride", C.c_uint32), ("threads", C.c_int32),
+                    ("row_first", C.c_int64), ("row_count", C.c_int64)]
     bp = acq.bp
     d = OracleDAS()
     d.acquisition_kind, d.acquisition_count, d.channel_count = bp.acquisition_kind, bp.acquisition_count, bp.channel_count
@@ -227,3 +228,27 @@ def test_oracle_output_is_frozen(oracle):
         # vintage may move sin/cos by an ulp, hence the tiny allowance
         assert np.abs(frame[ok] - want[ok]).max() <= 1e-6 * np.abs(want[ok]).max(), name
         assert int(pairs) == int(golden[name + ".pairs"]), name
+
+
+@pytest.mark.parametrize("name", ["config4_small", "hercules_demod_decode_cw", "uforces_sparse", "rca_nearest_real", "readi", "harness_tpw_small"])
+def test_rows_outermost_schedule_is_bit_identical_to_the_chunk_by_chunk_one(name):
+    """oracle_beamform's default schedule hands the rows of the image to the threads and walks the 16-channel chunks inside each
+    (one parallel region: a 256-thread host scales -- bench.py's cpu_baseline); the reference's literal schedule is one pass over
+    the image per chunk (beamformer_core.c:1604-1614).  Every voxel receives the same additions in the same order: same bits,
+    same pair count, also on a strided sub-grid."""
+    from oracle import binding as oracle
+    from tests import cases
+    acq = cases.make(name)
+    L = oracle.library()
+    try:
+        L.oracle_set_rows_outermost(0)
+        a, pa = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=4)
+        a2, pa2 = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=3, y=(1, 3), stride=(1, 2))
+        L.oracle_set_rows_outermost(1)
+        b, pb = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=4)
+        b2, pb2 = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=3, y=(1, 3), stride=(1, 2))
+    finally:
+        L.oracle_set_rows_outermost(1)
+    assert pa == pb and pa2 == pb2
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a2.view(np.uint32), b2.view(np.uint32))

@@ -39,10 +39,8 @@ for scale in (float(v) for v in args.scales.split(",")):
     frames = {}
     # (the third leg: the 48-sample window config 4 itself needs, on a grid that does not need it -- what the longer window costs)
     for name, env, shape in (("tables_in_lds", "1", None), ("uniform", None, None), ("uniform_48_sample_window", None, "6,4,48")):
-        if env: os.environ["BEAMFORMER_HIP_STAGED_NOUNIFORM"] = env
-        else:   os.environ.pop("BEAMFORMER_HIP_STAGED_NOUNIFORM", None)
-        if shape: os.environ["BEAMFORMER_HIP_STAGED_SHAPE"] = shape
-        else:     os.environ.pop("BEAMFORMER_HIP_STAGED_SHAPE", None)
+        lib.set_hook("STAGED_NOUNIFORM", env or None)
+        lib.set_hook("STAGED_SHAPE", shape or None)
         t = P.HipFrameTimings()
         best = 1e9
         for _ in range(4):
@@ -52,7 +50,7 @@ for scale in (float(v) for v in args.scales.split(",")):
             best = min(best, float(t.stage_ms[kinds.index(int(P.ShaderKind.DAS))]))
         row[name + "_ms"] = best
         row[name + "_path"] = int(t.das_path)
-    os.environ.pop("BEAMFORMER_HIP_STAGED_SHAPE", None)
+    lib.set_hook("STAGED_SHAPE", None)
     row["uniform_over_tables_in_lds"] = row["uniform_ms"] / row["tables_in_lds_ms"]
     rows.append(row)
     print(json.dumps(row), flush=True)
