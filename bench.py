@@ -276,15 +276,21 @@ def main():
     rows = [(last_id - k) % 32 for k in range(args.steps)]
     das_s = float(np.mean([stats.times[r][das_col] for r in rows]))
     stage_ms = {P.ShaderKind(ids[i]).name: float(np.mean([stats.times[r][i] for r in rows])) * 1e3 for i in range(n_stage)}
-    device_das_ms = None
+    device_das_ms, devices_info = None, None
     if in_process and n_gpus > 1:
-        device_das_ms = []
+        # what every device did with the newest frame: its slab, its DAS time, how long the RF copy into it took, whether that copy
+        # crossed xGMI directly, and a checksum of the RF it read -- computed on the device, compared here
+        device_das_ms, devices_info = [], []
         for i in range(n_gpus):
-            ti = P.HipFrameTimings()
-            assert L.beamformer_hip_get_device_frame_timings(i, C.byref(ti)), lib.last_error()
-            kinds = [int(ti.stage_kind[k]) for k in range(int(ti.stage_count))]
-            device_das_ms.append(float(ti.stage_ms[kinds.index(int(P.ShaderKind.DAS))]))
+            di = P.HipDeviceInfo()
+            assert L.beamformer_hip_get_device_info(i, C.byref(di)), lib.last_error()
+            device_das_ms.append(float(di.das_ms))
+            devices_info.append({"ordinal": int(di.ordinal), "slab": [int(di.slab_first), int(di.slab_count)], "das_ms": float(di.das_ms), "frame_ms": float(di.frame_ms),
+                                 "peer_copy_ms": float(di.peer_copy_ms), "peer_access": {2: "ingest device", 1: "direct (xGMI peer access)", 0: "staged through host memory"}[int(di.peer_access)],
+                                 "rf_checksum": f"{int(di.rf_checksum):016x}", "rf_bytes": int(di.rf_bytes)})
         das_s = device_das_ms[0] * 1e-3              # the launch `roofline` prices is device 0's
+        rf_checksum_ok = len({d["rf_checksum"] for d in devices_info}) == 1 and all(d["rf_bytes"] > 0 for d in devices_info)
+        assert rf_checksum_ok, f"the devices beamformed different RF: {devices_info}"
 
     if distributed:
         agg = torch.tensor([elapsed, das_s, float(pairs_local)], dtype=torch.float64, device="cpu" if rehearse else device)
@@ -353,7 +359,7 @@ def main():
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": how,
                 "das_path": PATH_NAMES[das_path], "slab_verified": verified, "rf_checksum_equal_on_all_ranks": rf_checksum_ok,
-                "stage_ms": stage_ms, **({"device_das_ms": device_das_ms} if device_das_ms else {}),
+                "stage_ms": stage_ms, **({"device_das_ms": device_das_ms, "devices": devices_info} if device_das_ms else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

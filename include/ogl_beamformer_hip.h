@@ -112,6 +112,23 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerH
  * times with the voxel and pair counts of the whole frame and the slowest device's frame time.) */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out);
 
+/* One device of the set and its share of the newest frame: what a scaling run needs to explain itself.
+ * peer_access: 2 = the ingest device (RF arrives from the host / the caller), 1 = direct peer access to the ingest device
+ * is enabled (hipDeviceCanAccessPeer said yes and hipDeviceEnablePeerAccess succeeded or was already on: the RF copy crosses
+ * one xGMI link), 0 = no peer access (the runtime stages hipMemcpyPeerAsync through host memory: slower, still correct).
+ * rf_checksum: sum over the 8-byte words w[i] of the RF this device's newest frame read of w[i] * (i + 1) mod 2^64, computed
+ * on the device -- equal on every device of a healthy set. */
+typedef struct {
+	int32_t  ordinal;             /* HIP device ordinal */
+	int32_t  peer_access;
+	uint32_t slab_first, slab_count;   /* z planes of the newest frame beamformed here */
+	float    peer_copy_ms;        /* the RF copy into this device (0 on the ingest device) */
+	float    das_ms, frame_ms;    /* its DAS stage and its whole stage list (HIP events on its compute stream) */
+	uint64_t rf_checksum;
+	uint64_t rf_bytes;
+} BeamformerHipDeviceInfo;
+BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_device_info(uint32_t device_index, BeamformerHipDeviceInfo *out);
+
 /* Frame graphs (BASELINE.json configs[4] names a "hipGraph-captured frame"; the reference records one command
  * list per frame, beamformer_core.c:1570-1620).  When enabled, the stage launches of a frame are captured into a
  * hipGraph, the parameter block's instantiated graph is updated in place from the capture (the frame-ring slot and

@@ -204,6 +204,8 @@ hipError_t bf_launch_display(const void *frame, uint64_t voxels, int complex_dat
                              float gamma, float db_cutoff, float *out, hipStream_t s);
 hipError_t bf_launch_min_max(const void *frame, uint64_t voxels, int complex_data,
                              float *scratch, float *out2, hipStream_t s);
+/* out (device) = sum over the 8-byte words w[i] of the buffer of w[i] * (i + 1) mod 2^64 */
+hipError_t bf_launch_rf_checksum(const void *data, uint64_t bytes, unsigned long long *out, hipStream_t s);
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,13 @@ struct Device {
 	hipEvent_t   rf_landed[BeamformerMaxRawDataFramesInFlight]{}, rf_consumed[BeamformerMaxRawDataFramesInFlight]{};
 	bool         consumed_pending[BeamformerMaxRawDataFramesInFlight]{};
 	uint32_t     slab_first = 0, slab_count = 0;               /* planes of the current multi-device frame */
+	int          peer_access = 2;                              /* how RF reaches this device from devices[0]: 2 = it IS that device (or the ingest
+	                                                              device itself), 1 = direct peer access over xGMI enabled, 0 = no peer access:
+	                                                              hipMemcpyPeerAsync stages the copy through host memory */
+	hipEvent_t   peer_copy_begin[BeamformerMaxRawDataFramesInFlight]{}, peer_copy_end[BeamformerMaxRawDataFramesInFlight]{};   /* timed */
+	uint32_t     last_rf_slot = 0;                             /* RF slot of the newest frame */
+	uint64_t     last_rf_bytes = 0;
+	const void  *last_rf = nullptr;                            /* what the newest frame's first stage read */
 	/* frame graphs (beamformer_hip_enable_frame_graphs): one instantiated hipGraph per parameter block, updated
 	 * in place from each frame's capture; graph_generation = the plan generation it was warmed up for */
 	hipGraphExec_t frame_exec[BeamformerMaxParameterBlocks]{};
@@ -142,6 +149,8 @@ struct Context {
 	Device      *cur = &devices[0];                            /* the device the executor functions act on */
 	std::vector<float> rf_time_deltas;
 	double       last_push_time = 0;
+	uint64_t     push_sequence = 0;                            /* id of the next frame, on EVERY device: one counter, so that the devices of
+	                                                              beamformer_hip_set_devices stay in lockstep even after a push that failed half way */
 };
 
 Context &ctx();
@@ -155,6 +164,7 @@ bool wait_for_frames(int32_t timeout_ms);
 bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms);
 bool last_frame_timings(BeamformerHipFrameTimings *out);
 bool device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out);
+bool device_info(uint32_t device_index, BeamformerHipDeviceInfo *out);
 bool fill_stats_table(BeamformerComputeStatsTable *out);
 bool frame_min_max(float out[2]);
 bool sum_last_frames(uint32_t count, void *out, uint64_t out_size);

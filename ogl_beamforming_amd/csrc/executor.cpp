@@ -77,6 +77,7 @@ static bool init_one_device(Context &c, Device &d, int ordinal, uint32_t index)
 	for (uint32_t k = 0; k < BeamformerMaxRawDataFramesInFlight; k++) {
 		if (!HIP_OK(hipEventCreateWithFlags(&d.rf_landed[k], hipEventDisableTiming))) return false;
 		if (!HIP_OK(hipEventCreateWithFlags(&d.rf_consumed[k], hipEventDisableTiming))) return false;
+		if (index != 0 && (!HIP_OK(hipEventCreate(&d.peer_copy_begin[k])) || !HIP_OK(hipEventCreate(&d.peer_copy_end[k])))) return false;
 		d.consumed_pending[k] = false;
 	}
 	if (!d.ring.ensure(c.frame_ring_bytes)) return false;
@@ -118,15 +119,27 @@ bool ensure_device()
 	if (!c.frame_ring_bytes) c.frame_ring_bytes = default_frame_ring_bytes();
 	bool ok = true;
 	for (uint32_t i = 0; i < n && ok; i++) ok = init_one_device(c, c.devices[i], ordinals[i], i);
-	/* peers copy RF slabs from the ingest device: let every device reach it directly over xGMI
-	 * (errors here only mean "already enabled" or "same device": the copies work either way) */
+	/* peers copy the RF from the ingest device: ask whether each can reach it directly (xGMI) and enable that; a refusal is not an
+	 * error -- hipMemcpyPeerAsync then stages the copy through host memory -- but it is remembered and reported
+	 * (beamformer_hip_get_device_info), because a scaling run that silently went through the host explains nothing */
+	for (uint32_t i = 0; i < n && ok; i++) c.devices[i].peer_access = 2;
 	for (uint32_t i = 1; i < n && ok; i++) {
 		if (c.devices[i].device == c.devices[0].device) continue;
-		(void)hipSetDevice(c.devices[i].device);
-		(void)hipDeviceEnablePeerAccess(c.devices[0].device, 0);
-		(void)hipSetDevice(c.devices[0].device);
-		(void)hipDeviceEnablePeerAccess(c.devices[i].device, 0);
+		int can = 0;
+		bool direct = HIP_OK(hipDeviceCanAccessPeer(&can, c.devices[i].device, c.devices[0].device)) && can;
+		if (direct) {
+			(void)hipSetDevice(c.devices[i].device);
+			hipError_t e = hipDeviceEnablePeerAccess(c.devices[0].device, 0);
+			direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+			/* and the other way (the ingest device's stream waits on the peer's events; some runtimes want both directions mapped) */
+			(void)hipSetDevice(c.devices[0].device);
+			hipError_t back = hipDeviceEnablePeerAccess(c.devices[i].device, 0);
+			direct = direct && (back == hipSuccess || back == hipErrorPeerAccessAlreadyEnabled);
+		}
 		(void)hipGetLastError();
+		c.devices[i].peer_access = direct ? 1 : 0;
+		if (!direct) std::fprintf(stderr, "[beamformer] device %d has no peer access to device %d: RF copies to it are staged through host memory\n",
+		                          c.devices[i].device, c.devices[0].device);
 	}
 	c.device_count = n;
 	c.cur = &c.devices[0];
@@ -159,7 +172,9 @@ static void release_one_device(Device &d)
 	for (uint32_t k = 0; k < BeamformerMaxRawDataFramesInFlight; k++) {
 		if (d.rf_landed[k])   (void)hipEventDestroy(d.rf_landed[k]);
 		if (d.rf_consumed[k]) (void)hipEventDestroy(d.rf_consumed[k]);
-		d.rf_landed[k] = d.rf_consumed[k] = nullptr; d.consumed_pending[k] = false;
+		if (d.peer_copy_begin[k]) (void)hipEventDestroy(d.peer_copy_begin[k]);
+		if (d.peer_copy_end[k])   (void)hipEventDestroy(d.peer_copy_end[k]);
+		d.rf_landed[k] = d.rf_consumed[k] = d.peer_copy_begin[k] = d.peer_copy_end[k] = nullptr; d.consumed_pending[k] = false;
 	}
 	for (auto &b : d.rf) b.release();
 	for (auto &b : d.scratch) b.release();
@@ -177,6 +192,7 @@ static void release_one_device(Device &d)
 	d.frames.clear();
 	d.ring_next_offset = 0; d.frame_counter = 0; d.rf_index = 0;
 	d.have_sample = false; d.last_sampled_frame = 0; d.last_sampled_block = 0; d.replan_frame = 0;
+	d.last_rf = nullptr; d.last_rf_bytes = 0; d.last_rf_slot = 0; d.peer_access = 2;
 	d.device = -1;
 }
 
@@ -186,6 +202,7 @@ void shutdown_device()
 	if (!c.device_ready) return;
 	for (uint32_t i = 0; i < kMaxDevices; i++) release_one_device(c.devices[i]);
 	c.device_ready = false; c.device_count = 1; c.cur = &c.devices[0];
+	c.push_sequence = 0;
 	for (auto &b : c.blocks) b.dirty |= Dirty_Parameters;   /* plans are rebuilt on next use */
 }
 
@@ -572,7 +589,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				if (c.count_pairs) {
 					/* geometry-only recount of the apodization test; its own segment so that it
 					 * stays out of the DAS time */
-					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * kTimingSlots);
+					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 1));
 					a.pair_counter = (unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots);
 					ok &= HIP_OK(hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned long long), s));
 					segment((uint32_t)st.kind);
@@ -599,11 +616,12 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 	if (plan.das_index < 0 && ok) {
 		/* no DAS in the pipeline: the frame exists and stays zero (the reference clears it,
 		 * beamformer_core.c:1573-1585, and nothing writes it) */
-		uint32_t points[3] = {plan.output_points[0], plan.output_points[1], plan.output_points[2]};
+		/* (several devices: the ingest device holds the whole zero frame, the others an empty slab of it) */
+		uint32_t points[3] = {plan.output_points[0], plan.output_points[1], c.device_count > 1 && d.index != 0 ? 0u : plan.output_points[2]};
 		FrameRecord *f = next_frame(points, plan.iq_pipeline, block);
 		if (!f) return set_error(BeamformerLibErrorKind_FrameSizeOverflow);
 		f->timing_slot = (int)(f->id % kTimingSlots);
-		ok &= HIP_OK(hipMemsetAsync((char *)d.ring.ptr + f->offset, 0, f->bytes, s));
+		if (f->bytes) ok &= HIP_OK(hipMemsetAsync((char *)d.ring.ptr + f->offset, 0, f->bytes, s));
 		t.das_voxels = 0; t.das_taps = 0; t.das_sample_bytes = 0; t.das_path = 0; t.frame_id = f->id;
 	}
 	if (!ok) return set_error(BeamformerLibErrorKind_InvalidAccess);
@@ -647,8 +665,11 @@ static bool run_peers(uint32_t block, const void *src, uint64_t rf_size, uint32_
 		/* the frame that read this slot three pushes ago must be done with it */
 		if (p.consumed_pending[slot]) ok &= HIP_OK(hipStreamWaitEvent(p.peer_stream, p.rf_consumed[slot], 0));
 		if (!ok) break;
+		ok &= HIP_OK(hipEventRecord(p.peer_copy_begin[slot], p.peer_stream));
 		ok &= HIP_OK(hipMemcpyPeerAsync(p.rf[slot].ptr, p.device, src, d0.device, rf_size, p.peer_stream));
+		ok &= HIP_OK(hipEventRecord(p.peer_copy_end[slot], p.peer_stream));
 		ok &= HIP_OK(hipEventRecord(p.rf_landed[slot], p.peer_stream));
+		p.last_rf = p.rf[slot].ptr; p.last_rf_bytes = rf_size; p.last_rf_slot = slot;
 		ok &= HIP_OK(hipStreamWaitEvent(p.stream, p.rf_landed[slot], 0));
 		TimingSlot &t = p.timing[p.frame_counter % kTimingSlots];
 		t.sampled = true; t.events_slot = (uint32_t)(p.frame_counter % kTimingSlots);
@@ -686,6 +707,12 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	uint32_t slot = (uint32_t)(d.rf_index++ % BeamformerMaxRawDataFramesInFlight);
 	if (!d.rf[slot].ensure(round_up(rf_size, 64) + 64)) return set_error(BeamformerLibErrorKind_RFDataSizeOverflow);
 	const bool multi = c.device_count > 1;
+	/* ONE frame id for every device of the set, taken here: whatever fails below -- a peer's replan, a peer copy, the ingest
+	 * device's own stages -- the next push starts all devices on the same id again, and beamformer_get_last_frames refuses exactly
+	 * the frames that are incomplete instead of skipping every frame from then on */
+	const uint64_t sequence = c.push_sequence++;
+	for (uint32_t i = 0; i < c.device_count; i++) c.devices[i].frame_counter = sequence;
+	struct Lockstep { Context &c; uint64_t next; ~Lockstep() { for (uint32_t i = 0; i < c.device_count; i++) c.devices[i].frame_counter = next; } } lockstep{c, sequence + 1};
 	if (multi) {
 		/* every peer replans before the ingest device does (its commit clears the dirty bits) */
 		for (uint32_t i = 1; i < c.device_count; i++) {
@@ -829,6 +856,7 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	c.last_push_time = now;
 
+	d.last_rf = borrowed ? data : d.rf[slot].ptr; d.last_rf_bytes = rf_size; d.last_rf_slot = slot;
 	if (multi && !run_peers(block, borrowed ? data : d.rf[slot].ptr, rf_size, slot)) return false;
 	bool done = borrowed ? run_frame(block, data, (int64_t)rf_size, true)
 	                     : run_frame(block, d.rf[slot].ptr, (int64_t)d.rf[slot].size, true);
@@ -903,7 +931,13 @@ bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t ti
 			voxels += v; if (v) elem = (uint64_t)bf_kind_byte_size[f.data_kind];
 		}
 		uint64_t whole = round_up(voxels * elem, 64);
-		if (!valid || !whole || exported + whole > out_size) continue;
+		if (!valid || !whole) {
+			/* a device of the set holds no complete slab of this frame (a push that failed half way, storage reused): older frames
+			 * are skipped as in the one-device export; the NEWEST frame missing is an error, not an unwritten buffer */
+			if (n + 1 == req) { ok = false; break; }
+			continue;
+		}
+		if (exported + whole > out_size) continue;
 		uint64_t at = exported;
 		for (uint32_t i = 0; i < c.device_count; i++) {
 			Device &p = c.devices[i];
@@ -965,6 +999,39 @@ bool device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out)
 	bool ok = timings_of(c.devices[device_index], out);
 	(void)hipSetDevice(c.devices[0].device);
 	return ok;
+}
+
+bool device_info(uint32_t device_index, BeamformerHipDeviceInfo *out)
+{
+	Context &c = g_context;
+	std::memset(out, 0, sizeof(*out));
+	if (!c.device_ready || device_index >= c.device_count) return set_error(BeamformerLibErrorKind_InvalidAccess);
+	Device &d = c.devices[device_index];
+	out->ordinal = d.device; out->peer_access = d.peer_access;
+	out->slab_first = d.slab_first; out->slab_count = d.slab_count;
+	bool ok = HIP_OK(hipSetDevice(d.device)) && HIP_OK(hipStreamSynchronize(d.stream));
+	if (ok && d.frame_counter) {
+		BeamformerHipFrameTimings t;
+		if (timings_of(d, &t)) {
+			out->frame_ms = t.frame_ms;
+			for (uint32_t i = 0; i < t.stage_count; i++) if (t.stage_kind[i] == (uint32_t)BeamformerShaderKind_DAS) out->das_ms = t.stage_ms[i];
+		}
+		if (device_index != 0 && d.peer_copy_end[d.last_rf_slot]) {
+			float ms = 0;
+			if (HIP_OK(hipStreamSynchronize(d.peer_stream)) && HIP_OK(hipEventElapsedTime(&ms, d.peer_copy_begin[d.last_rf_slot], d.peer_copy_end[d.last_rf_slot]))) out->peer_copy_ms = ms;
+			(void)hipGetLastError();
+		}
+		if (d.last_rf && d.last_rf_bytes) {
+			ok = d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 1));
+			unsigned long long *sum = ok ? (unsigned long long *)d.pair_counter.ptr + kTimingSlots : nullptr;
+			unsigned long long host = 0;
+			ok = ok && HIP_OK(bf_launch_rf_checksum(d.last_rf, d.last_rf_bytes, sum, d.stream)) &&
+			     HIP_OK(hipMemcpyAsync(&host, sum, sizeof(host), hipMemcpyDeviceToHost, d.stream)) && HIP_OK(hipStreamSynchronize(d.stream));
+			out->rf_checksum = host; out->rf_bytes = d.last_rf_bytes;
+		}
+	}
+	(void)hipSetDevice(c.devices[0].device);
+	return ok || set_error(BeamformerLibErrorKind_InvalidAccess);
 }
 
 /* the newest frame: stage times of the ingest device; with several devices the voxel and pair counts

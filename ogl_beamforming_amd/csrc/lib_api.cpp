@@ -412,6 +412,12 @@ uint32_t beamformer_hip_get_device_frame_timings(uint32_t device_index, Beamform
 	return device_frame_timings(device_index, out);
 }
 
+uint32_t beamformer_hip_get_device_info(uint32_t device_index, BeamformerHipDeviceInfo *out)
+{
+	if (!check(out != nullptr, BeamformerLibErrorKind_InvalidAccess) || !ensure_device()) return 0;
+	return device_info(device_index, out);
+}
+
 uint32_t beamformer_hip_set_stream(void *hip_stream)
 {
 	Context &c = ctx();

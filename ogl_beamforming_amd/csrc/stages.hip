@@ -617,3 +617,29 @@ extern "C" hipError_t bf_launch_min_max(const void *frame, uint64_t voxels, int 
 	hipLaunchKernelGGL(min_max_final_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, out2);
 	return hipGetLastError();
 }
+
+
+/* Position-weighted 64-bit checksum of a device buffer: sum over 8-byte words w[i] of w[i] * (i + 1) (mod 2^64; integer addition:
+ * any order gives the same bits).  What bench.py all-reduces over the ranks of a multi-GPU run -- here for the devices of
+ * beamformer_hip_set_devices: a peer that beamformed a stale, partial or misplaced RF copy is caught. */
+__global__ __launch_bounds__(256) void rf_checksum_kernel(const unsigned long long *words, uint64_t count, unsigned long long *out)
+{
+	unsigned long long sum = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256u) sum += words[i] * (i + 1u);
+	for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+	__shared__ unsigned long long part[4];
+	if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" hipError_t bf_launch_rf_checksum(const void *data, uint64_t bytes, unsigned long long *out, hipStream_t s)
+{
+	hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+	if (e != hipSuccess) return e;
+	const uint64_t words = bytes / 8u;
+	if (!words) return hipSuccess;
+	uint32_t blocks = (uint32_t)((words + 255u) / 256u > 2048u ? 2048u : (words + 255u) / 256u);
+	hipLaunchKernelGGL(rf_checksum_kernel, dim3(blocks), dim3(256), 0, s, (const unsigned long long *)data, words, out);
+	return hipGetLastError();
+}

@@ -98,6 +98,7 @@ def _load():
         "beamformer_hip_set_devices": (u32, [C.POINTER(i32), u32]),
         "beamformer_hip_get_device_count": (u32, []),
         "beamformer_hip_get_device_frame_timings": (u32, [u32, C.POINTER(P.HipFrameTimings)]),
+        "beamformer_hip_get_device_info": (u32, [u32, C.POINTER(P.HipDeviceInfo)]),
         "beamformer_hip_set_stream": (u32, [vp]),
         "beamformer_hip_set_output_shard": (u32, [u32, u32, u32]),
         "beamformer_hip_push_device_data_with_compute": (u32, [vp, u32, u32, u32]),

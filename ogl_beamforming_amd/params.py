@@ -215,6 +215,12 @@ class HipFrameTimings(C.Structure):
     ]
 
 
+class HipDeviceInfo(C.Structure):
+    _fields_ = [("ordinal", C.c_int32), ("peer_access", C.c_int32), ("slab_first", C.c_uint32), ("slab_count", C.c_uint32),
+                ("peer_copy_ms", C.c_float), ("das_ms", C.c_float), ("frame_ms", C.c_float),
+                ("rf_checksum", C.c_uint64), ("rf_bytes", C.c_uint64)]
+
+
 class HipDasDescription(C.Structure):
     _fields_ = [("path", C.c_int32), ("kernel", C.c_char * 48), ("name", C.c_char * 64), ("declined", (C.c_char * 160) * 6),
                 ("tile_shift", C.c_uint32 * 3), ("blocks", C.c_uint32 * 3), ("split_shift", C.c_uint32), ("tile_walk", C.c_uint32),

@@ -142,3 +142,42 @@ def test_device_set_rules(bflib, devices):
     assert not lib.beamformer_hip_set_device(0)
     assert not lib.beamformer_hip_set_stream(C.c_void_p(1))             # a stream belongs to one device
     assert not lib.beamformer_hip_set_devices(two, 0) and not lib.beamformer_hip_set_devices(two, 9)
+
+
+def test_device_info_reports_slabs_copies_and_one_rf_checksum(bflib, devices):
+    """beamformer_hip_get_device_info: every device of the set names its slab, its DAS time, the time of the RF copy into it,
+    how the copy travels (2 ingest device / same GPU, 1 direct peer access, 0 staged through the host) and a checksum of the RF
+    it read, computed on the device: equal everywhere, and equal to numpy's on the pushed bytes"""
+    acq = cases.make("config4_small")
+    devices([0, 0, 0])
+    frame = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    infos = []
+    for i in range(3):
+        di = P.HipDeviceInfo()
+        assert lib.beamformer_hip_get_device_info(i, C.byref(di))
+        infos.append(di)
+    assert [int(d.ordinal) for d in infos] == [0, 0, 0]
+    assert all(int(d.peer_access) == 2 for d in infos)                 # one GPU listed three times: no link to enable
+    assert sum(int(d.slab_count) for d in infos) == frame.shape[0]
+    assert infos[0].peer_copy_ms == 0 and all(d.peer_copy_ms > 0 for d in infos[1:])
+    assert all(d.das_ms > 0 and d.frame_ms >= d.das_ms for d in infos)
+    sums = {int(d.rf_checksum) for d in infos}
+    assert len(sums) == 1 and all(int(d.rf_bytes) == acq.rf.nbytes for d in infos)
+    words = np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1)[: acq.rf.nbytes // 8 * 8].view(np.uint64)
+    want = int((words * np.arange(1, words.size + 1, dtype=np.uint64)).sum(dtype=np.uint64))
+    assert sums == {want}
+    assert not lib.beamformer_hip_get_device_info(3, C.byref(P.HipDeviceInfo()))
+
+
+def test_pipeline_without_das_on_several_devices_exports_one_zero_frame(bflib, devices):
+    """a pipeline that never reaches DAS leaves a zero frame (beamformer_core.c:1573-1585): with several devices the ingest device
+    holds it whole and the others an empty slab -- the stitched export has the one-device size, not N times it"""
+    acq = cases.make("hercules_demod_decode_cw")
+    acq.bp.compute_stages_count = 2                         # {Demodulate, Decode}
+    devices([0])
+    one = bflib.beamform(acq.bp, acq.rf, acq.filters).copy()
+    assert not one.any()
+    devices([0, 0])
+    two = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    assert same_bits(one, two)
