@@ -362,10 +362,14 @@ def main():
                 "stage_ms": stage_ms, **({"device_das_ms": device_das_ms, "devices": devices_info} if device_das_ms else {}),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                # what limits the dominant kernel (`binding` prices it): VALU issue for the LDS-staged kernel, the per-CU texture-address path for
+                # the gather kernels.  achieved / peak / frac keep the contract's HBM formula (see contract_note)
+                "bound": {"das_rca_staged_kernel": "valu-issue"}.get(KERNEL_NAMES[das_path], "texture-address path (per-lane gathers served by L1)"),
+                "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK,
-                "frac_note": "contract formula: ALGORITHMIC gather bytes / kernel time / 8 TB/s.  It exceeds 1 because the taps are served by L1/L2, "
-                             "not HBM: HBM is not the binding resource (hbm_measured_GBps), `binding` is",
+                "contract_note": "achieved / peak / frac follow the contract's formula: ALGORITHMIC gather bytes / kernel time / 8 TB/s.  The quotient exceeds 1 "
+                                 "because the taps are served by LDS / L1 / L2, not HBM (hbm_measured_GBps is what reaches the HBM side): HBM is not the binding "
+                                 "resource -- `bound` names it and `binding` prices the kernel against it",
                 "traffic": traffic, "traffic_source": traffic_source,
                 "hbm_measured_GBps": (traffic / das_s / 1e9) if traffic else None,
                 "hbm_copy_measured": hbm_copy,        # GB/s (read + write) of a 1 GiB device-to-device copy on this box
@@ -445,6 +449,15 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_term_per_simd": per_term,
                 "source": "profiles/r02_microbench.json valu_stream (tools/microbench.hip term_probe); achieved measured in this run",
             }
+            # the datasheet figure next to the measured one: wave64 issue costs of MI355X_MICROARCH.md (plain f32 2 clk, packed f32 and
+            # conversions 4, transcendentals 8) for the loop's 36 instructions per 4 terms: 4 packed adds + 12 packed fmas + 2 packed adds
+            # (72) + 4 v_lshlrev_b16 (8) + 4 x (v_mul, v_fmac, v_sqrt) (48) = 128 clk per 4 terms
+            issue_clk = 32.0
+            issue_peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / issue_clk
+            out["issue_bound"] = {"cycles_per_term_per_simd": issue_clk, "peak": issue_peak / 1e12, "frac": terms / das_s / issue_peak,
+                                  "model": "datasheet issue rates (2 / 4 / 8 clk per wave64 instruction: plain, packed or converting, transcendental) x the inner loop's "
+                                           "36 VALU instructions per 4 terms = 32 clk per term per SIMD, at the probe's clock: the ceiling if the hardware met its "
+                                           "datasheet rates; `frac` above prices against what the same instruction stream MEASURED"}
             # the same loop WITH its LDS reads (delays, phasors, taps at addresses formed as the kernel forms them) and
             # nothing else of the kernel -- no staging, no barriers: what the instruction mix of the inner loop allows
             loops = [v for v in micro["valu_stream"] if v["stream"].startswith("das_staged inner loop with its LDS reads: address by v_lshlrev_b16")]
@@ -501,9 +514,11 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
 def cpu_baseline(acq, budget_s):
     """The CPU oracle (port of the reference shaders) on a bounded sample of the same frame: all x,
     a few rows, on EVENLY SPACED z-planes (the f-number culling -- and with it the work per voxel --
-    varies with depth); voxels are independent, so voxels/s extrapolates linearly.  Three legs as
-    BASELINE.md section 3 asks: every core the process may use, the 16-core share a one-GPU box owns,
-    one thread."""
+    varies with depth); voxels are independent, so voxels/s extrapolates linearly.  Legs as
+    BASELINE.md section 3 asks: every core the process may use, half of them, the 16-core share a one-GPU
+    box owns, one thread.  Since round 3 the oracle's DAS hands ROWS of the image to the threads and walks
+    the 16-channel chunks inside each (one parallel region; bit-identical to the reference's chunk-by-chunk
+    order, tests/test_oracle.py), so the all-core leg scales instead of losing to the 16-thread one."""
     from oracle import binding as oracle
     bp = acq.bp
     X, Y, Z = (max(1, v) for v in bp.output_points[:3])
@@ -515,14 +530,14 @@ def cpu_baseline(acq, budget_s):
 
     def sample(threads, seconds):
         # ~1.2e7 pairs/s per thread for the scalar port (hyperthreads share cores: 0.6e7 assumed past 64 threads);
-        # the sample is sized for the budget and so that every thread gets several rows (a row is the oracle's
-        # unit of parallel work: X voxels x one 16-channel pass)
+        # the sample is sized for the budget and so that every thread gets several rows (a row of X voxels over all
+        # channels is the oracle's unit of parallel work)
         rate = 1.2e7 * min(threads, 64) + 0.6e7 * max(0, threads - 64)
         target_voxels = max(X, int(seconds * rate / per_voxel_pairs))
         planes = max(1, min(Z, 8, target_voxels // X))
         rows = max(1, min(Y, target_voxels // (X * planes)))
-        if rows * planes < 2 * threads:                       # fewer rows than threads would idle most of them
-            rows = max(1, min(Y, -(-2 * threads // planes)))
+        if rows * planes < 3 * threads:                       # fewer rows than threads would idle most of them
+            rows = max(1, min(Y, -(-3 * threads // planes)))
         z_stride = max(1, Z // planes)
         y_stride = max(1, Y // rows)
         timing = {}
@@ -541,8 +556,7 @@ def cpu_baseline(acq, budget_s):
     total = sum(weight.values())
     legs = {n: sample(n, budget_s * weight[n] / total) for n in counts}
     best = max(legs.values(), key=lambda leg: leg["value"])
-    # the headline figure is the fastest leg (the scalar port stops scaling well before 256 logical CPUs: its
-    # 16-channel passes are short parallel regions over a shared 20 MB RF chunk); every leg is listed
+    # the headline figure is the fastest leg; every leg is listed
     return {
         "value": best["value"], "unit": "voxels/s", "cores": best["cores"], "kind": "port", "sample": best["sample"],
         "all_cores": legs[affinity], "half_of_them": legs[max(1, affinity // 2)], "box_share": legs[share], "one_thread": legs[1],

@@ -345,8 +345,14 @@ extern "C" hipError_t bf_launch_decode(const BfDecodeArgs *a, hipStream_t s)
  * by the position inside that window, filter.glsl:99-107).  Four such groups share a
  * 256-thread block.  F16 selects the shader's SAMPLE_TYPE (filter.glsl:2-14): binary16 for
  * every 16-bit input kind, binary32 otherwise; products and sums are f32. */
-template <int IN_KIND, bool DEMOD>
-__global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
+/* TRANSPOSE: the stage feeds Decode, whose input layout is [sample][channel][transmit] (transmit fastest,
+ * beamformer_core.c:645-664): a wave's 64 outputs then lie C x A elements apart and the plain store writes 64 separate
+ * 4- / 8-byte pieces (the harness's HERCULES frame: 1.9 ms of a 28 ms frame for a 0.8 GB stage).  Here the 16 waves of a
+ * block take the SAME 64 samples of 16 CONSECUTIVE transmits, meet in an LDS tile [64 samples][16 transmits] and the block
+ * stores it with 16 transmits contiguous per sample -- 64- / 128-byte pieces.  Same arithmetic, same values. */
+constexpr uint32_t kFilterTransposeWaves = 16;
+template <int IN_KIND, bool DEMOD, bool TRANSPOSE = false>
+__global__ __launch_bounds__(TRANSPOSE ? 1024 : 256) void filter_kernel(const BfFilterArgs a)
 {
 	constexpr bool F16 = (IN_KIND >> 1) != 1;                       /* every 16-bit kind stages through binary16 */
 	extern __shared__ __attribute__((aligned(16))) float filter_lds[];
@@ -354,8 +360,10 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 	const uint32_t window = D * 64 + L - 1;
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t wg   = blockIdx.x * 4 + wave;                  /* the shader's gl_WorkGroupID.x */
-	const uint32_t channel = blockIdx.y, transmit = blockIdx.z;
+	const uint32_t wg   = TRANSPOSE ? blockIdx.x : blockIdx.x * 4 + wave;          /* the shader's gl_WorkGroupID.x */
+	const uint32_t channel = blockIdx.y;
+	const uint32_t transmit_wanted = TRANSPOSE ? blockIdx.z * kFilterTransposeWaves + wave : blockIdx.z;
+	const uint32_t transmit = transmit_wanted < a.transmits ? transmit_wanted : a.transmits - 1;     /* (TRANSPOSE: a ragged last block computes a copy, stores nothing) */
 	float *w = filter_lds + (size_t)wave * window * 2;
 	constexpr bool in_complex     = (IN_KIND & 1) != 0;
 	constexpr bool complex_sample = in_complex || DEMOD;             /* filter.glsl:16-19 */
@@ -405,6 +413,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
 	const uint32_t out_sample = wg * 64 + lane;
+	[[maybe_unused]] f32x2 *tile = reinterpret_cast<f32x2 *>(filter_lds + (size_t)kFilterTransposeWaves * window * 2);   /* TRANSPOSE: [64][16] */
 	if (out_sample < a.sample_count / D) {                            /* filter.glsl:115 */
 		f32x2 result = {0.f, 0.f};
 		const float *x = w + 2 * (size_t)(D * lane);
@@ -423,6 +432,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 				result.y += x[2 * j + 1] * h;
 			}
 		}
+		if constexpr (TRANSPOSE) {
+			tile[lane * kFilterTransposeWaves + wave] = result;
+		} else {
 		int64_t off = a.out_stride[1] * channel + a.out_stride[2] * transmit + a.out_stride[0] * out_sample;
 		if (a.batch_sample_count == 0 && a.out_kind == 3) {           /* the common case: f32 complex, one 8-byte store */
 			reinterpret_cast<f32x2 *>(a.out)[off] = result;
@@ -434,6 +446,19 @@ __global__ __launch_bounds__(256) void filter_kernel(const BfFilterArgs a)
 		} else {
 			store_scalar(a.out_kind, a.out, off, result.x);
 		}
+		}
+	}
+	if constexpr (TRANSPOSE) {
+		__syncthreads();
+		/* thread t stores sample t / 16 of transmit t % 16: 16 consecutive elements of the output per sample */
+		const uint32_t ts = threadIdx.x / kFilterTransposeWaves, tt = threadIdx.x % kFilterTransposeWaves;
+		const uint32_t sample = wg * 64 + ts, tx = blockIdx.z * kFilterTransposeWaves + tt;
+		if (sample < a.sample_count / D && tx < a.transmits) {
+			const f32x2 v = tile[ts * kFilterTransposeWaves + tt];
+			const int64_t off = a.out_stride[1] * channel + a.out_stride[2] * tx + a.out_stride[0] * sample;
+			if (a.out_kind == 3) reinterpret_cast<f32x2 *>(a.out)[off] = v;
+			else                 store_element(a.out_kind, a.out, off, v);
+		}
 	}
 }
 
@@ -444,6 +469,23 @@ extern "C" hipError_t bf_launch_filter(const BfFilterArgs *a, hipStream_t s)
 	dim3 grid((groups + 3) / 4, a->channels, a->transmits);
 	size_t lds = (size_t)4 * (a->decimation * 64 + a->filter_length - 1) * 2 * sizeof(float);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	/* output with the transmits contiguous and the samples far apart (Decode's input layout), complex elements, several transmits:
+	 * the transposing form */
+	const size_t lds_t = (size_t)kFilterTransposeWaves * (a->decimation * 64 + a->filter_length - 1) * 2 * sizeof(float) + 64 * kFilterTransposeWaves * sizeof(f32x2);
+	const bool transpose = a->out_stride[2] == 1 && a->out_stride[0] >= (int64_t)a->transmits && a->transmits >= 4 && a->batch_sample_count == 0 &&
+	                       (a->out_kind & 1) && lds_t <= 64 * 1024;
+	if (transpose) {
+		dim3 grid_t(groups, a->channels, (a->transmits + kFilterTransposeWaves - 1) / kFilterTransposeWaves);
+		#define BF_FILTER_T(kind) \
+			case kind: if (a->demodulate) hipLaunchKernelGGL((filter_kernel<kind, true,  true>), grid_t, dim3(1024), lds_t, s, *a); \
+			           else               hipLaunchKernelGGL((filter_kernel<kind, false, true>), grid_t, dim3(1024), lds_t, s, *a); break;
+		switch (a->in_kind) {
+		BF_FILTER_T(0) BF_FILTER_T(1) BF_FILTER_T(2) BF_FILTER_T(3) BF_FILTER_T(4) BF_FILTER_T(5)
+		default: return hipErrorInvalidValue;
+		}
+		#undef BF_FILTER_T
+		return hipGetLastError();
+	}
 	#define BF_FILTER_CASE(kind) \
 		case kind: if (a->demodulate) hipLaunchKernelGGL((filter_kernel<kind, true>),  grid, dim3(256), lds, s, *a); \
 		           else               hipLaunchKernelGGL((filter_kernel<kind, false>), grid, dim3(256), lds, s, *a); break;
