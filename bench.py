@@ -46,7 +46,7 @@ KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel
 # kernel's own file plus the headers every DAS kernel includes
 KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
                 "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
-COMMON_SOURCES = ["das_common.h", "bf_kernels.h"]
+COMMON_SOURCES = ["das_common.h", "bf_kernels.h", "das_select.cpp"]       # (the selection rules decide tile shapes, windows and walks: they change a kernel's traffic)
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--frame-graph", action="store_true",
                     help="replay every frame from a captured hipGraph (beamformer_hip_enable_frame_graphs; BASELINE configs[4] names a "
                          "hipGraph-captured frame).  Off by default: never faster (profiles/r02_graph_probe.json), and a graph frame times as one segment")
+    ap.add_argument("--interpolation", choices=["nearest", "linear", "cubic"], default=None,
+                    help="override the configuration's interpolation mode (config 5 with cubic = the reference harness's own setting)")
     ap.add_argument("--planes", type=int, default=0, help="profiling aid: beamform only this many centre z-planes (value is then NOT the metric)")
     return ap.parse_args()
 
@@ -120,6 +122,8 @@ def main():
         args.config = int(args.config)
     acq = configs.by_name(args.config, args.scale)
     bp = acq.bp
+    if args.interpolation:
+        bp.interpolation_mode = {"nearest": 0, "linear": 1, "cubic": 2}[args.interpolation]
     X, Y, Z = (max(1, v) for v in bp.output_points[:3])
     voxels_total = X * Y * Z
     for slot, fp in enumerate(acq.filters):
@@ -215,6 +219,15 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(device)
+
+    # what the library will run for this block, in its own words (beamformer_hip_describe_das)
+    dd = P.HipDasDescription()
+    assert L.beamformer_hip_describe_das(0, C.byref(dd)), lib.last_error()
+    das_plan = {"kernel": dd.kernel.decode(), "tile_shift": list(dd.tile_shift), "blocks": list(dd.blocks), "split_shift": int(dd.split_shift),
+                "tile_walk": int(dd.tile_walk), "span_stage": int(dd.span_stage), "u_axis": int(dd.u_axis), "u_shift": int(dd.u_shift), "v_shift": int(dd.v_shift),
+                "window_samples": int(dd.window_samples), "uniform_tables": int(dd.uniform_tables), "lds_bytes": int(dd.lds_bytes), "threads": int(dd.threads),
+                "channel_chunk": int(dd.channel_chunk), "hercules_prepared_copy": int(dd.hercules_prepared_copy),
+                "declined": {str(k): bytes(dd.declined[k]).split(b"\0")[0].decode() for k in range(6) if bytes(dd.declined[k]).split(b"\0")[0]}}
 
     # one untimed frame with the geometry-only pair count: G of BASELINE.md section 4
     L.beamformer_hip_enable_pair_counting(1)
@@ -358,13 +371,13 @@ def main():
                           "profiles/r02_other_configs.json, DESIGN.md section 8)"),
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": how,
-                "das_path": PATH_NAMES[das_path], "slab_verified": verified, "rf_checksum_equal_on_all_ranks": rf_checksum_ok,
+                "das_path": PATH_NAMES[das_path], "das_plan": das_plan, "slab_verified": verified, "rf_checksum_equal_on_all_ranks": rf_checksum_ok,
                 "stage_ms": stage_ms, **({"device_das_ms": device_das_ms, "devices": devices_info} if device_das_ms else {}),
             },
             "roofline": {
                 # what limits the dominant kernel (`binding` prices it): VALU issue for the LDS-staged kernel, the per-CU texture-address path for
                 # the gather kernels.  achieved / peak / frac keep the contract's HBM formula (see contract_note)
-                "bound": {"das_rca_staged_kernel": "valu-issue"}.get(KERNEL_NAMES[das_path], "texture-address path (per-lane gathers served by L1)"),
+                "bound": {"das_rca_staged_kernel": "valu-issue", "das_hercules_kernel": "valu-issue"}.get(KERNEL_NAMES[das_path], "texture-address path (per-lane gathers served by L1)"),
                 "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK,
                 "contract_note": "achieved / peak / frac follow the contract's formula: ALGORITHMIC gather bytes / kernel time / 8 TB/s.  The quotient exceeds 1 "
@@ -414,7 +427,7 @@ def measured_traffic(config, kernel):
     try:
         with open(path) as f:
             table = json.load(f)
-        entry = table[f"config{config}"][kernel]
+        entry = table[f"config{config}" if isinstance(config, int) else config][kernel]
     except (OSError, KeyError, ValueError):
         return None, "no committed PMC pass for this configuration and kernel"
     if entry.get("kernel_source_sha16") != kernel_source_hash(kernel):
@@ -433,10 +446,26 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_microbench.json")) as f:
+        micro_name = next(n for n in ("r03_microbench.json", "r02_microbench.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        with open(os.path.join(ROOT, "profiles", micro_name)) as f:
             micro = json.load(f)
         cus = int(micro["compute_units"])
-        if kernel == "das_rca_staged_kernel":
+        if kernel == "das_hercules_kernel" and micro.get("hercules_stream") and bytes_per_gather >= 16:
+            # VALU issue, priced against the kernel's own instruction stream run with no memory instruction (tools/microbench.hip
+            # hercules_probe: the expressions of das_hercules.hip's unchecked IQ loop, 4 pairs per iteration)
+            cubic = bytes_per_gather >= 32
+            rows = [v for v in micro["hercules_stream"] if ("cubic" in v["stream"]) == cubic]
+            best = min(rows, key=lambda v: v["cycles_per_pair_per_simd_wall"])
+            per_pair = best["cycles_per_pair_per_simd_wall"]
+            peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / per_pair
+            out = {
+                "resource": f"VALU issue: {per_pair:.1f} clk per wave64 (channel, transmit-element) pair per SIMD for the HERCULES inner loop's instruction stream, measured with no memory instruction in it",
+                "achieved": terms / das_s / 1e12, "unit": "T pairs/s (pairs that pass the f-number test)", "peak": peak / 1e12,
+                "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_pair:.2f} clk",
+                "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_pair_per_simd": per_pair,
+                "source": f"profiles/{micro_name} hercules_stream (tools/microbench.hip hercules_probe); achieved measured in this run",
+            }
+        elif kernel == "das_rca_staged_kernel":
             best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8 and v["stream"].startswith("das_staged term, shipping form")),
                        key=lambda v: v["cycles_per_term_per_simd_wall"])
             per_term = best["cycles_per_term_per_simd_wall"]
@@ -447,7 +476,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "peak": peak / 1e12,
                 "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_term:.2f} clk",
                 "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_term_per_simd": per_term,
-                "source": "profiles/r02_microbench.json valu_stream (tools/microbench.hip term_probe); achieved measured in this run",
+                "source": f"profiles/{micro_name} valu_stream (tools/microbench.hip term_probe); achieved measured in this run",
             }
             # the datasheet figure next to the measured one: wave64 issue costs of MI355X_MICROARCH.md (plain f32 2 clk, packed f32 and
             # conversions 4, transcendentals 8) for the loop's 36 instructions per 4 terms: 4 packed adds + 12 packed fmas + 2 packed adds
@@ -481,14 +510,15 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "peak_model": f"{best['bytes_per_clk_per_cu_wall']:.1f} B/clk/CU (measured, L1-resident window, DAS-like addresses, {best['waves_per_simd']} waves/SIMD) x {cus} CUs x {best['clock_ghz']:.3f} GHz (clock sustained in that probe)",
                 "frac": gather_bytes / das_s / peak,
                 "peak_bytes_per_clk_per_cu": best["bytes_per_clk_per_cu_wall"], "probe_clock_ghz": best["clock_ghz"],
-                "source": "profiles/r02_microbench.json (tools/microbench.hip); achieved measured in this run",
+                "source": f"profiles/{micro_name} (tools/microbench.hip); achieved measured in this run",
             }
-    except (OSError, KeyError, ValueError):
-        out = {"resource": "unpriced: profiles/r02_microbench.json missing or without the probe this kernel needs"}
+    except (OSError, KeyError, ValueError, StopIteration):
+        out = {"resource": "unpriced: profiles/r0x_microbench.json missing or without the probe this kernel needs"}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_das_bound.json")) as f:
+        bound_name = next(n for n in ("r03_das_bound.json", "r02_das_bound.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        with open(os.path.join(ROOT, "profiles", bound_name)) as f:
             bound = json.load(f)
-        entry = bound[f"config{config}"][kernel]
+        entry = bound[f"config{config}" if isinstance(config, int) else config][kernel]
         out["valu_busy_frac"] = entry["valu_busy_frac"]
         out["ta_busy_frac"] = entry.get("ta_busy_frac")
         if entry.get("lds_idx_active_frac") is not None:
@@ -502,11 +532,11 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             out["frac_at_sustained_clock"] = out["frac"] * out["probe_clock_ghz"] / clock
             if "inner_loop_with_lds" in out:
                 out["inner_loop_with_lds"]["frac_at_sustained_clock"] = out["inner_loop_with_lds"]["frac"] * out["inner_loop_with_lds"]["probe_clock_ghz"] / clock
-        out["valu_source"] = (f"profiles/r02_das_bound.json: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
+        out["valu_source"] = (f"profiles/{bound_name}: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
                               f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash(kernel) else " (STALE: sources changed since)"))
         if kernel != "das_rca_staged_kernel" and entry["valu_busy_frac"] > out.get("frac", 0):
             out["resource_note"] = "VALU issue is the tighter bound for this kernel (valu_busy_frac)"
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         pass
     return out
 

@@ -176,9 +176,9 @@ typedef struct {
 uint64_t oracle_das(const OracleDAS *p, const float *rf, float *output, float *incoherent);
 /* Schedule of oracle_beamform's DAS (test infrastructure; the frames are bit-identical either way, tests/test_oracle.py):
  * 0 = the reference's literal order -- per 16-channel chunk one pass over the image (beamformer_core.c:1604-1614), the rows of a
- * pass shared out to the threads; 1 (default) = rows outermost: every chunk's DAS input is kept, each thread takes rows of the image
- * and walks the chunks in the same order inside -- the same additions per voxel in the same order, one parallel region instead of
- * C / 16 short ones (a 256-thread host scales; bench.py's cpu_baseline) */
+ * pass shared out to the threads, a fork / join per chunk; 1 (default) = ONE parallel region: every chunk's DAS input is kept,
+ * each thread owns a fixed set of rows of the image for the whole frame and walks the chunks in the reference's order over them --
+ * the same additions per voxel in the same order, no barrier between chunks (bench.py's cpu_baseline on a many-core host) */
 void oracle_set_rows_outermost(int enable);
 /* float64 twin of the same loops (truth for tolerance budgeting); outputs double */
 uint64_t oracle_das_f64(const OracleDAS *p, const float *rf, double *output, double *incoherent);

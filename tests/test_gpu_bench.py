@@ -28,7 +28,11 @@ def test_single_gpu_line():
     assert d["unit"] == "voxels/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 64 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     roof = d["roofline"]
-    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    # `bound` names the resource that limits the dominant kernel (this reduced frame has 5 transmits: the gather kernel, bound by the
+    # texture-address path; the full-size frame: "valu-issue"); achieved / peak / frac keep the contract's HBM formula
+    assert roof["bound"] in ("valu-issue", "texture-address path (per-lane gathers served by L1)") and roof["contract_note"]
+    assert roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert d["config"]["das_plan"]["kernel"] == roof["kernel"]
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["kernel_ms"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
     cpu = d["cpu_baseline"]
@@ -60,5 +64,7 @@ def test_in_process_two_device_contexts():
     d = last_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and "beamformer_hip_set_devices" in d["config"]["sharding"]
     assert len(d["config"]["device_das_ms"]) == 2 and all(v > 0 for v in d["config"]["device_das_ms"])
+    assert d["config"]["rf_checksum_equal_on_all_ranks"] is True and len(d["config"]["devices"]) == 2
+    assert [dev["slab"] for dev in d["config"]["devices"]] == [[0, 32], [32, 32]]
     assert d["roofline"]["pairs_total"] > d["roofline"]["pairs_per_launch"] > 0
     assert abs(d["value"] - 64 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

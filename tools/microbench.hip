@@ -210,6 +210,86 @@ __global__ __launch_bounds__(1024) void term_probe_packed(Stamp *stamps, float *
 	}
 }
 
+/* ------------------------------------------------------------------ the VALU stream of das_hercules.hip's inner loop
+ * What the aligned-grid HERCULES kernel issues per batch of four (channel, transmit-element) pairs in its unchecked IQ loop with
+ * coherency weighting and the per-lane phase reduction (config 5's instantiation) once the gathered samples are in registers:
+ * (od2 + z2) + D2 and w = ws D2 + ws od2 as packed ops over two pairs, v_sqrt, the packed index fma, the degree-5 apodization
+ * polynomial (packed), v_fract + v_cvt_flr of the index, the tap offset, the interpolation (one packed fma of the prepared
+ * {sample, difference} pair; CUBIC: the three-step Horner chain of the prepared segment polynomial), turns fma, v_sin, v_cos, the
+ * phasor scaled by the apodization, two packed fmas of rotate-accumulate and mul / fma / v_sqrt / fma for |s|.  Written in the
+ * kernel's own C++ (the expressions of das_hercules.hip's `group` lambda, CHECK = false, B = 4) with the table entries and the
+ * gathered data made opaque every iteration; no memory instruction.  Its rate is the ceiling of that formulation. */
+__device__ __forceinline__ f32x2 mb_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 mb_apod_poly(f32x2 w)
+{
+	f32x2 r = mb_splat(-0.000112471265f);
+	r = r * w + mb_splat(0.0030977894f);
+	r = r * w + mb_splat(-0.044347722f);
+	r = r * w + mb_splat(0.33327785f);
+	r = r * w + mb_splat(-0.9999883f);
+	r = r * w + mb_splat(0.9999996f);
+	return r;
+}
+template <bool CUBIC>
+__global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink, int iters)
+{
+	const float lane = (float)(threadIdx.x & 63);
+	float d2[4] = {1.0e-6f, 2.0e-6f, 3.0e-6f, 4.0e-6f};
+	f32x4 lo[4], hi[4];
+	for (int k = 0; k < 4; k++) { lo[k] = f32x4{0.5f + k, 0.25f, 0.125f, -0.5f}; hi[k] = f32x4{0.3f, 0.1f + k, -0.2f, 0.05f}; }
+	const f32x2 oz2p = mb_splat(4.0e-4f + 1.0e-7f * lane), wodp = mb_splat(0.01f), wsp = mb_splat(1.0e3f), T0p = mb_splat(100.f + lane),
+	            kp = mb_splat(8117.f), tpsp = mb_splat(0.5f), btp = mb_splat(130.f);
+	f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+	float mag = 0.f;
+	uint32_t row = 4096;
+	asm volatile("" : "+s"(row));
+	__syncthreads();
+	uint64_t t0 = memtime(), r0 = memrealtime();
+	for (int i = 0; i < iters; i++) {
+		asm volatile("" : "+s"(d2[0]), "+s"(d2[1]), "+s"(d2[2]), "+s"(d2[3]));
+		asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]));
+		if constexpr (CUBIC) asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+		f32x2 index[2], apod[2], turns[2];
+		#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const f32x2 dn = f32x2{d2[2 * k], d2[2 * k + 1]};
+			const f32x2 dd = oz2p + dn;
+			apod[k] = mb_apod_poly(dn * wsp + wodp);
+			const f32x2 dist = f32x2{__builtin_amdgcn_sqrtf(dd.x), __builtin_amdgcn_sqrtf(dd.y)};
+			index[k] = dist * kp + T0p;
+			turns[k] = index[k] * tpsp - btp;
+		}
+		#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const float idx = (k & 1) ? index[k >> 1].y : index[k >> 1].x;
+			const float ap  = (k & 1) ? apod[k >> 1].y : apod[k >> 1].x;
+			const float frac = __builtin_amdgcn_fractf(idx);
+			int ki; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ki) : "v"(idx));
+			const uint32_t off = (uint32_t)ki * (CUBIC ? 32u : 16u);
+			asm volatile("" :: "v"(off));
+			f32x2 sv;
+			if constexpr (CUBIC) {
+				sv = f32x2{hi[k].z, hi[k].w} * frac + f32x2{hi[k].x, hi[k].y};
+				sv = sv * frac + f32x2{lo[k].z, lo[k].w};
+				sv = sv * frac + f32x2{lo[k].x, lo[k].y};
+			} else {
+				sv = f32x2{lo[k].x, lo[k].y} + frac * f32x2{lo[k].z, lo[k].w};
+			}
+			const float tr = (k & 1) ? turns[k >> 1].y : turns[k >> 1].x;
+			const f32x2 cs = f32x2{__builtin_amdgcn_cosf(tr), __builtin_amdgcn_sinf(tr)} * ap;
+			acc1 += sv.x * cs;
+			acc2 += sv.y * cs;
+			mag = __builtin_fmaf(ap, __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x)), mag);
+		}
+	}
+	uint64_t t1 = memtime(), r1 = memrealtime();
+	if (mag + acc1.x + acc1.y + acc2.x + acc2.y == 12345.678f) sink[0] = mag;
+	if ((threadIdx.x & 63) == 0) {
+		uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+		stamps[wave] = Stamp{t1 - t0, r1 - r0};
+	}
+}
+
 /* ------------------------------------------------------------------ the whole inner loop of das_staged.hip: VALU stream AND its LDS reads
  * Config 4's shape (76 padded transmits, 32-element windows, a 32 x 32 tile, 16 waves per block, two blocks per CU): per batch
  * of 4 terms one ds_read2_b64 (delays), two ds_read_b128 (phasors) and four ds_read_b128 taps at addresses formed from the
@@ -574,6 +654,20 @@ template <int PARTS> static void term_packed_case(const char *what)
 	}
 }
 
+template <bool CUBIC> static void hercules_case(const char *what, bool first)
+{
+	const int iters = 20000;                           /* 80k pairs per wave */
+	for (int wps : {4, 7}) {                            /* the kernel holds 7 waves per SIMD (64-66 VGPRs) */
+		int waves_per_block = 4, blocks_per_cu = wps;
+		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
+		Result r = run([&] { hipLaunchKernelGGL(hercules_probe<CUBIC>, dim3(blocks), dim3(256), 0, 0, d_stamps, d_sink, iters); }, waves);
+		double pairs = 4.0 * iters;
+		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
+		emit("%s{\"stream\":\"%s\",\"waves_per_simd\":%d,\"cycles_per_pair_per_simd_wall\":%.3f,\"cycles_per_pair_per_simd_stamps\":%.3f,"
+		     "\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", (first && wps == 4) ? "" : ",\n  ", what, wps, wall_cycles / (pairs * wps), r.cycles_per_wave / (pairs * wps), r.clock_ghz, r.wall_ms);
+	}
+}
+
 template <int MODE> static void loop_case(const char *what)
 {
 	const int iters = 1000;                            /* 76k terms per wave */
@@ -717,6 +811,11 @@ int main(int argc, char **argv)
 	loop_case<49>("das_staged inner loop with its LDS reads, delays and phasors read a batch ahead (v_lshlrev_b16)");
 	loop_case<5>("das_staged inner loop, taps read as ds_read_b64 (half the returned bytes; v_lshlrev_b16)");
 	loop_case<9>("das_staged inner loop, LDS reads and position / address arithmetic only (v_lshlrev_b16)");
+	emit("],\n");
+
+	emit(" \"hercules_stream\":[\n  ");
+	hercules_case<false>("das_hercules inner loop (IQ, linear interpolation of the prepared {sample, difference} pairs, coherency weighting, per-lane phase reduction): VALU only", true);
+	hercules_case<true>("das_hercules inner loop (IQ, cubic: three-step Horner chain of the prepared segment polynomial, coherency weighting): VALU only", false);
 	emit("],\n");
 
 	bool first = true;

@@ -43,7 +43,7 @@ GROUPS = [
 # the geometry-only pair-count instantiation das_kernel<FAMILY, 0, false, false, true> is not the DAS launch
 COUNT_KERNEL = re.compile(r"das_kernel<[^>]*,\s*true>")
 
-KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_staged_cubic.hip", "das_hercules.hip", "bf_kernels.h"]
+KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_staged_cubic.hip", "das_hercules.hip", "bf_kernels.h", "das_select.cpp"]
 
 
 def kernel_source_hash():
@@ -79,7 +79,7 @@ def main():
         bench += ["--planes", str(args.planes)]
     pick = [int(v) for v in args.groups.split(",") if v] or range(len(GROUPS))
     env = dict(os.environ, TMPDIR="/tmp")
-    counters, dispatches, kernel_names, failed = {}, None, set(), []
+    counters, dispatches, kernel_names, failed, das_plan = {}, None, set(), [], None
     for gi in pick:
         group = GROUPS[gi]
         d = os.path.join(out, f"g{gi}")
@@ -89,6 +89,13 @@ def main():
         except subprocess.TimeoutExpired:
             failed.append({"group": group, "why": "timeout"})
             break                                      # a timed-out GPU step: run nothing further
+        if das_plan is None:
+            for line in r.stdout.decode(errors="replace").splitlines():
+                if line.startswith("{") and '"das_plan"' in line:
+                    try:
+                        das_plan = json.loads(line)["config"]["das_plan"]
+                    except (ValueError, KeyError):
+                        pass
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
             failed.append({"group": group, "why": r.stderr.decode(errors="replace")[-400:]})
@@ -111,7 +118,7 @@ def main():
             dispatches = max(len(v) for v in seen.values())
     summary = {
         "command": " ".join(bench).replace(ROOT + "/", ""), "kernel_filter": args.kernel, "kernels": sorted(kernel_names),
-        "dispatches_summed": dispatches, "counters": counters, "failed_groups": failed,
+        "dispatches_summed": dispatches, "counters": counters, "failed_groups": failed, "das_plan": das_plan,
         "kernel_source_sha16": kernel_source_hash(),
         "notes": "one rocprofv3 --pmc pass per counter group; values summed over the kernel's dispatches (bench.py runs the "
                  "geometry-only count frame on a separate kernel, excluded, plus one timed frame). SQ_*CYCLES and SQ_ACTIVE/WAIT "

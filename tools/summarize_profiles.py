@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # as bench.py: the kernel's own file plus the headers every DAS kernel includes, comments and whitespace removed
 KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
                 "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
-COMMON_SOURCES = ["das_common.h", "bf_kernels.h"]
+COMMON_SOURCES = ["das_common.h", "bf_kernels.h", "das_select.cpp"]
 
 
 def kernel_source_hash(kernel):
@@ -65,16 +65,17 @@ def main():
     for path in args.summaries:
         s = json.load(open(path))
         c = s["counters"]
-        m = re.search(r"--config (\d+)", s["command"])
-        config = int(m.group(1)) if m else 4
+        m = re.search(r"--config (\S+)", s["command"])
+        config = m.group(1) if m else "4"
+        config = int(config) if config.isdigit() else config
         planes = re.search(r"--planes (\d+)", s["command"])
         kernel = s["kernels"][0].split("<")[0] if s["kernels"] else "?"
         n = s["dispatches_summed"] or 1
-        key = f"config{config}"
+        key = f"config{config}" if isinstance(config, int) else config
         if "GRBM_GUI_ACTIVE" in c:
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # shader-clock cycles the launches were resident, all dispatches
             e = {"command": s["command"], "kernel_source_sha16": kernel_source_hash(kernel), "tree_sha16_at_run": s["kernel_source_sha16"], "dispatches_summed": n,
-                 "planes": int(planes.group(1)) if planes else "whole frame", "kernel_cycles_per_launch": cycles / n}
+                 "planes": int(planes.group(1)) if planes else "whole frame", "kernel_cycles_per_launch": cycles / n, "das_plan": s.get("das_plan")}
             if "SQ_ACTIVE_INST_VALU" in c:
                 e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * SIMDS)
             if "TA_BUSY_avr" in c:
@@ -117,7 +118,8 @@ def main():
                 "fetch_size_kib": c["FETCH_SIZE"] / n, "write_size_kib": c["WRITE_SIZE"] / n, "hbm_bytes_per_launch": hbm,
                 "compulsory_bytes": COMPULSORY.get(config), "ratio_to_compulsory": hbm / COMPULSORY[config] if config in COMPULSORY else None,
                 "l2_hit_rate": (c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])) if "TCC_HIT_sum" in c else None,
-                "launches_averaged": n, "round": args.round, "command": s["command"], "kernel_source_sha16": kernel_source_hash(kernel), "tree_sha16_at_run": s["kernel_source_sha16"]}
+                "launches_averaged": n, "round": args.round, "command": s["command"], "kernel_source_sha16": kernel_source_hash(kernel), "tree_sha16_at_run": s["kernel_source_sha16"],
+                "das_plan": s.get("das_plan")}
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     json.dump(bound, open(bound_path, "w"), indent=1)
     print("wrote", traffic_path, bound_path)
