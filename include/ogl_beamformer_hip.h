@@ -100,7 +100,7 @@ typedef struct {
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
 	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel,
-	                              4 (retired), 5 HERCULES aligned-grid kernel */
+	                              4 (retired), 5 HERCULES aligned-grid kernel, 6 factored kernel with block-wide LDS staging (das_tile.hip) */
 	uint32_t staged_window_violations;   /* LDS-staged kernels with the STAGED_CHECKED hook: (wave, channel) pairs in which a term's position
 	                                        fell outside the staged window -- the host's window bound was wrong.  Must be 0. */
 } BeamformerHipFrameTimings;
@@ -205,6 +205,9 @@ typedef enum {
 	                                                 wherever the kernel supports it -- automatic only on coarse grids (a voxel step along x of a
 	                                                 sample of delay or more, like the reference harness's view plane) */
 	BeamformerHipDasPath_NoSpanStaging    = 0x80, /* flag: never (the gather loop; the two give bit-identical frames) */
+	BeamformerHipDasPath_TileStaging      = 0x100,/* flag: das_tile.hip (factored kernel, block-wide LDS staging of cubic polynomials) wherever it is supported --
+	                                                 automatic on fine grids only */
+	BeamformerHipDasPath_NoTileStaging    = 0x200,/* flag: never */
 } BeamformerHipDasPath;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 /* Environment variables the library reads (none is needed in production):
@@ -293,10 +296,11 @@ typedef struct {
 	int32_t  path;
 	char     kernel[48];            /* "das_rca_staged_kernel", ... */
 	char     name[64];              /* "separable-delay LDS-staged kernel", ... */
-	char     declined[6][160];      /* by path number: why that kernel does not run ("" for the one that does) */
+	char     declined[8][160];      /* by path number: why that kernel does not run ("" for the one that does) */
 	uint32_t tile_shift[3], blocks[3], split_shift;      /* per-voxel kernels (general, factored): block shape and count */
 	uint32_t tile_walk;             /* 0 x,y,z; 1 z fastest; 2 y fastest; 3 view plane in XCD-balanced bands; staged kernels: + their flag bits */
 	uint32_t span_stage;            /* factored kernel: wave-span staging */
+	uint32_t tile_window_samples;   /* block-staged factored kernel (path 6): staged window length */
 	uint32_t u_axis, u_shift, v_shift, window_samples, uniform_tables, lds_bytes, threads, channel_chunk;   /* separable-delay kernels: the tile is 2^u_shift voxels
 	                                   along the receive axis (voxel axis u_axis) by 2^v_shift along the transmit axis, one plane thick */
 	uint32_t hercules_prepared_copy;/* HERCULES kernel: reads the {sample, difference} / polynomial copy of the DAS input */

@@ -62,6 +62,7 @@ typedef struct {
 	uint32_t band_rows;               /* depth_major == 3: tile rows per band */
 	uint32_t zero_offset;             /* factored kernel: byte offset (from rf) of >= 32 zero bytes the host keeps
 	                                     behind the DAS input, the gather target of out-of-range lanes */
+	uint32_t tile_window_shift;       /* das_tile.hip: log2 of the staged window length (5 or 6) */
 	uint32_t span_stage;              /* factored kernel, IQ + linear / cubic: 1 = wave-span staging (every wave copies the span of
 	                                     each RF row its 64 voxels touch into its own LDS slot by LDS-DMA; coarse grids) */
 } BfDasArgs;
@@ -198,6 +199,7 @@ hipError_t bf_launch_das_staged_cubic(const BfDasArgs *a, const BfSeparableArgs 
 /* |v| (complex) or v (real) min/max over a frame -> out2 (device float[2]); scratch holds
  * 2*1024 floats */
 hipError_t bf_launch_das_factored(const BfDasArgs *a, hipStream_t s);
+hipError_t bf_launch_das_tile(const BfDasArgs *a, hipStream_t s);          /* das_tile.hip: the factored kernel with block-wide LDS staging (cubic IQ, fine grids) */
 hipError_t bf_launch_das_hercules(const BfDasArgs *a, const BfHerculesArgs *q, hipStream_t s);
 hipError_t bf_launch_sum(void *out, const void *in, float prescale, uint64_t bytes, hipStream_t s);
 hipError_t bf_launch_display(const void *frame, uint64_t voxels, int complex_data, float threshold_db,

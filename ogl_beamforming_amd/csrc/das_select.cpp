@@ -21,15 +21,16 @@ namespace bf {
 const char *das_path_name(int path)
 {
 	static const char *names[] = {"general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
-	                              "(retired: LDS row-cache experiment)", "HERCULES aligned-grid kernel", "?", "none: the frame is cleared"};
-	return path >= 0 && path <= 7 ? names[path] : "?";
+	                              "(retired: LDS row-cache experiment)", "HERCULES aligned-grid kernel", "per-voxel factored kernel with block-wide LDS staging",
+	                              "?", "none: the frame is cleared"};
+	return path >= 0 && path <= 8 ? names[path] : "?";
 }
 
 const char *das_kernel_name(int path)
 {
 	static const char *names[] = {"das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
-	                              "das_hercules_kernel", "?", "(none)"};
-	return path >= 0 && path <= 7 ? names[path] : "?";
+	                              "das_hercules_kernel", "das_tile_kernel", "?", "(none)"};
+	return path >= 0 && path <= 8 ? names[path] : "?";
 }
 
 /* ---------------------------------------------------------------- hooks */
@@ -529,6 +530,8 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	const uint32_t das_mode = mode & 0xF;
 	const bool factored = factored_applies(a, tx, das_mode);
 	auto &why = out.why;
+	why[DasPath_Tile] = "only where the factored kernel would run (its block-staged form)";
+	why[DasPath_Retired] = "retired";
 	if (das_mode == 1) {
 		why[DasPath_Gather] = why[DasPath_Staged] = why[DasPath_Hercules] = why[DasPath_Factored] = "das path 1: the general kernel was asked for";
 	}
@@ -614,6 +617,47 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	}
 	if (factored) {
 		a.zero_offset = (uint32_t)out.das_input_bytes;
+		/* das_tile.hip: cubic IQ frames on FINE grids -- there the four taps of a term are two gather instructions through L1 (32.6 clk
+		 * per CU per term: what config 2 waits for) and a 64 x 16-voxel block touches a window of a few dozen samples of every RF row, which
+		 * the block stages as cubic polynomials.  Tried when the estimated spread of such a tile fits a 64-sample window (the kernel measures
+		 * the real spread per block and chunk and falls back to the gather loop itself, so the estimate only decides whether it is worth
+		 * trying); flag 0x100 forces it wherever it is supported, 0x200 forbids it. */
+		{
+			const bool tile_ok = plan.iq_pipeline && a.interpolation == 2 && !a.split_shift && Sd >= 8 && out.das_input_bytes < (1ull << 31) &&
+			                     (uint64_t)ext[0] * ext[1] * ext[2] >= 1024u && A - (a.family == BF_DAS_FORCES && a.sparse ? 1u : 0u) >= 4u;
+			/* tile: 64 voxels along x (a wave), the other 16 along the next axis that has voxels */
+			uint32_t shift[3] = {0, 0, 0}, left = 10;
+			for (int k = 0; k < 3 && left; k++) {
+				uint32_t room = ceil_log2(ext[k]), want = k == 0 ? 6u : left;
+				uint32_t give = room < want ? room : want;
+				give = give < left ? give : left;
+				shift[k] = give; left -= give;
+			}
+			for (int k = 0; k < 3 && left; k++) { uint32_t room = ceil_log2(ext[k]) - shift[k]; uint32_t give = room < left ? room : left; shift[k] += give; left -= give; }
+			float spread = 0.f;
+			for (int k = 0; k < 3; k++) {
+				const float n = (float)(a.size[k] > 1 ? a.size[k] - 1 : 1);
+				const float dx = to_xdc[4 * k + 0] / n, dy = to_xdc[4 * k + 1] / n, dz = to_xdc[4 * k + 2] / n;
+				/* a voxel step along this axis moves the receive distance by at most its length, the transmit distance likewise */
+				spread += 2.0f * std::sqrt(dx * dx + dy * dy + dz * dz) * a.sampling_frequency * a.inv_speed_of_sound * (float)((1u << shift[k]) - 1u);
+			}
+			const bool forced = (mode & 0x100) != 0;
+			if (tile_ok && left == 0 && !(mode & 0x200) && (forced || (spread == spread && spread <= 58.f && lane_step_samples(to_xdc, a) < 1.0f))) {
+				for (int k = 0; k < 3; k++) a.tile_shift[k] = shift[k];
+				for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
+				a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
+				a.tile_window_shift = spread <= 26.f ? 5u : 6u;
+				out.path = DasPath_Tile;
+				why[DasPath_Factored] = "superseded by its block-staged form (das_tile.hip)";
+				why[DasPath_General] = "a specialised kernel applies";
+				out.valid = true;
+				return;
+			}
+			why[DasPath_Tile] = !plan.iq_pipeline || a.interpolation != 2 ? "cubic interpolation of IQ samples only"
+			                  : !tile_ok ? "small frame (channel split), fewer than 4 transmits, or a DAS input of 2 GiB or more"
+			                  : (mode & 0x200) ? "das path flag 0x200: no block staging"
+			                  : "coarse grid or steep delays: a 64 x 16-voxel tile's estimated spread exceeds a 64-sample window";
+		}
 		/* wave-span staging (das_factored.hip): on COARSE grids -- a voxel step along x of a sample of delay or more, as the
 		 * reference harness's 0.23 mm pixels have (tests/throughput.c:20-23) -- the lanes of a gather land in 64 different
 		 * places and the per-wave LDS-DMA copy of the span is cheaper (harness frames: 0.90-0.93 of the gather loop's time;

@@ -1,0 +1,508 @@
+/* das_tile.hip -- delay-and-sum for gfx950 (MI355X): the per-voxel factored kernel with BLOCK-WIDE LDS staging, for fine
+ * grids on which receive and transmit delays both move with both tile axes -- 2-D plane-wave compounding (tx and rx on one
+ * array axis: BASELINE config 2), view planes through row-column data, FORCES -- with cubic interpolation of IQ samples.
+ *
+ * Same arithmetic contract as das_factored.hip (shaders/das.glsl RCA :204-231, FORCES :288-321, cubic :67-97): the sample
+ * index of a voxel is a receive term plus a transmit term, so a thread keeps the receive factors {R index, apod e^{j phi(R)},
+ * apod} of CH channels in registers, walks the transmits computing {T index, e^{j phi(T)}} once per transmit and chunk, and
+ * per (voxel, channel, transmit) term adds the two indices, interpolates and rotate-accumulates.
+ *
+ * das_factored.hip gathers the four taps of a term through L1: two wave64 gather instructions, 32.6 clk per CU per term
+ * (tools/microbench.hip), which is what config 2 waits for (texture path 0.88 busy; 59 VALU clk per term beside it).  Neither
+ * das_staged_cubic.hip's tables (T[a][v], R[c][u]: nothing factorises over the tile axes here) nor wave-span staging (a fine
+ * grid: L1 already serves the gathers at their floor) apply.  Here a 1024-thread block owns a 64 x 16 tile of the image and
+ * stages, per chunk of CH channels and group of AT transmits, the CH x AT RF windows its 1024 voxels touch -- as cubic
+ * POLYNOMIALS (das_staged_cubic.hip: the Catmull-Rom segment between window samples j and j + 1 expanded around its middle,
+ * four complex coefficients, 32 bytes; the staging thread gets its neighbours' samples by one-lane wave shifts):
+ *   * per term: position p = R' + T' (both relative to the window: exact differences), y = p + M rounds it and leaves the
+ *     element index in the low mantissa bits (M = 2^23 + element base; das_staged.hip explains the trick), one v_mul_u32_u24
+ *     gives the LDS address, g = p - (y - M) the offset from the segment's middle; two aligned ds_read_b128, a three-step
+ *     Horner chain and two packed fmas of rotate-accumulate;
+ *   * the window of row (c, a) starts at floor(min R_c) + floor(min T_a) - 1, minima over the BLOCK's voxels, computed by
+ *     the block itself (wave reductions + one LDS exchange): no host bound exists that could be wrong -- a chunk whose spread
+ *     does not fit the window (near field, steep grids) takes das_factored.hip's gather loop instead, block-uniformly;
+ *   * two LDS buffers of CH x AT windows: the loads of group g + 1 are in flight (registers) while group g is consumed,
+ *     converted and written behind it; one barrier per group;
+ *   * sample_rf's range test (1 <= index < S - 2) per wave: waves that cannot leave the RF row run an unchecked loop, the
+ *     others test every term and read a zero element instead.
+ * One block per CU (131 KB of windows, <= 128 VGPRs).  No MFMA: gather-accumulate.
+ */
+#include "das_common.h"
+
+namespace {
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int   lds_i32;
+
+constexpr int      kTileCH      = 4;            /* channels per register chunk */
+constexpr uint32_t kTileThreads = 1024;
+constexpr uint32_t kTileElems   = 2048;         /* window elements per LDS buffer: CH x AT x W; two per thread */
+
+/* das.glsl:187-202 with the per-transmit constants precomputed (das_factored.hip) */
+__device__ __forceinline__ float tile_transmit_distance(const BfTransmit &t, float wx, float wy, float wz)
+{
+	float result = 0.f;
+	if (!(t.flags & BF_TX_NONE)) {
+		float px = (t.flags & BF_TX_ROWS) ? wy : wx;
+		if (t.flags & BF_TX_PLANE) {
+			result = px * t.sin_a + wz * t.cos_a;
+		} else {
+			float dx = px - t.focus_x, dz = wz - t.focus_z;
+			result = hw_sqrt(dx * dx + dz * dz);
+		}
+	}
+	return result;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float tile_dpp(float v)       /* lanes with no source lane keep their own value */
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+/* minimum (MAX: maximum) over each row of 16 lanes, valid in lane 15 of the row */
+template <bool MAX>
+__device__ __forceinline__ float row16_extreme(float v)
+{
+	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+	v = pick(v, tile_dpp<0x111>(v));
+	v = pick(v, tile_dpp<0x112>(v));
+	v = pick(v, tile_dpp<0x114>(v));
+	v = pick(v, tile_dpp<0x118>(v));
+	return v;
+}
+template <bool MAX>
+__device__ __forceinline__ float wave64_extreme(float v)
+{
+	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+	v = row16_extreme<MAX>(v);
+	float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+	float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+	float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
+	float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+	return pick(pick(r1, r2), pick(r3, r4));
+}
+
+/* LDS (byte address 0 = start of the dynamic segment; the kernel has no static LDS):
+ *   [0, 64)                         two unused 32-byte elements (a rounded position of -1 lands there, never consumed)
+ *   [64, 64 + 2 x 2048 x 32)        two buffers of CH x AT windows of W polynomial elements
+ *   then one zero element (checked loop), tfl[A padded to 16] (floor of the block's smallest transmit index, per transmit),
+ *   exch[2][CH][16] (per-wave receive extremes of a chunk) */
+template <int FAMILY, bool CW, int WS>
+__global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
+{
+	constexpr int      CH = kTileCH;
+	constexpr uint32_t W  = 1u << WS;
+	constexpr uint32_t AT = kTileElems / (CH * W);            /* transmits per staged group: 16 (W = 32) or 8 (W = 64) */
+	constexpr uint32_t ES = 8;
+	extern __shared__ __attribute__((aligned(16))) unsigned char tile_lds[];
+
+	/* blockIdx -> tile, thread -> voxel: das_factored.hip */
+	const uint32_t total = p.blocks[0] * p.blocks[1] * p.blocks[2];
+	const uint32_t bid   = blockIdx.x;
+	const uint32_t per   = (total + 7u) / 8u;
+	const uint32_t tile  = (bid & 7u) * per + (bid >> 3);
+	if (p.depth_major != 3u && tile >= total) return;
+	uint32_t bx, by, bz;
+	if (p.depth_major == 3u) {
+		bz = 0;
+		if (!bf_plane_walk(bid, p.blocks[0], p.blocks[1], p.band_rows, bx, by)) return;     /* whole block */
+	} else if (p.depth_major == 2u) {
+		by = tile % p.blocks[1];
+		bx = (tile / p.blocks[1]) % p.blocks[0];
+		bz = tile / (p.blocks[1] * p.blocks[0]);
+	} else if (p.depth_major) {
+		bz = tile % p.blocks[2];
+		bx = (tile / p.blocks[2]) % p.blocks[0];
+		by = tile / (p.blocks[2] * p.blocks[0]);
+	} else {
+		bx = tile % p.blocks[0];
+		by = (tile / p.blocks[0]) % p.blocks[1];
+		bz = tile / (p.blocks[0] * p.blocks[1]);
+	}
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const uint32_t lx  = tid & ((1u << p.tile_shift[0]) - 1u);
+	const uint32_t ly  = (tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u);
+	const uint32_t lz  = (tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u);
+	uint32_t x = (bx << p.tile_shift[0]) + lx, y = (by << p.tile_shift[1]) + ly, zl = (bz << p.tile_shift[2]) + lz;
+	const bool store = x < p.size[0] && y < p.size[1] && zl < p.z_count;
+	/* every thread takes part in the staging and the reductions: threads outside the grid repeat its last voxel (and store nothing) */
+	x = x < p.size[0] ? x : p.size[0] - 1u;
+	y = y < p.size[1] ? y : p.size[1] - 1u;
+	zl = zl < p.z_count ? zl : p.z_count - 1u;
+
+	const int   S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
+	const float turns_per_sample = p.demodulation_frequency * p.inv_sampling_frequency;
+	float wx, wy, wz, xx, xy, xz;
+	{
+		const uint32_t z = p.z_first + zl;
+		const float px = (float)x / fmaxf(1.0f, (float)p.size[0] - 1.0f);       /* das.glsl:374-376 */
+		const float py = (float)y / fmaxf(1.0f, (float)p.size[1] - 1.0f);
+		const float pz = (float)z / fmaxf(1.0f, (float)p.size[2] - 1.0f);
+		m4_point(p.voxel_transform, px, py, pz, wx, wy, wz);
+	}
+	if constexpr (FAMILY == BF_DAS_RCA) m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+	else { xx = wx; xy = wy; xz = wz; }
+	const float zz = xz * xz;
+	float lateral, pitch, f_over_z;
+	if constexpr (FAMILY == BF_DAS_RCA) {
+		const bool rx_rows = (p.transmits[0].flags & BF_RX_ROWS) != 0;
+		lateral  = rx_rows ? xy : xx;
+		pitch    = rx_rows ? p.pitch[1] : p.pitch[0];
+		f_over_z = p.f_number * hw_rcp(__builtin_fabsf(xz));
+	} else {
+		lateral  = xx;
+		pitch    = p.pitch[0];
+		f_over_z = p.f_number * hw_rcp(xz);
+	}
+	const int first_transmit = FAMILY == BF_DAS_RCA ? 0 : (p.sparse != 0);
+	float transmit_yz_squared = 0.f;
+	if constexpr (FAMILY != BF_DAS_RCA) {
+		float dy = xy - p.pitch[1] * (float)C * 0.5f;
+		transmit_yz_squared = dy * dy + zz;
+	}
+	/* (through the constant address space: with buffer loads in flight hipcc would otherwise wait vmcnt(0) for vector copies of
+	 * these wave-uniform reads -- das_factored.hip) */
+	typedef __attribute__((address_space(4))) const f32x4   const_f32x4;
+	typedef __attribute__((address_space(4))) const int16_t const_i16;
+	const_f32x4 *transmits_c = (const_f32x4 *)(uintptr_t)p.transmits;
+	const_i16   *sparse_c    = (const_i16 *)(uintptr_t)p.sparse_elements;
+	auto transmit_index = [&](int a) -> float {
+		if constexpr (FAMILY == BF_DAS_RCA) {
+			const f32x4 t_lo = transmits_c[2 * a], t_hi = transmits_c[2 * a + 1];
+			BfTransmit t;
+			t.sin_a = t_lo.x; t.cos_a = t_lo.y; t.focus_x = t_lo.z; t.focus_z = t_lo.w;
+			{ const float f = t_hi.x; t.flags = __builtin_bit_cast(uint32_t, f); }
+			return (div_speed_of_sound(tile_transmit_distance(t, wx, wy, wz), p) + p.time_offset) * p.sampling_frequency;
+		} else {
+			float tx_channel = p.sparse ? (float)sparse_c[a - first_transmit] : (float)a;
+			float tdx        = xx - p.pitch[0] * tx_channel;
+			return div_speed_of_sound(hw_sqrt(transmit_yz_squared + tdx * tdx) * p.sampling_frequency, p);   /* das.glsl:312 */
+		}
+	};
+
+	/* ---- LDS */
+	const uint32_t A_pad = ((uint32_t)A + 15u) & ~15u;
+	const uint32_t stage_base = 64u;                                   /* element e of buffer b sits at 64 + (b * 2048 + e) * 32 */
+	const uint32_t zero_at    = stage_base + 2u * kTileElems * 32u;    /* one zero element */
+	const uint32_t tfl_at     = zero_at + 32u;
+	const uint32_t exch_at    = tfl_at + 4u * A_pad;                   /* [2][CH][16] floats */
+	auto lds_f = [](uint32_t at) -> lds_f32 * { return (lds_f32 *)(uintptr_t)at; };
+	auto lds_i = [](uint32_t at) -> lds_i32 * { return (lds_i32 *)(uintptr_t)at; };
+	if (tid < 8) *lds_f(zero_at + 4u * tid) = 0.f;
+
+	/* ---- per transmit: floor of the block's smallest transmit index, and the block's largest spread.  Wave extremes meet in the
+	 * (still unused) staging area: [a][wave] minima at byte 64, maxima behind them. */
+	{
+		const uint32_t mins = stage_base, maxs = stage_base + 4u * 16u * A_pad;
+		for (int a = first_transmit; a < A; a++) {
+			const float t = transmit_index(a);
+			const float lo = wave64_extreme<false>(t), hi = wave64_extreme<true>(t);
+			if (lane == 0) { *lds_f(mins + 4u * ((uint32_t)a * 16u + wave)) = lo; *lds_f(maxs + 4u * ((uint32_t)a * 16u + wave)) = hi; }
+		}
+		__syncthreads();
+		float spread = 0.f, tlo_all = __builtin_inff(), thi_all = -__builtin_inff();
+		for (uint32_t a = (uint32_t)first_transmit + tid; a < (uint32_t)A; a += kTileThreads) {
+			float lo = __builtin_inff(), hi = -__builtin_inff();
+			for (uint32_t w = 0; w < 16u; w++) { lo = fminf(lo, *lds_f(mins + 4u * (a * 16u + w))); hi = fmaxf(hi, *lds_f(maxs + 4u * (a * 16u + w))); }
+			const float fl = __builtin_floorf(lo);
+			*lds_i(tfl_at + 4u * a) = (int)fl;
+			spread = fmaxf(spread, __builtin_floorf(hi) - fl);
+			tlo_all = fminf(tlo_all, lo); thi_all = fmaxf(thi_all, hi);
+		}
+		/* the three block-wide scalars: through the exchange area (threads that own no transmit contribute the identities) */
+		const float s1 = wave64_extreme<true>(spread), s2 = wave64_extreme<false>(tlo_all), s3 = wave64_extreme<true>(thi_all);
+		if (lane == 0) { *lds_f(exch_at + 4u * wave) = s1; *lds_f(exch_at + 4u * (16u + wave)) = s2; *lds_f(exch_at + 4u * (32u + wave)) = s3; }
+		__syncthreads();
+	}
+	float tspread_f = 0.f, t_lo = __builtin_inff(), t_hi = -__builtin_inff();
+	for (uint32_t w = 0; w < 16u; w++) {
+		tspread_f = fmaxf(tspread_f, *lds_f(exch_at + 4u * w));
+		t_lo = fminf(t_lo, *lds_f(exch_at + 4u * (16u + w)));
+		t_hi = fmaxf(t_hi, *lds_f(exch_at + 4u * (32u + w)));
+	}
+	tspread_f = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tspread_f)));
+	t_lo      = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t_lo)));
+	t_hi      = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t_hi)));
+	const bool t_finite = tspread_f == tspread_f && tspread_f < 1.0e6f;
+	__syncthreads();                                                   /* the staging area is free again */
+
+	/* ---- staging: thread tid owns elements e = tid and tid + 1024 of a group: window e / W (= k * AT + a_local), sample e % W */
+	const __amdgpu_buffer_rsrc_t rf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<void *>(p.rf), 0, (int)((uint32_t)C * (uint32_t)A * (uint32_t)S * ES), 0x00020000);
+	auto lane_shift = [](float v, bool up) {
+		return up ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true))    /* lane i <- i + 1 */
+		          : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));   /* lane i <- i - 1 */
+	};
+
+	const char *rf = (const char *)p.rf;
+	sample_t<true> coherent = {0.f, 0.f};
+	float incoherent = 0.f;
+
+	for (int c0 = 0; c0 < C; c0 += CH) {
+		/* receive factors of the chunk (das_factored.hip) */
+		float r_index[CH], r_re[CH], r_im[CH], r_apod[CH];
+		bool  any = false;
+		#pragma unroll
+		for (int k = 0; k < CH; k++) {
+			const int   channel = c0 + k;
+			const float dx      = lateral - (float)channel * pitch;
+			const float a_arg   = __builtin_fabsf(dx * f_over_z);
+			const bool  pass    = a_arg < 0.5f && channel < C;
+			const float dist    = hw_sqrt(dx * dx + zz);
+			const float index   = FAMILY == BF_DAS_RCA ? div_speed_of_sound(dist, p) * p.sampling_frequency
+			                                           : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+			const float apod    = pass ? apodize(a_arg) : 0.f;
+			r_index[k] = pass ? index : -1.0e9f;
+			r_apod[k]  = apod;
+			const float turns = hw_fract(turns_per_sample * index);
+			r_re[k] = apod * hw_cos_turns(turns);
+			r_im[k] = apod * hw_sin_turns(turns);
+			any |= pass;
+		}
+		/* block-wide extremes of the receive index over the voxels inside each channel's aperture */
+		__syncthreads();                                               /* (the exchange area's previous readers are done) */
+		#pragma unroll
+		for (int k = 0; k < CH; k++) {
+			const bool  pass = r_index[k] > -1.0e8f;
+			const float lo = wave64_extreme<false>(pass ? r_index[k] :  __builtin_inff());
+			const float hi = wave64_extreme<true >(pass ? r_index[k] : -__builtin_inff());
+			if (lane == 0) { *lds_f(exch_at + 4u * ((uint32_t)k * 16u + wave)) = lo; *lds_f(exch_at + 4u * ((uint32_t)(CH + k) * 16u + wave)) = hi; }
+		}
+		__syncthreads();
+		float rlo[CH], rhi[CH];
+		bool  fits = t_finite, some = false;
+		#pragma unroll
+		for (int k = 0; k < CH; k++) {
+			/* every wave reduces the 16 wave values itself (lanes 0-15 hold them; one row of DPP shifts) */
+			const float vlo = *lds_f(exch_at + 4u * ((uint32_t)k * 16u + (lane & 15u)));
+			const float vhi = *lds_f(exch_at + 4u * ((uint32_t)(CH + k) * 16u + (lane & 15u)));
+			rlo[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row16_extreme<false>(vlo)), 15));
+			rhi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row16_extreme<true >(vhi)), 15));
+			const bool on = rlo[k] <= rhi[k];
+			some |= on;
+			/* segment floor(index) - (window start) must lie in [1, W - 3]: receive spread + transmit spread + 5 (two floors, the sum's
+			 * rounding, the early sample, the taps) */
+			fits = fits && (!on || (__builtin_floorf(rhi[k]) - __builtin_floorf(rlo[k])) + tspread_f <= (float)(W - 6u));
+		}
+		if (!some) continue;                                           /* block uniform: nobody is inside any aperture of the chunk */
+
+		sample_t<true> part[CH];
+		float          part_abs[CH];
+		f32x2 acc1[CH], acc2[CH];
+		#pragma unroll
+		for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; part_abs[k] = 0.f; }
+
+		if (fits) {
+			/* ---------------- staged path */
+			int   rfl[CH];
+			float r_rel[CH];
+			bool  wave_safe = true;
+			#pragma unroll
+			for (int k = 0; k < CH; k++) {
+				const bool on = rlo[k] <= rhi[k];
+				const float flo = on ? __builtin_floorf(rlo[k]) : 0.f;
+				rfl[k] = (int)flo;
+				const bool pass = r_index[k] > -1.0e8f;
+				/* lanes outside the aperture (weight zero, and it stays zero) take the smallest index inside it: their reads stay in the
+				 * window; a channel nobody uses reads from the window's start */
+				const float idx = pass ? r_index[k] : (on ? rlo[k] : 0.f);
+				r_rel[k] = idx - flo;                                      /* exact */
+				/* this wave's lanes inside the aperture never leave the RF row for any transmit (one sample of margin for the sum's rounding) */
+				const float wlo = wave64_extreme<false>(pass ? r_index[k] :  __builtin_inff());
+				const float whi = wave64_extreme<true >(pass ? r_index[k] : -__builtin_inff());
+				wave_safe = wave_safe && (wlo > whi || (wlo + t_lo >= 2.0f && whi + t_hi < (float)(S - 3)));
+			}
+			const uint32_t chunk_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)c0 * (uint32_t)A));
+			const uint32_t groups = ((uint32_t)(A - first_transmit) + AT - 1u) / AT;
+			/* window of element e: k = e / (AT W), a_local = (e / W) % AT; the thread's two elements are tid and tid + 1024, and AT W = 512:
+			 * both channels are wave uniform.  (The floors go through an opaque copy: hipcc otherwise folds the selects below into ONE load
+			 * from rfl[] at a run-time index, keeps rfl[] in memory for it and "promotes" that memory to 16 KB of static LDS in front of
+			 * the dynamic segment, whose address 0 this kernel relies on.) */
+			const uint32_t my_j = tid & (W - 1u);
+			const uint32_t e0 = tid, e1 = tid + kTileThreads;
+			const uint32_t k0 = wave / (AT * W / 64u), k1 = k0 + kTileThreads / (AT * W);
+			const uint32_t al0 = (e0 / W) % AT, al1 = (e1 / W) % AT;
+			int rf0 = rfl[0], rf1 = rfl[1], rf2 = rfl[2], rf3 = rfl[3];
+			asm volatile("" : "+v"(rf0), "+v"(rf1), "+v"(rf2), "+v"(rf3));
+			const int rfl_0 = k0 == 0 ? rf0 : rf1;                         /* k0 in {0, 1}, k1 in {2, 3} */
+			const int rfl_1 = k1 == 2 ? rf2 : rf3;
+			auto load_one = [&](uint32_t g, uint32_t kk, uint32_t al, int rk) -> f32x2 {
+				const uint32_t a = (uint32_t)first_transmit + g * AT + al;
+				uint32_t off = 0x80000000u;                                /* transmits past the last (a ragged final group) stage zeros */
+				if (a < (uint32_t)A && c0 + (int)kk < C) {
+					const int first = rk + *lds_i(tfl_at + 4u * a) - 1 + (int)my_j;              /* window sample j = sample floor(rmin) + floor(tmin) - 1 + j */
+					/* a window that starts before its row or ends behind it holds samples of the neighbouring rows (or zeros beyond the buffer):
+					 * never consumed -- unchecked waves stay inside their row, checked waves test every term */
+					off = ((chunk_rows + kk * (uint32_t)A + a) * (uint32_t)S + (uint32_t)first) * ES;
+				}
+				i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rf_rsrc, (int)off, 0, 0);
+				return __builtin_bit_cast(f32x2, v);
+			};
+			auto store_one = [&](uint32_t buf, uint32_t e, f32x2 s1) {
+				/* das_staged_cubic.hip: Catmull-Rom segment [j, j + 1] (das.glsl:67-97) re-expanded around t = 1/2 */
+				const float p1x = s1.x, p1y = s1.y;
+				const float p2x = lane_shift(p1x, true),  p2y = lane_shift(p1y, true);
+				const float p3x = lane_shift(p2x, true),  p3y = lane_shift(p2y, true);
+				const float p0x = lane_shift(p1x, false), p0y = lane_shift(p1y, false);
+				const f32x2 P0 = {p0x, p0y}, P1 = {p1x, p1y}, P2 = {p2x, p2y}, P3 = {p3x, p3y};
+				const f32x2 T1 = 0.5f * (P2 - P0), T2 = 0.5f * (P3 - P1);
+				const f32x2 a2 = 3.f * (P2 - P1) - 2.f * T1 - T2, a3 = 2.f * (P1 - P2) + T1 + T2;
+				const f32x2 b0 = P1 + 0.5f * T1 + 0.25f * a2 + 0.125f * a3;
+				const f32x2 b1 = T1 + a2 + 0.75f * a3;
+				const f32x2 b2 = a2 + 1.5f * a3;
+				const uint32_t at = stage_base + (buf * kTileElems + e) * 32u;
+				*(lds_f32x4 *)(uintptr_t)at         = f32x4{b0.x, b0.y, b1.x, b1.y};
+				*(lds_f32x4 *)(uintptr_t)(at + 16u) = f32x4{b2.x, b2.y, a3.x, a3.y};
+			};
+			/* one group of AT transmits out of buffer `buf` */
+			auto consume = [&](auto checked, uint32_t g, uint32_t buf) {
+				constexpr bool CHECK = decltype(checked)::value;
+				for (uint32_t al = 0; al < AT; al++) {
+					const int a = first_transmit + (int)(g * AT + al);
+					if (a >= A) break;                                     /* block uniform */
+					float t_index = transmit_index(a);
+					asm volatile("" : "+v"(t_index));
+					const int   tf = __builtin_amdgcn_readfirstlane(*lds_i(tfl_at + 4u * (uint32_t)a));
+					const float turns = hw_fract(turns_per_sample * t_index);
+					const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
+					const float t_rel = (t_index - (float)tf) + 0.5f;        /* both steps exact; + 1/2: y below rounds to the SEGMENT (the window starts one sample early) */
+					uint32_t at[CH]; float gm[CH];
+					#pragma unroll
+					for (int k = 0; k < CH; k++) {
+						/* element index 2 + buf * 2048 + (k * AT + al) * W + segment in the low mantissa bits of y = p + M */
+						const uint32_t m_bits = 0x4B000002u + buf * kTileElems + ((uint32_t)k * AT + al) * W;
+						const float M = __builtin_bit_cast(float, m_bits);
+						const float pos = r_rel[k] + t_rel;
+						const float yv = pos + M;
+						gm[k] = pos - (yv - M);
+						const uint32_t yb = __builtin_bit_cast(uint32_t, yv);
+						asm("v_mul_u32_u24 %0, 32, %1" : "=v"(at[k]) : "v"(yb));
+						if constexpr (CHECK) {
+							/* absolute tap k_abs = segment - 1 + the two floors; valid for 1 <= k_abs < S - 2; and -- the window is the block's own
+							 * construction -- never outside it: a segment beyond [1, W - 3] would be a bug in this kernel, so it reads zeros too */
+							const uint32_t seg = yb - m_bits;
+							const uint32_t k_abs = (uint32_t)((int)seg - 1 + rfl[k] + tf);
+							at[k] = ((k_abs - 1u) < (uint32_t)(S - 3) && (seg - 1u) <= W - 4u) ? at[k] : zero_at;
+						}
+					}
+					f32x4 lo[CH], hi[CH];
+					#pragma unroll
+					for (int k = 0; k < CH; k++) { lo[k] = *(lds_f32x4 *)(uintptr_t)at[k]; hi[k] = *(lds_f32x4 *)(uintptr_t)(at[k] + 16u); }
+					#pragma unroll
+					for (int k = 0; k < CH; k++) {
+						f32x2 sv = f32x2{hi[k].z, hi[k].w} * gm[k] + f32x2{hi[k].x, hi[k].y};
+						sv = sv * gm[k] + f32x2{lo[k].z, lo[k].w};
+						sv = sv * gm[k] + f32x2{lo[k].x, lo[k].y};
+						acc1[k] += sv.x * cs;
+						acc2[k] += sv.y * cs;
+						if constexpr (CW) part_abs[k] += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+					}
+				}
+			};
+			f32x2 in0 = load_one(0, k0, al0, rfl_0), in1 = load_one(0, k1, al1, rfl_1);
+			__syncthreads();                       /* the previous chunk's last group has been consumed by everyone */
+			store_one(0, e0, in0); store_one(0, e1, in1);
+			__syncthreads();
+			for (uint32_t g = 0; g < groups; g++) {
+				const uint32_t buf = g & 1u;
+				const bool more = g + 1 < groups;
+				if (more) { in0 = load_one(g + 1, k0, al0, rfl_0); in1 = load_one(g + 1, k1, al1, rfl_1); }      /* in flight during the arithmetic */
+				if (wave_safe) consume(std::false_type{}, g, buf);
+				else           consume(std::true_type{},  g, buf);
+				if (more) { store_one(buf ^ 1u, e0, in0); store_one(buf ^ 1u, e1, in1); }    /* the other buffer: its readers passed the barrier below a group ago */
+				__syncthreads();
+			}
+		} else {
+			/* ---------------- das_factored.hip's gather loop (near field, steep grids: the spread does not fit the window) */
+			for (int a = first_transmit; a < A; a++) {
+				float t_index = transmit_index(a);
+				asm volatile("" : "+v"(t_index));
+				const float turns = hw_fract(turns_per_sample * t_index);
+				const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
+				const uint32_t row0 = ((uint32_t)c0 * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES;
+				const uint32_t row_step = (uint32_t)A * (uint32_t)S * ES;
+				float frac[CH]; uint32_t off[CH];
+				#pragma unroll
+				for (int k = 0; k < CH; k++) {
+					const float index = t_index + r_index[k];
+					frac[k] = hw_fract(index);
+					const uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
+					off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+				}
+				f32x4 d0[CH], d1[CH];
+				#pragma unroll
+				for (int k = 0; k < CH; k++) { d0[k] = gather<f32x4_a8>(rf, off[k]); d1[k] = gather<f32x4_a8>(rf, off[k] + 16); }
+				#pragma unroll
+				for (int k = 0; k < CH; k++) {
+					f32x2 s0 = {d0[k].x, d0[k].y}, s1 = {d0[k].z, d0[k].w}, s2 = {d1[k].x, d1[k].y}, s3 = {d1[k].z, d1[k].w};
+					f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
+					f32x2 c3 = (T1 + T2) - 2.0f * D;
+					f32x2 c2 = (D - T1) - c3;
+					float t  = frac[k];
+					f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
+					acc1[k] += sv.x * cs;
+					acc2[k] += sv.y * cs;
+					if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
+				}
+			}
+		}
+
+		#pragma unroll
+		for (int k = 0; k < CH; k++) {
+			part[k] = f32x2{acc1[k].x - acc2[k].y, acc1[k].y + acc2[k].x};
+			coherent.x += r_re[k] * part[k].x - r_im[k] * part[k].y;
+			coherent.y += r_im[k] * part[k].x + r_re[k] * part[k].y;
+			if constexpr (CW) incoherent += r_apod[k] * part_abs[k];
+		}
+		(void)any;
+	}
+
+	if (store) {
+		const uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
+		sample_t<true> v = coherent;
+		if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
+		reinterpret_cast<sample_t<true> *>(p.out)[out_index] = v;
+	}
+}
+
+template <int FAMILY, bool CW, int WS>
+hipError_t launch_tile(const BfDasArgs *a, hipStream_t s)
+{
+	const uint32_t total = a->blocks[0] * a->blocks[1] * a->blocks[2];
+	const uint32_t grid  = a->depth_major == 3u ? bf_plane_walk_blocks(a->blocks[0], a->blocks[1], a->band_rows) : ((total + 7u) / 8u) * 8u;
+	const uint32_t A_pad = ((uint32_t)a->acquisition_count + 15u) & ~15u;
+	uint32_t lds = 64u + 2u * kTileElems * 32u + 32u + 4u * A_pad + 4u * 2u * kTileCH * 16u + 64u;
+	const uint32_t scratch = 64u + 2u * 4u * 16u * A_pad;             /* the transmit pass borrows the staging area */
+	if (scratch > lds) lds = scratch;
+	auto kernel = das_tile_kernel<FAMILY, CW, WS>;
+	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(kernel, dim3(grid), dim3(kTileThreads), lds, s, *a);
+	return hipGetLastError();
+}
+
+template <int FAMILY, bool CW>
+hipError_t launch_tile_window(const BfDasArgs *a, hipStream_t s)
+{
+	return a->tile_window_shift == 6 ? launch_tile<FAMILY, CW, 6>(a, s) : launch_tile<FAMILY, CW, 5>(a, s);
+}
+
+} // namespace
+
+/* IQ samples, cubic interpolation, RCA-family (one receive orientation) and FORCES frames whose tile is 1024 voxels (tile_shift
+ * sums to 10) with the lanes of a wave consecutive voxels of one axis; DAS input under 2 GiB (staging offsets) */
+extern "C" hipError_t bf_launch_das_tile(const BfDasArgs *a, hipStream_t s)
+{
+	if (!a->complex_data || a->interpolation != BF_INTERP_CUBIC || a->split_shift) return hipErrorInvalidValue;
+	if (a->tile_shift[0] + a->tile_shift[1] + a->tile_shift[2] != 10 || a->sample_count < 8) return hipErrorInvalidValue;
+	if ((uint64_t)a->channel_count * (uint64_t)a->acquisition_count * (uint64_t)a->sample_count * 8u >= (1ull << 31)) return hipErrorInvalidValue;
+	switch (a->family) {
+	case BF_DAS_RCA:    return a->coherency_weighting ? launch_tile_window<BF_DAS_RCA, true>(a, s)    : launch_tile_window<BF_DAS_RCA, false>(a, s);
+	case BF_DAS_FORCES: return a->coherency_weighting ? launch_tile_window<BF_DAS_FORCES, true>(a, s) : launch_tile_window<BF_DAS_FORCES, false>(a, s);
+	}
+	return hipErrorInvalidValue;
+}

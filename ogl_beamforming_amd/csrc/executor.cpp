@@ -582,6 +582,9 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				case DasPath_Factored:
 					ok &= HIP_OK(bf_launch_das_factored(&a, s));
 					break;
+				case DasPath_Tile:
+					ok &= HIP_OK(bf_launch_das_tile(&a, s));
+					break;
 				default:
 					ok &= HIP_OK(bf_launch_das(&a, s));
 					break;

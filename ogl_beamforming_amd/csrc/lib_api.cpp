@@ -595,10 +595,11 @@ uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDe
 	out->path = d.path == DasPath_Zero ? -2 : d.path;
 	std::snprintf(out->kernel, sizeof(out->kernel), "%s", das_kernel_name(d.path));
 	std::snprintf(out->name, sizeof(out->name), "%s", das_path_name(d.path));
-	for (int k = 0; k < DasPath_Count && k < 6; k++) std::snprintf(out->declined[k], sizeof(out->declined[k]), "%s", d.why[k].c_str());
+	for (int k = 0; k < DasPath_Count && k < 8; k++) std::snprintf(out->declined[k], sizeof(out->declined[k]), "%s", d.why[k].c_str());
 	for (int k = 0; k < 3; k++) { out->tile_shift[k] = d.a.tile_shift[k]; out->blocks[k] = d.a.blocks[k]; }
 	out->split_shift = d.a.split_shift; out->tile_walk = d.path == DasPath_Hercules ? d.herc.depth_major : (d.path == DasPath_Gather || d.path == DasPath_Staged) ? d.sep.depth_major : d.a.depth_major;
 	out->span_stage = d.a.span_stage;
+	out->tile_window_samples = d.path == DasPath_Tile ? 1u << d.a.tile_window_shift : 0u;
 	if (d.path == DasPath_Gather || d.path == DasPath_Staged) {
 		out->u_axis = d.sep.u_axis; out->u_shift = d.sep.u_shift; out->v_shift = d.sep.v_shift; out->window_samples = d.path == DasPath_Staged ? d.sep.window_samples : 0;
 		out->uniform_tables = d.sep.uniform; out->lds_bytes = d.sep.lds_bytes; out->threads = d.sep.threads; out->channel_chunk = d.sep.channel_chunk;

@@ -235,5 +235,5 @@ def describe_das(bp, filters=(), slot=0):
     assert L.beamformer_push_simple_parameters_at(C.byref(bp), slot), last_error()
     d = P.HipDasDescription()
     assert L.beamformer_hip_describe_das(slot, C.byref(d)), last_error()
-    reasons = {k: bytes(d.declined[k]).split(b"\0")[0].decode() for k in range(6)}
+    reasons = {k: bytes(d.declined[k]).split(b"\0")[0].decode() for k in range(8)}
     return int(d.path), d.kernel.decode(), d.name.decode(), reasons, d

@@ -406,3 +406,45 @@ def test_factored_kernel_wave_span_staging(name, bflib, oracle):
         lib.beamformer_hip_set_das_path(0)
     compare(span, ref, acq, flags)
     assert np.array_equal(span.view(np.uint32), gather.view(np.uint32)), "wave-span staging and the gather loop differ"
+
+
+def tile_candidates():
+    from ogl_beamforming_amd import lib as bflib_mod
+    out = []
+    lib = bflib_mod.library()
+    lib.beamformer_hip_set_das_path(0x14 | 0x100)
+    try:
+        for n in sorted(cases.CASES):
+            acq = cases.make(n)
+            if bflib_mod.describe_das(acq.bp, acq.filters)[0] == 6:
+                out.append(n)
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    return sorted(out)
+
+
+TILE = tile_candidates()
+
+
+def test_block_staging_candidates():
+    assert len(TILE) >= 4, TILE
+
+
+@pytest.mark.parametrize("name", TILE)
+def test_factored_kernel_block_staging(name, bflib, oracle):
+    """das_tile.hip (flag 0x100: a 1024-thread block stages the RF windows of its 64 x 16 voxels as cubic polynomials in LDS;
+    automatic on fine grids with tx and rx on one axis -- BASELINE config 2) against the oracle, and against das_factored.hip's
+    gather loop (flag 0x200) within the parity tolerance: the polynomial re-expansion rounds differently, so not bit for bit."""
+    acq = cases.make(name)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    try:
+        lib.beamformer_hip_set_das_path(0x14 | 0x100)
+        tile = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
+        assert last_das_path(bflib) == 6
+        lib.beamformer_hip_set_das_path(0x14 | 0x200)
+        np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters))
+        assert last_das_path(bflib) != 6
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+    compare(tile, ref, acq, flags)
