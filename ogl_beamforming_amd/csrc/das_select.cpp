@@ -520,6 +520,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	out.depth_axis = choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
 	for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 	a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
+	out.general = a;
 
 	if (a.family < 0 || a.interpolation < 0 || a.interpolation > 2) {
 		out.path = DasPath_Zero;

@@ -52,6 +52,7 @@ struct DasDecision {
 	uint64_t generation = 0, hooks_version = 0;              /* what it was computed for */
 	uint32_t z_first = 0, z_count = 0, mode = 0;
 	BfDasArgs a{};                      /* everything but the device pointers */
+	BfDasArgs general{};                /* the same with the general kernel's tile geometry (no channel split): what the pair count runs with */
 	int      path = DasPath_General;
 	int      depth_axis = 2;
 	BfSeparableArgs sep{};              /* Gather: its geometry; Staged: the staged kernel's */

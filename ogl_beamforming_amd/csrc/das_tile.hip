@@ -73,16 +73,31 @@ __device__ __forceinline__ float row16_extreme(float v)
 	v = pick(v, tile_dpp<0x118>(v));
 	return v;
 }
+/* minimum (MAX: maximum) over the wave, valid in lane 63: four shifts inside each row of 16, then the last lane of a row into the
+ * rows behind it (gfx9's row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) */
 template <bool MAX>
-__device__ __forceinline__ float wave64_extreme(float v)
+__device__ __forceinline__ float wave64_extreme_lane63(float v)
 {
 	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
 	v = row16_extreme<MAX>(v);
-	float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
-	float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
-	float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
-	float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-	return pick(pick(r1, r2), pick(r3, r4));
+	const int b15 = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false);
+	v = pick(v, __builtin_bit_cast(float, b15));
+	const int b31 = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false);
+	v = pick(v, __builtin_bit_cast(float, b31));
+	return v;
+}
+template <bool MAX>
+__device__ __forceinline__ float wave64_extreme(float v)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave64_extreme_lane63<MAX>(v)), 63));
+}
+
+/* 32 x the low 24 bits: the byte address of the polynomial element whose index sits in the low mantissa bits of y */
+__device__ __forceinline__ uint32_t element_address(uint32_t y_bits)
+{
+	uint32_t at;
+	asm("v_mul_u32_u24 %0, 32, %1" : "=v"(at) : "v"(y_bits));
+	return at;
 }
 
 /* LDS (byte address 0 = start of the dynamic segment; the kernel has no static LDS):
@@ -128,7 +143,6 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 	const uint32_t ly  = (tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u);
 	const uint32_t lz  = (tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u);
 	uint32_t x = (bx << p.tile_shift[0]) + lx, y = (by << p.tile_shift[1]) + ly, zl = (bz << p.tile_shift[2]) + lz;
-	const bool store = x < p.size[0] && y < p.size[1] && zl < p.z_count;
 	/* every thread takes part in the staging and the reductions: threads outside the grid repeat its last voxel (and store nothing) */
 	x = x < p.size[0] ? x : p.size[0] - 1u;
 	y = y < p.size[1] ? y : p.size[1] - 1u;
@@ -243,9 +257,9 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 	float incoherent = 0.f;
 
 	for (int c0 = 0; c0 < C; c0 += CH) {
-		/* receive factors of the chunk (das_factored.hip) */
-		float r_index[CH], r_re[CH], r_im[CH], r_apod[CH];
-		bool  any = false;
+		/* receive index of the chunk's channels (das_factored.hip); the weights -- apodization and e^{j phi(R)} -- are only needed when the
+		 * chunk's sums are folded in, and are computed there: twelve registers the transmit loop does not have to carry */
+		float r_index[CH];
 		#pragma unroll
 		for (int k = 0; k < CH; k++) {
 			const int   channel = c0 + k;
@@ -255,22 +269,17 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			const float dist    = hw_sqrt(dx * dx + zz);
 			const float index   = FAMILY == BF_DAS_RCA ? div_speed_of_sound(dist, p) * p.sampling_frequency
 			                                           : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
-			const float apod    = pass ? apodize(a_arg) : 0.f;
 			r_index[k] = pass ? index : -1.0e9f;
-			r_apod[k]  = apod;
-			const float turns = hw_fract(turns_per_sample * index);
-			r_re[k] = apod * hw_cos_turns(turns);
-			r_im[k] = apod * hw_sin_turns(turns);
-			any |= pass;
 		}
 		/* block-wide extremes of the receive index over the voxels inside each channel's aperture */
+		float wlo[CH], whi[CH];
 		__syncthreads();                                               /* (the exchange area's previous readers are done) */
 		#pragma unroll
 		for (int k = 0; k < CH; k++) {
-			const bool  pass = r_index[k] > -1.0e8f;
-			const float lo = wave64_extreme<false>(pass ? r_index[k] :  __builtin_inff());
-			const float hi = wave64_extreme<true >(pass ? r_index[k] : -__builtin_inff());
-			if (lane == 0) { *lds_f(exch_at + 4u * ((uint32_t)k * 16u + wave)) = lo; *lds_f(exch_at + 4u * ((uint32_t)(CH + k) * 16u + wave)) = hi; }
+			const bool pass = r_index[k] > -1.0e8f;
+			wlo[k] = wave64_extreme_lane63<false>(pass ? r_index[k] :  __builtin_inff());       /* (valid in lane 63) */
+			whi[k] = wave64_extreme_lane63<true >(pass ? r_index[k] : -__builtin_inff());
+			if (lane == 63) { *lds_f(exch_at + 4u * ((uint32_t)k * 16u + wave)) = wlo[k]; *lds_f(exch_at + 4u * ((uint32_t)(CH + k) * 16u + wave)) = whi[k]; }
 		}
 		__syncthreads();
 		float rlo[CH], rhi[CH];
@@ -290,8 +299,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 		}
 		if (!some) continue;                                           /* block uniform: nobody is inside any aperture of the chunk */
 
-		sample_t<true> part[CH];
-		float          part_abs[CH];
+		float part_abs[CH];
 		f32x2 acc1[CH], acc2[CH];
 		#pragma unroll
 		for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; part_abs[k] = 0.f; }
@@ -299,22 +307,20 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 		if (fits) {
 			/* ---------------- staged path */
 			int   rfl[CH];
-			float r_rel[CH];
+			f32x2 r_rel[CH / 2];
 			bool  wave_safe = true;
 			#pragma unroll
 			for (int k = 0; k < CH; k++) {
 				const bool on = rlo[k] <= rhi[k];
 				const float flo = on ? __builtin_floorf(rlo[k]) : 0.f;
-				rfl[k] = (int)flo;
+				rfl[k] = __builtin_amdgcn_readfirstlane((int)flo);
 				const bool pass = r_index[k] > -1.0e8f;
 				/* lanes outside the aperture (weight zero, and it stays zero) take the smallest index inside it: their reads stay in the
 				 * window; a channel nobody uses reads from the window's start */
 				const float idx = pass ? r_index[k] : (on ? rlo[k] : 0.f);
-				r_rel[k] = idx - flo;                                      /* exact */
+				r_rel[k / 2][k & 1] = idx - flo;                          /* exact */
 				/* this wave's lanes inside the aperture never leave the RF row for any transmit (one sample of margin for the sum's rounding) */
-				const float wlo = wave64_extreme<false>(pass ? r_index[k] :  __builtin_inff());
-				const float whi = wave64_extreme<true >(pass ? r_index[k] : -__builtin_inff());
-				wave_safe = wave_safe && (wlo > whi || (wlo + t_lo >= 2.0f && whi + t_hi < (float)(S - 3)));
+				wave_safe = wave_safe && (wlo[k] > whi[k] || (wlo[k] + t_lo >= 2.0f && whi[k] + t_hi < (float)(S - 3)));      /* (lane 63's verdict counts) */
 			}
 			const uint32_t chunk_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)c0 * (uint32_t)A));
 			const uint32_t groups = ((uint32_t)(A - first_transmit) + AT - 1u) / AT;
@@ -349,73 +355,103 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				const float p3x = lane_shift(p2x, true),  p3y = lane_shift(p2y, true);
 				const float p0x = lane_shift(p1x, false), p0y = lane_shift(p1y, false);
 				const f32x2 P0 = {p0x, p0y}, P1 = {p1x, p1y}, P2 = {p2x, p2y}, P3 = {p3x, p3y};
-				const f32x2 T1 = 0.5f * (P2 - P0), T2 = 0.5f * (P3 - P1);
-				const f32x2 a2 = 3.f * (P2 - P1) - 2.f * T1 - T2, a3 = 2.f * (P1 - P2) + T1 + T2;
-				const f32x2 b0 = P1 + 0.5f * T1 + 0.25f * a2 + 0.125f * a3;
-				const f32x2 b1 = T1 + a2 + 0.75f * a3;
-				const f32x2 b2 = a2 + 1.5f * a3;
+				/* p(1/2 + g) = b0 + b1 g + b2 g^2 + a3 g^3, the four coefficients straight from the taps:
+				 *   b0 = (9 (P1 + P2) - (P0 + P3)) / 16     b1 = (11 (P2 - P1) - (P3 - P0)) / 8
+				 *   b2 = ((P0 + P3) - (P1 + P2)) / 4        a3 = ((P3 - P0) - 3 (P2 - P1)) / 2 */
+				const f32x2 S12 = P1 + P2, S03 = P0 + P3, D12 = P2 - P1, D03 = P3 - P0;
+				const f32x2 b0 = 0.5625f * S12 - 0.0625f * S03;
+				const f32x2 b1 = 1.375f * D12 - 0.125f * D03;
+				const f32x2 b2 = 0.25f * (S03 - S12);
+				const f32x2 a3 = 0.5f * D03 - 1.5f * D12;
 				const uint32_t at = stage_base + (buf * kTileElems + e) * 32u;
 				*(lds_f32x4 *)(uintptr_t)at         = f32x4{b0.x, b0.y, b1.x, b1.y};
 				*(lds_f32x4 *)(uintptr_t)(at + 16u) = f32x4{b2.x, b2.y, a3.x, a3.y};
 			};
-			/* one group of AT transmits out of buffer `buf` */
-			auto consume = [&](auto checked, uint32_t g, uint32_t buf) {
+			/* one transmit of a group: its phase factor, and per channel the LDS address of the term's polynomial and the offset from the
+			 * segment's middle */
+			struct Term { f32x2 cs; f32x2 gm[CH / 2]; uint32_t at[CH]; };
+			auto prepare = [&](auto checked, uint32_t g, uint32_t buf, uint32_t al, int tf_lanes, int tfh_lanes) -> Term {
 				constexpr bool CHECK = decltype(checked)::value;
-				for (uint32_t al = 0; al < AT; al++) {
-					const int a = first_transmit + (int)(g * AT + al);
-					if (a >= A) break;                                     /* block uniform */
-					float t_index = transmit_index(a);
-					asm volatile("" : "+v"(t_index));
-					const int   tf = __builtin_amdgcn_readfirstlane(*lds_i(tfl_at + 4u * (uint32_t)a));
-					const float turns = hw_fract(turns_per_sample * t_index);
-					const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
-					const float t_rel = (t_index - (float)tf) + 0.5f;        /* both steps exact; + 1/2: y below rounds to the SEGMENT (the window starts one sample early) */
-					uint32_t at[CH]; float gm[CH];
-					#pragma unroll
-					for (int k = 0; k < CH; k++) {
-						/* element index 2 + buf * 2048 + (k * AT + al) * W + segment in the low mantissa bits of y = p + M */
-						const uint32_t m_bits = 0x4B000002u + buf * kTileElems + ((uint32_t)k * AT + al) * W;
-						const float M = __builtin_bit_cast(float, m_bits);
-						const float pos = r_rel[k] + t_rel;
-						const float yv = pos + M;
-						gm[k] = pos - (yv - M);
-						const uint32_t yb = __builtin_bit_cast(uint32_t, yv);
-						asm("v_mul_u32_u24 %0, 32, %1" : "=v"(at[k]) : "v"(yb));
-						if constexpr (CHECK) {
-							/* absolute tap k_abs = segment - 1 + the two floors; valid for 1 <= k_abs < S - 2; and -- the window is the block's own
-							 * construction -- never outside it: a segment beyond [1, W - 3] would be a bug in this kernel, so it reads zeros too */
-							const uint32_t seg = yb - m_bits;
-							const uint32_t k_abs = (uint32_t)((int)seg - 1 + rfl[k] + tf);
-							at[k] = ((k_abs - 1u) < (uint32_t)(S - 3) && (seg - 1u) <= W - 4u) ? at[k] : zero_at;
-						}
+				Term term;
+				const int a = first_transmit + (int)(g * AT + al);
+				float t_index = transmit_index(a);
+				asm volatile("" : "+v"(t_index));
+				const int   tf = __builtin_amdgcn_readlane(tf_lanes, (int)al);
+				const float turns = hw_fract(turns_per_sample * t_index);
+				term.cs = f32x2{hw_cos_turns(turns), hw_sin_turns(turns)};
+				/* + 1/2: y below rounds to the SEGMENT (the window starts one sample early); exact (multiples of an ulp of t_index, small) */
+				const float t_rel = t_index - __builtin_bit_cast(float, __builtin_amdgcn_readlane(tfh_lanes, (int)al));
+				#pragma unroll
+				for (int h = 0; h < CH / 2; h++) {
+					/* element index 2 + buf * 2048 + (k * AT + al) * W + segment in the low mantissa bits of y = p + M */
+					const uint32_t m0 = 0x4B000002u + buf * kTileElems + ((uint32_t)(2 * h) * AT + al) * W, m1 = m0 + AT * W;
+					const f32x2 M = {__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1)};
+					const f32x2 pos = r_rel[h] + t_rel;
+					const f32x2 yv = pos + M;
+					term.gm[h] = pos - (yv - M);
+					/* (copies first: hipcc's __builtin_bit_cast of a vector ELEMENT reads element 0 whichever one is named) */
+					const float    y0 = yv.x, y1 = yv.y;
+					const uint32_t yb[2] = {__builtin_bit_cast(uint32_t, y0), __builtin_bit_cast(uint32_t, y1)};
+					uint32_t at[2] = {element_address(yb[0]), element_address(yb[1])};
+					if constexpr (CHECK) {
+						/* absolute tap k_abs = segment - 1 + the two floors; valid for 1 <= k_abs < S - 2; and -- the window is the block's own
+						 * construction -- never outside it: a segment beyond [1, W - 3] would be a bug in this kernel, so it reads zeros too */
+						const uint32_t seg[2]   = {yb[0] - m0, yb[1] - m1};
+						const uint32_t k_abs[2] = {(uint32_t)((int)seg[0] - 1 + rfl[2 * h] + tf), (uint32_t)((int)seg[1] - 1 + rfl[2 * h + 1] + tf)};
+						at[0] = ((k_abs[0] - 1u) < (uint32_t)(S - 3) && (seg[0] - 1u) <= W - 4u) ? at[0] : zero_at;
+						at[1] = ((k_abs[1] - 1u) < (uint32_t)(S - 3) && (seg[1] - 1u) <= W - 4u) ? at[1] : zero_at;
 					}
+					term.at[2 * h] = at[0]; term.at[2 * h + 1] = at[1];
+				}
+				return term;
+			};
+			/* one group of AT transmits out of buffer `buf`: the reads of a transmit's four polynomials are in flight while the next transmit's
+			 * addresses are computed */
+			auto consume = [&](auto checked, uint32_t g, uint32_t buf) {
+				const uint32_t a0 = (uint32_t)first_transmit + g * AT;
+				const uint32_t n  = (uint32_t)A - a0 < AT ? (uint32_t)A - a0 : AT;            /* block uniform; >= 1 */
+				uint32_t a_lane = a0 + (lane & (AT - 1u));
+				a_lane = a_lane < (uint32_t)A ? a_lane : (uint32_t)A - 1u;
+				const int tf_lanes  = *lds_i(tfl_at + 4u * a_lane);      /* lane l: floor of the block's smallest index of transmit a0 + l % AT */
+				const int tfh_lanes = __builtin_bit_cast(int, (float)tf_lanes - 0.5f);
+				Term cur = prepare(checked, g, buf, 0, tf_lanes, tfh_lanes);
+				for (uint32_t al = 0; al < n; al++) {
 					f32x4 lo[CH], hi[CH];
 					#pragma unroll
-					for (int k = 0; k < CH; k++) { lo[k] = *(lds_f32x4 *)(uintptr_t)at[k]; hi[k] = *(lds_f32x4 *)(uintptr_t)(at[k] + 16u); }
+					for (int k = 0; k < CH; k++) { lo[k] = *(lds_f32x4 *)(uintptr_t)cur.at[k]; hi[k] = *(lds_f32x4 *)(uintptr_t)(cur.at[k] + 16u); }
+					Term next = cur;
+					if (al + 1u < n) next = prepare(checked, g, buf, al + 1u, tf_lanes, tfh_lanes);       /* block uniform */
 					#pragma unroll
 					for (int k = 0; k < CH; k++) {
-						f32x2 sv = f32x2{hi[k].z, hi[k].w} * gm[k] + f32x2{hi[k].x, hi[k].y};
-						sv = sv * gm[k] + f32x2{lo[k].z, lo[k].w};
-						sv = sv * gm[k] + f32x2{lo[k].x, lo[k].y};
-						acc1[k] += sv.x * cs;
-						acc2[k] += sv.y * cs;
+						const float gk = cur.gm[k / 2][k & 1];
+						f32x2 sv = f32x2{hi[k].z, hi[k].w} * gk + f32x2{hi[k].x, hi[k].y};
+						sv = sv * gk + f32x2{lo[k].z, lo[k].w};
+						sv = sv * gk + f32x2{lo[k].x, lo[k].y};
+						acc1[k] += sv.x * cur.cs;
+						acc2[k] += sv.y * cur.cs;
 						if constexpr (CW) part_abs[k] += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
 					}
+					cur = next;
 				}
 			};
-			f32x2 in0 = load_one(0, k0, al0, rfl_0), in1 = load_one(0, k1, al1, rfl_1);
-			__syncthreads();                       /* the previous chunk's last group has been consumed by everyone */
-			store_one(0, e0, in0); store_one(0, e1, in1);
-			__syncthreads();
-			for (uint32_t g = 0; g < groups; g++) {
-				const uint32_t buf = g & 1u;
-				const bool more = g + 1 < groups;
-				if (more) { in0 = load_one(g + 1, k0, al0, rfl_0); in1 = load_one(g + 1, k1, al1, rfl_1); }      /* in flight during the arithmetic */
-				if (wave_safe) consume(std::false_type{}, g, buf);
-				else           consume(std::true_type{},  g, buf);
-				if (more) { store_one(buf ^ 1u, e0, in0); store_one(buf ^ 1u, e1, in1); }    /* the other buffer: its readers passed the barrier below a group ago */
+			/* (the range-checked and the unchecked loops as two copies of the whole group loop -- the same barriers in both: accumulators
+			 * that meet after every group cost sixteen moves each time) */
+			auto run_groups = [&](auto checked) {
+				f32x2 in0 = load_one(0, k0, al0, rfl_0), in1 = load_one(0, k1, al1, rfl_1);
+				__syncthreads();                       /* the previous chunk's last group has been consumed by everyone */
+				store_one(0, e0, in0); store_one(0, e1, in1);
 				__syncthreads();
-			}
+				for (uint32_t g = 0; g < groups; g++) {
+					const uint32_t buf = g & 1u;
+					const bool more = g + 1 < groups;
+					if (more) { in0 = load_one(g + 1, k0, al0, rfl_0); in1 = load_one(g + 1, k1, al1, rfl_1); }      /* in flight during the arithmetic */
+					consume(checked, g, buf);
+					if (more) { store_one(buf ^ 1u, e0, in0); store_one(buf ^ 1u, e1, in1); }    /* the other buffer: its readers passed the barrier below a group ago */
+					__syncthreads();
+				}
+			};
+			if (__builtin_amdgcn_readlane((int)wave_safe, 63)) run_groups(std::false_type{});
+			else                                               run_groups(std::true_type{});
 		} else {
 			/* ---------------- das_factored.hip's gather loop (near field, steep grids: the spread does not fit the window) */
 			for (int a = first_transmit; a < A; a++) {
@@ -451,21 +487,32 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			}
 		}
 
+		/* fold the chunk in: sum_a s e^{j phi(T)} times the channel's apod e^{j phi(R)} (das_factored.hip) */
 		#pragma unroll
 		for (int k = 0; k < CH; k++) {
-			part[k] = f32x2{acc1[k].x - acc2[k].y, acc1[k].y + acc2[k].x};
-			coherent.x += r_re[k] * part[k].x - r_im[k] * part[k].y;
-			coherent.y += r_im[k] * part[k].x + r_re[k] * part[k].y;
-			if constexpr (CW) incoherent += r_apod[k] * part_abs[k];
+			const bool  pass  = r_index[k] > -1.0e8f;
+			const float dx    = lateral - (float)(c0 + k) * pitch;
+			const float apod  = pass ? apodize(__builtin_fabsf(dx * f_over_z)) : 0.f;
+			const float turns = hw_fract(turns_per_sample * r_index[k]);
+			const float r_re  = apod * hw_cos_turns(turns), r_im = apod * hw_sin_turns(turns);
+			const f32x2 part  = f32x2{acc1[k].x - acc2[k].y, acc1[k].y + acc2[k].x};
+			coherent.x += r_re * part.x - r_im * part.y;
+			coherent.y += r_im * part.x + r_re * part.y;
+			if constexpr (CW) incoherent += apod * part_abs[k];
 		}
-		(void)any;
 	}
 
-	if (store) {
-		const uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
-		sample_t<true> v = coherent;
-		if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
-		reinterpret_cast<sample_t<true> *>(p.out)[out_index] = v;
+	/* (the voxel is worked out again rather than carried through the loops) */
+	{
+		const uint32_t sx = (bx << p.tile_shift[0]) + (tid & ((1u << p.tile_shift[0]) - 1u));
+		const uint32_t sy = (by << p.tile_shift[1]) + ((tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u));
+		const uint32_t sz = (bz << p.tile_shift[2]) + ((tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u));
+		if (sx < p.size[0] && sy < p.size[1] && sz < p.z_count) {
+			const uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * sz + (uint64_t)p.size[0] * sy + sx;
+			sample_t<true> v = coherent;
+			if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
+			reinterpret_cast<sample_t<true> *>(p.out)[out_index] = v;
+		}
 	}
 }
 

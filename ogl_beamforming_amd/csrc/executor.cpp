@@ -593,10 +593,13 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					/* geometry-only recount of the apodization test; its own segment so that it
 					 * stays out of the DAS time */
 					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 1));
-					a.pair_counter = (unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots);
-					ok &= HIP_OK(hipMemsetAsync(a.pair_counter, 0, sizeof(unsigned long long), s));
+					BfDasArgs count = dd.general;              /* the general kernel's own tiles: the specialised kernels reshape them */
+					count.rf = a.rf; count.out = a.out; count.transmits = a.transmits; count.sparse_elements = a.sparse_elements;
+					count.readi_hadamard = a.readi_hadamard;
+					count.pair_counter = (unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots);
+					ok &= HIP_OK(hipMemsetAsync(count.pair_counter, 0, sizeof(unsigned long long), s));
 					segment((uint32_t)st.kind);
-					ok &= HIP_OK(bf_launch_das_count(&a, s));
+					ok &= HIP_OK(bf_launch_das_count(&count, s));
 					segment(kStagePairCount);
 					t.counted = true;
 					das_segment_done = true;

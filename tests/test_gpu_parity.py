@@ -440,11 +440,16 @@ def test_factored_kernel_block_staging(name, bflib, oracle):
     lib = bflib.library()
     try:
         lib.beamformer_hip_set_das_path(0x14 | 0x100)
+        lib.beamformer_hip_enable_pair_counting(1)         # (the count runs with the general kernel's tiles, not the block's)
         tile = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
-        assert last_das_path(bflib) == 6
+        t = last_timings(bflib)
+        assert int(t.das_path) == 6
+        assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs), (int(t.das_pairs), pairs)
+        lib.beamformer_hip_enable_pair_counting(0)
         lib.beamformer_hip_set_das_path(0x14 | 0x200)
         np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters))
         assert last_das_path(bflib) != 6
     finally:
+        lib.beamformer_hip_enable_pair_counting(0)
         lib.beamformer_hip_set_das_path(0)
     compare(tile, ref, acq, flags)

@@ -43,7 +43,7 @@ GROUPS = [
 # the geometry-only pair-count instantiation das_kernel<FAMILY, 0, false, false, true> is not the DAS launch
 COUNT_KERNEL = re.compile(r"das_kernel<[^>]*,\s*true>")
 
-KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_staged_cubic.hip", "das_hercules.hip", "bf_kernels.h", "das_select.cpp"]
+KERNEL_SOURCES = ["das.hip", "das_common.h", "das_factored.hip", "das_tile.hip", "das_separable.hip", "das_staged.hip", "das_staged_real.hip", "das_staged_cubic.hip", "das_hercules.hip", "bf_kernels.h", "das_select.cpp"]
 
 
 def kernel_source_hash():
