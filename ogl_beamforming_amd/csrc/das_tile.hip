@@ -57,35 +57,35 @@ __device__ __forceinline__ float tile_transmit_distance(const BfTransmit &t, flo
 	return result;
 }
 
-template <int CTRL>
-__device__ __forceinline__ float tile_dpp(float v)       /* lanes with no source lane keep their own value */
-{
-	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-/* minimum (MAX: maximum) over each row of 16 lanes, valid in lane 15 of the row */
+/* minimum (MAX: maximum) over each row of 16 lanes, valid in lane 15 of the row: four fused DPP steps (lanes with no source lane
+ * are left alone).  Written out: from fminf() over a DPP move hipcc makes four instructions a step (copy, shift, canonicalise,
+ * min), and these reductions run per channel and wave.  The s_nop are the two wait states between a VALU write and a DPP read
+ * of the same register, which nobody inserts inside an asm block. */
+#define BF_DPP_STEP(op, ctrl) "s_nop 1\n\t" op " %0, %0, %0 " ctrl "\n\t"
 template <bool MAX>
 __device__ __forceinline__ float row16_extreme(float v)
 {
-	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
-	v = pick(v, tile_dpp<0x111>(v));
-	v = pick(v, tile_dpp<0x112>(v));
-	v = pick(v, tile_dpp<0x114>(v));
-	v = pick(v, tile_dpp<0x118>(v));
+	if constexpr (MAX)
+		asm(BF_DPP_STEP("v_max_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf") BF_DPP_STEP("v_max_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+		    BF_DPP_STEP("v_max_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf") BF_DPP_STEP("v_max_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf") : "+v"(v));
+	else
+		asm(BF_DPP_STEP("v_min_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf") BF_DPP_STEP("v_min_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+		    BF_DPP_STEP("v_min_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf") BF_DPP_STEP("v_min_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf") : "+v"(v));
 	return v;
 }
-/* minimum (MAX: maximum) over the wave, valid in lane 63: four shifts inside each row of 16, then the last lane of a row into the
- * rows behind it (gfx9's row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) */
+/* minimum (MAX: maximum) over the wave, valid in lane 63: the row steps, then the last lane of a row into the rows behind it
+ * (gfx9's row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) */
 template <bool MAX>
 __device__ __forceinline__ float wave64_extreme_lane63(float v)
 {
-	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
 	v = row16_extreme<MAX>(v);
-	const int b15 = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false);
-	v = pick(v, __builtin_bit_cast(float, b15));
-	const int b31 = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false);
-	v = pick(v, __builtin_bit_cast(float, b31));
+	if constexpr (MAX)
+		asm(BF_DPP_STEP("v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf") BF_DPP_STEP("v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf") : "+v"(v));
+	else
+		asm(BF_DPP_STEP("v_min_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf") BF_DPP_STEP("v_min_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf") : "+v"(v));
 	return v;
 }
+#undef BF_DPP_STEP
 template <bool MAX>
 __device__ __forceinline__ float wave64_extreme(float v)
 {
@@ -414,13 +414,13 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				a_lane = a_lane < (uint32_t)A ? a_lane : (uint32_t)A - 1u;
 				const int tf_lanes  = *lds_i(tfl_at + 4u * a_lane);      /* lane l: floor of the block's smallest index of transmit a0 + l % AT */
 				const int tfh_lanes = __builtin_bit_cast(int, (float)tf_lanes - 0.5f);
-				Term cur = prepare(checked, g, buf, 0, tf_lanes, tfh_lanes);
-				for (uint32_t al = 0; al < n; al++) {
+				/* one transmit: issue its reads, prepare the one after it (if any) into `next` while they fly, then the arithmetic */
+				auto step = [&](const Term &cur, Term &next, uint32_t al) -> bool {
 					f32x4 lo[CH], hi[CH];
 					#pragma unroll
 					for (int k = 0; k < CH; k++) { lo[k] = *(lds_f32x4 *)(uintptr_t)cur.at[k]; hi[k] = *(lds_f32x4 *)(uintptr_t)(cur.at[k] + 16u); }
-					Term next = cur;
-					if (al + 1u < n) next = prepare(checked, g, buf, al + 1u, tf_lanes, tfh_lanes);       /* block uniform */
+					const bool more = al + 1u < n;                               /* block uniform */
+					if (more) next = prepare(checked, g, buf, al + 1u, tf_lanes, tfh_lanes);
 					#pragma unroll
 					for (int k = 0; k < CH; k++) {
 						const float gk = cur.gm[k / 2][k & 1];
@@ -431,7 +431,13 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 						acc2[k] += sv.y * cur.cs;
 						if constexpr (CW) part_abs[k] += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
 					}
-					cur = next;
+					return more;
+				};
+				/* (two transmits per turn, their terms in two fixed sets of registers: handing `next` over to `cur` costs six moves a transmit) */
+				Term even = prepare(checked, g, buf, 0, tf_lanes, tfh_lanes), odd = even;
+				for (uint32_t al = 0; ; al += 2u) {
+					if (!step(even, odd, al)) break;
+					if (!step(odd, even, al + 1u)) break;
 				}
 			};
 			/* (the range-checked and the unchecked loops as two copies of the whole group loop -- the same barriers in both: accumulators
