@@ -300,9 +300,9 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 		if (!some) continue;                                           /* block uniform: nobody is inside any aperture of the chunk */
 
 		float part_abs[CH];
-		f32x2 acc1[CH], acc2[CH];
+		f32x2 acc[CH];                                                 /* sum over the transmits of s e^{j phi(T)} */
 		#pragma unroll
-		for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; part_abs[k] = 0.f; }
+		for (int k = 0; k < CH; k++) { acc[k] = f32x2{0.f, 0.f}; part_abs[k] = 0.f; }
 
 		if (fits) {
 			/* ---------------- staged path */
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			};
 			/* one transmit of a group: its phase factor, and per channel the LDS address of the term's polynomial and the offset from the
 			 * segment's middle */
-			struct Term { f32x2 cs; f32x2 gm[CH / 2]; uint32_t at[CH]; };
+			struct Term { float turns; f32x2 gm[CH / 2]; uint32_t at[CH]; };       /* (the phase as turns: cos and sin are made where they are used) */
 			auto prepare = [&](auto checked, uint32_t g, uint32_t buf, uint32_t al, int tf_lanes, int tfh_lanes) -> Term {
 				constexpr bool CHECK = decltype(checked)::value;
 				Term term;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				asm volatile("" : "+v"(t_index));
 				const int   tf = __builtin_amdgcn_readlane(tf_lanes, (int)al);
 				const float turns = hw_fract(turns_per_sample * t_index);
-				term.cs = f32x2{hw_cos_turns(turns), hw_sin_turns(turns)};
+				term.turns = turns;
 				/* + 1/2: y below rounds to the SEGMENT (the window starts one sample early); exact (multiples of an ulp of t_index, small) */
 				const float t_rel = t_index - __builtin_bit_cast(float, __builtin_amdgcn_readlane(tfh_lanes, (int)al));
 				#pragma unroll
@@ -421,14 +421,15 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 					for (int k = 0; k < CH; k++) { lo[k] = *(lds_f32x4 *)(uintptr_t)cur.at[k]; hi[k] = *(lds_f32x4 *)(uintptr_t)(cur.at[k] + 16u); }
 					const bool more = al + 1u < n;                               /* block uniform */
 					if (more) next = prepare(checked, g, buf, al + 1u, tf_lanes, tfh_lanes);
+					const f32x2 cs = {hw_cos_turns(cur.turns), hw_sin_turns(cur.turns)}, csr = {-cs.y, cs.x};
 					#pragma unroll
 					for (int k = 0; k < CH; k++) {
 						const float gk = cur.gm[k / 2][k & 1];
 						f32x2 sv = f32x2{hi[k].z, hi[k].w} * gk + f32x2{hi[k].x, hi[k].y};
 						sv = sv * gk + f32x2{lo[k].z, lo[k].w};
 						sv = sv * gk + f32x2{lo[k].x, lo[k].y};
-						acc1[k] += sv.x * cur.cs;
-						acc2[k] += sv.y * cur.cs;
+						acc[k] += sv.x * cs;                                     /* s e^{j phi}: the real part times (cos, sin) ... */
+						acc[k] += sv.y * csr;                                    /* ... the imaginary part times (-sin, cos) */
 						if constexpr (CW) part_abs[k] += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
 					}
 					return more;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				float t_index = transmit_index(a);
 				asm volatile("" : "+v"(t_index));
 				const float turns = hw_fract(turns_per_sample * t_index);
-				const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
+				const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)}, csr = {-cs.y, cs.x};
 				const uint32_t row0 = ((uint32_t)c0 * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES;
 				const uint32_t row_step = (uint32_t)A * (uint32_t)S * ES;
 				float frac[CH]; uint32_t off[CH];
@@ -486,8 +487,8 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 					f32x2 c2 = (D - T1) - c3;
 					float t  = frac[k];
 					f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
-					acc1[k] += sv.x * cs;
-					acc2[k] += sv.y * cs;
+					acc[k] += sv.x * cs;
+					acc[k] += sv.y * csr;
 					if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
 				}
 			}
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			const float apod  = pass ? apodize(__builtin_fabsf(dx * f_over_z)) : 0.f;
 			const float turns = hw_fract(turns_per_sample * r_index[k]);
 			const float r_re  = apod * hw_cos_turns(turns), r_im = apod * hw_sin_turns(turns);
-			const f32x2 part  = f32x2{acc1[k].x - acc2[k].y, acc1[k].y + acc2[k].x};
+			const f32x2 part  = acc[k];
 			coherent.x += r_re * part.x - r_im * part.y;
 			coherent.y += r_im * part.x + r_re * part.y;
 			if constexpr (CW) incoherent += apod * part_abs[k];
@@ -510,9 +511,11 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 
 	/* (the voxel is worked out again rather than carried through the loops) */
 	{
-		const uint32_t sx = (bx << p.tile_shift[0]) + (tid & ((1u << p.tile_shift[0]) - 1u));
-		const uint32_t sy = (by << p.tile_shift[1]) + ((tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u));
-		const uint32_t sz = (bz << p.tile_shift[2]) + ((tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u));
+		uint32_t t = threadIdx.x;
+		asm volatile("" : "+v"(t));                                      /* (or hipcc keeps the first computation's registers alive instead) */
+		const uint32_t sx = (bx << p.tile_shift[0]) + (t & ((1u << p.tile_shift[0]) - 1u));
+		const uint32_t sy = (by << p.tile_shift[1]) + ((t >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u));
+		const uint32_t sz = (bz << p.tile_shift[2]) + ((t >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u));
 		if (sx < p.size[0] && sy < p.size[1] && sz < p.z_count) {
 			const uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * sz + (uint64_t)p.size[0] * sy + sx;
 			sample_t<true> v = coherent;
