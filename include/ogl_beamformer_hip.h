@@ -103,6 +103,9 @@ typedef struct {
 	                              4 (retired), 5 HERCULES aligned-grid kernel, 6 factored kernel with block-wide LDS staging (das_tile.hip) */
 	uint32_t staged_window_violations;   /* LDS-staged kernels with the STAGED_CHECKED hook: (wave, channel) pairs in which a term's position
 	                                        fell outside the staged window -- the host's window bound was wrong.  Must be 0. */
+	uint32_t tile_staged_chunks;         /* das path 6 (das_tile.hip): (block, chunk of four channels) pairs whose terms were read from the windows the
+	                                        block staged in LDS ... */
+	uint32_t tile_gather_chunks;         /* ... and those whose spread did not fit the window: the block ran das_factored.hip's gather loop for them */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);

@@ -44,6 +44,7 @@ typedef struct {
 	const int16_t    *sparse_elements;
 	const uint16_t   *readi_hadamard; /* binary16 bits, G*G */
 	unsigned long long *pair_counter; /* COUNT kernels only */
+	uint32_t *tile_counters;          /* das_tile.hip: [0] += (block, channel chunk) pairs that ran out of staged windows, [1] += those that took the gather loop; or null */
 	int32_t  family, interpolation, complex_data, coherency_weighting;
 	int32_t  acquisition_count, channel_count, sample_count, sparse;
 	float    sampling_frequency, inv_sampling_frequency, demodulation_frequency;

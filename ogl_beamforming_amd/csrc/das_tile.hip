@@ -298,6 +298,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			fits = fits && (!on || (__builtin_floorf(rhi[k]) - __builtin_floorf(rlo[k])) + tspread_f <= (float)(W - 6u));
 		}
 		if (!some) continue;                                           /* block uniform: nobody is inside any aperture of the chunk */
+		if (tid == 0 && p.tile_counters) atomicAdd(p.tile_counters + (fits ? 0 : 1), 1u);
 
 		float part_abs[CH];
 		f32x2 acc[CH];                                                 /* sum over the transmits of s e^{j phi(T)} */

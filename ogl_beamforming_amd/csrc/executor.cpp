@@ -548,10 +548,10 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					}
 					if (staged) {
 						/* window positions outside the staged window are counted (range-checked loop only: STAGED_CHECKED) */
-						ok &= d.staged_violations.ensure(sizeof(uint32_t) * kTimingSlots);
+						ok &= d.staged_violations.ensure(sizeof(uint32_t) * 4 * kTimingSlots);
 						if (ok) {
-							sep.violations = (uint32_t *)d.staged_violations.ptr + (f->id % kTimingSlots);
-							ok &= HIP_OK(hipMemsetAsync(sep.violations, 0, sizeof(uint32_t), s));
+							sep.violations = (uint32_t *)d.staged_violations.ptr + 4 * (f->id % kTimingSlots);
+							ok &= HIP_OK(hipMemsetAsync(sep.violations, 0, 4 * sizeof(uint32_t), s));
 							violations_slot = f->id % kTimingSlots;
 						}
 						ok &= HIP_OK(!plan.iq_pipeline ? bf_launch_das_staged_real(&a, &sep, s) :
@@ -583,6 +583,14 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					ok &= HIP_OK(bf_launch_das_factored(&a, s));
 					break;
 				case DasPath_Tile:
+					/* (block, channel chunk) pairs served from staged windows, and those the kernel sent through its gather loop: words 1, 2 */
+					ok &= d.staged_violations.ensure(sizeof(uint32_t) * 4 * kTimingSlots);
+					if (ok) {
+						uint32_t *slot = (uint32_t *)d.staged_violations.ptr + 4 * (f->id % kTimingSlots);
+						ok &= HIP_OK(hipMemsetAsync(slot, 0, 4 * sizeof(uint32_t), s));
+						a.tile_counters = slot + 1;
+						violations_slot = f->id % kTimingSlots;
+					}
 					ok &= HIP_OK(bf_launch_das_tile(&a, s));
 					break;
 				default:
@@ -983,9 +991,10 @@ static bool timings_of(Device &d, BeamformerHipFrameTimings *out)
 	out->das_voxels = t.das_voxels; out->das_taps = t.das_taps;
 	out->das_sample_bytes = t.das_sample_bytes; out->das_path = t.das_path;
 	if (t.violations_slot != ~0ull && d.staged_violations.ptr) {
-		uint32_t n = 0;
-		(void)hipMemcpy(&n, (uint32_t *)d.staged_violations.ptr + t.violations_slot, sizeof(n), hipMemcpyDeviceToHost);
-		out->staged_window_violations = n;
+		uint32_t n[4] = {0, 0, 0, 0};
+		(void)hipMemcpy(n, (uint32_t *)d.staged_violations.ptr + 4 * t.violations_slot, sizeof(n), hipMemcpyDeviceToHost);
+		out->staged_window_violations = n[0];
+		out->tile_staged_chunks = n[1]; out->tile_gather_chunks = n[2];
 	}
 	if (t.counted && d.pair_counter.ptr) {
 		unsigned long long n = 0;
@@ -1053,6 +1062,7 @@ bool last_frame_timings(BeamformerHipFrameTimings *out)
 		if (!timings_of(c.devices[i], &peer)) { (void)hipSetDevice(c.devices[0].device); return false; }
 		out->das_voxels += peer.das_voxels; out->das_pairs += peer.das_pairs;
 		out->staged_window_violations += peer.staged_window_violations;
+		out->tile_staged_chunks += peer.tile_staged_chunks; out->tile_gather_chunks += peer.tile_gather_chunks;
 		if (peer.frame_ms > out->frame_ms) out->frame_ms = peer.frame_ms;
 	}
 	(void)hipSetDevice(c.devices[0].device);

@@ -212,6 +212,7 @@ class HipFrameTimings(C.Structure):
         ("stage_ms", C.c_float * HIP_MAX_TIMED_STAGES), ("frame_ms", C.c_float),
         ("das_pairs", C.c_uint64), ("das_voxels", C.c_uint64), ("das_taps", C.c_uint32),
         ("das_sample_bytes", C.c_uint32), ("das_path", C.c_uint32), ("staged_window_violations", C.c_uint32),
+        ("tile_staged_chunks", C.c_uint32), ("tile_gather_chunks", C.c_uint32),
     ]
 
 

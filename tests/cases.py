@@ -144,6 +144,33 @@ def _cases():
         stages=(S.Decode, S.Filter, S.DAS), filters=[cfg.kaiser_filter(25e6, 5e6, length=24, beta=5.0)])
     # FORCES family
     c["forces"] = lambda: cfg.forces("forces", 16, 16, 512, (20, 1, 20), LO3, HI3, seed=31)
+    # das_tile.hip (block-wide LDS staging of cubic polynomial windows; automatic on fine grids with tx and rx on one axis -- BASELINE
+    # config 2's class): a 25 um x 69 um view-plane grid, ragged in both directions (160 = 2.5 tiles of 64, 48 = 3 of 16) ...
+    c["tile_tpw"] = lambda: cfg.rca("tile_tpw", 24, 9, 768, (160, 48, 1), (-2.0e-3, 0, 6.0e-3), (2.0e-3, 0, 9.3e-3), seed=71,
+                                    interp=I.Cubic, orientation=0x22, f_number=1.0, pitch=0.2e-3, angles=np.linspace(-10, 10, 9))
+    # ... coherency weighting over rows that end inside the image (index 396 at the deepest voxels, 384 samples: the range-checked
+    # loop, zeros past the end), 7 transmits (a ragged group of 8), 18 channels (a ragged chunk of 4) ...
+    c["tile_tpw_cw_short"] = lambda: cfg.rca("tile_tpw_cw_short", 18, 7, 384, (96, 40, 1), (-1.2e-3, 0, 9.5e-3), (1.2e-3, 0, 12.2e-3),
+                                             seed=72, interp=I.Cubic, orientation=0x22, cw=True, f_number=0.8, pitch=0.2e-3,
+                                             angles=np.linspace(-8, 8, 7))
+    # ... a grid fine enough for the 32-sample window (16 transmits per staged group) ...
+    c["tile_w32"] = lambda: cfg.rca("tile_w32", 16, 20, 768, (128, 32, 1), (-0.5e-3, 0, 8.0e-3), (0.5e-3, 0, 8.3e-3), seed=77,
+                                    interp=I.Cubic, orientation=0x22, f_number=1.2, pitch=0.2e-3, angles=np.linspace(-9, 9, 20))
+    # ... diverging and focused transmits (the square root per transmit), steered along the receive axis ...
+    c["tile_vls"] = lambda: cfg.rca("tile_vls", 16, 6, 768, (128, 32, 1), (-1.6e-3, 0, 7.0e-3), (1.6e-3, 0, 9.2e-3), seed=73,
+                                    interp=I.Cubic, orientation=0x22, kind=K.RCA_VLS, f_number=0.9, pitch=0.2e-3,
+                                    angles=np.linspace(-6, 6, 6), depths=np.array([-12e-3, 30e-3, -20e-3, 45e-3, 25e-3, -15e-3]))
+    # ... the near field under a wide aperture: the receive spread of most chunks does not fit a window there and the block runs its
+    # gather loop for them (both kinds of chunk in one frame) ...
+    c["tile_near_field"] = lambda: cfg.rca("tile_near_field", 96, 5, 512, (128, 32, 1), (-10.0e-3, 0, 3.0e-3), (10.0e-3, 0, 8.0e-3), seed=74,
+                                           interp=I.Cubic, orientation=0x22, f_number=0.3, pitch=0.2e-3, angles=np.linspace(-10, 10, 5))
+    # ... and FORCES / UFORCES (transmit element = a channel; sparse: the first acquisition is skipped, das.glsl:297-299) on IQ samples
+    c["tile_forces"] = lambda: cfg.forces("tile_forces", 16, 16, 512, (96, 1, 40), (-1.5e-3, 0, 8.0e-3), (1.5e-3, 0, 10.0e-3), seed=75,
+                                          interp=I.Cubic, f_number=0.9, pitch=0.2e-3,
+                                          stages=(P.ShaderKind.Demodulate, P.ShaderKind.Decode, P.ShaderKind.DAS))
+    c["tile_uforces_cw"] = lambda: cfg.forces("tile_uforces_cw", 16, 8, 512, (64, 1, 48), (-1.2e-3, 0, 8.0e-3), (1.2e-3, 0, 10.4e-3), seed=76,
+                                              kind=K.UFORCES, sparse=[1, 4, 6, 8, 11, 13, 15], decode=0, interp=I.Cubic, cw=True,
+                                              f_number=0.9, pitch=0.2e-3, stages=(P.ShaderKind.Demodulate, P.ShaderKind.DAS))
     c["uforces_sparse"] = lambda: cfg.forces("uforces_sparse", 16, 8, 512, (16, 1, 16), LO3, HI3, seed=32,
                                              kind=K.UFORCES, sparse=[1, 4, 6, 8, 11, 13, 15], decode=0, interp=I.Cubic,
                                              cw=True)

@@ -48,6 +48,39 @@ def test_forced_paths_and_reasons():
         L.beamformer_hip_set_das_path(0)
 
 
+def test_block_staged_kernel_selection():
+    """das_tile.hip (path 6): automatic for BASELINE config 2 at full size (fine grid, cubic IQ, tx and rx on one axis: 64 x 16 tiles,
+    64-sample windows, the banded plane walk), declined with its reason on small frames (channel split), under flag 0x200, for other
+    sample kinds; flag 0x100 asks for it wherever the kernel is able to run, with the 32-sample window on very fine grids."""
+    L = lib.library()
+    try:
+        L.beamformer_hip_set_das_path(0)
+        full = cfg.config(2)
+        path, kernel, _, reasons, d = lib.describe_das(full.bp, full.filters)
+        assert (path, kernel) == (6, "das_tile_kernel") and "block-staged" in reasons[3]
+        assert list(d.tile_shift) == [6, 4, 0] and list(d.blocks) == [16, 64, 1] and d.tile_window_samples == 64 and d.tile_walk == 3
+        L.beamformer_hip_set_das_path(0x200)
+        path, _, _, reasons, d = lib.describe_das(full.bp, full.filters)
+        assert path == 3 and "0x200" in reasons[6] and d.tile_window_samples == 0
+        L.beamformer_hip_set_das_path(0)
+        small = cases.make("config2_small")
+        path, _, _, reasons, _ = lib.describe_das(small.bp, small.filters)
+        assert path == 3 and "channel split" in reasons[6]
+        real = cases.make("forces")
+        assert "cubic interpolation of IQ samples only" in lib.describe_das(real.bp, real.filters)[3][6]
+        coarse = cases.make("harness_tpw_small")
+        L.beamformer_hip_set_das_path(0x10)
+        path, _, _, reasons, _ = lib.describe_das(coarse.bp, coarse.filters)
+        assert path == 3 and "coarse grid" in reasons[6]
+        L.beamformer_hip_set_das_path(0x14 | 0x100)
+        assert lib.describe_das(coarse.bp, coarse.filters)[0] == 6
+        fine = cases.make("tile_w32")
+        path, _, _, _, d = lib.describe_das(fine.bp, fine.filters)
+        assert path == 6 and d.tile_window_samples == 32
+    finally:
+        L.beamformer_hip_set_das_path(0)
+
+
 def _matrix(m16):
     return np.array(m16[:], np.float64).reshape(4, 4).T          # column major
 

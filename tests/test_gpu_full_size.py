@@ -125,11 +125,12 @@ def test_full_size_linearity(bflib, config4):
     assert np.abs(bz - want).max() / np.abs(want).max() < 2e-4
 
 
-@pytest.mark.parametrize("n, path_name", [(2, "factored"), (3, "hercules"), (5, "hercules")])
+@pytest.mark.parametrize("n, path_name", [(2, "tile"), (3, "hercules"), (5, "hercules")])
 def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     """Configs 2, 3 and 5 at BASELINE sizes (config 5 on a 16-plane slab: 4.3 s per whole frame):
     the scatterer (where the acquisition has one) peaks where it was placed, the automatic DAS path is the expected one
-    (factored kernel for config 2, HERCULES aligned-grid kernel for configs 3 and 5), it agrees with the general kernel on the
+    (factored kernel with block-wide LDS staging for config 2 -- every chunk of every block served from the staged windows --,
+    HERCULES aligned-grid kernel for configs 3 and 5), it agrees with the general kernel on the
     same frame, and the oracle agrees on a few full-size rows around the scatterer."""
     acq = cfg.config(n)
     X, Y, Z = (max(1, v) for v in acq.bp.output_points[:3])
@@ -146,7 +147,11 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     frame = run(bflib, acq, shard=shard)
     t = P.HipFrameTimings()
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
-    assert int(t.das_path) == {"general": 0, "factored": 3, "hercules": 5}[path_name]
+    assert int(t.das_path) == {"general": 0, "factored": 3, "hercules": 5, "tile": 6}[path_name]
+    if path_name == "tile":
+        # 1024 blocks x 32 chunks of four channels: (almost) all of them read from the staged windows
+        assert int(t.tile_staged_chunks) + int(t.tile_gather_chunks) <= 1024 * 32
+        assert int(t.tile_gather_chunks) <= 0.02 * int(t.tile_staged_chunks), (int(t.tile_staged_chunks), int(t.tile_gather_chunks))
     z0 = shard[0] if shard else 0
     if want is not None:
         mag = np.abs(np.nan_to_num(frame))
@@ -290,7 +295,7 @@ def test_config4_f32_complex_rows_at_the_edges_of_the_volume(das_mode, kernel, b
 
 
 def test_config2_f32_complex_first_and_last_rows(bflib, oracle):
-    """Config 2's geometry (128 ch x 31 tx -> 1024^2, cubic, factored kernel) on Float32Complex RF: the
+    """Config 2's geometry (128 ch x 31 tx -> 1024^2, cubic, block-staged factored kernel) on Float32Complex RF: the
     first and the last three image rows (depth extremes) and the scatterer's rows against the float oracle."""
     path = 4096 / 25e6 * cfg.SPEED_OF_SOUND
     z0, z1 = 0.12 * path, 0.40 * path
@@ -300,7 +305,7 @@ def test_config2_f32_complex_first_and_last_rows(bflib, oracle):
                     angles=np.linspace(-15.0, 15.0, 31), scatterer=scatterer)
     frame = run(bflib, acq)
     t = P.HipFrameTimings()
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 3
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 6
     mag = np.abs(frame)
     _, py, px = np.unravel_index(np.argmax(mag), mag.shape)
     assert abs(px - (scatterer[0] + 12.8e-3) / 25.6e-3 * 1023) <= 2 and abs(py - 0.4 * 1023) <= 2, (px, py)

@@ -425,26 +425,43 @@ def tile_candidates():
 
 TILE = tile_candidates()
 
+# what the block does with its (block, chunk of four channels) pairs -- staged windows, or the kernel's own gather loop where the
+# spread of the chunk does not fit the window (BeamformerHipFrameTimings::tile_staged_chunks / tile_gather_chunks)
+TILE_STAGED_ONLY = {"tile_tpw", "tile_tpw_cw_short", "tile_vls", "tile_w32", "tile_forces", "tile_uforces_cw"}
+TILE_BOTH        = {"tile_near_field"}
+TILE_WINDOW      = {"tile_w32": 32, "tile_tpw": 64}
+
 
 def test_block_staging_candidates():
-    assert len(TILE) >= 4, TILE
+    assert TILE_STAGED_ONLY | TILE_BOTH <= set(TILE), TILE
+    assert len(TILE) >= 12, TILE
 
 
 @pytest.mark.parametrize("name", TILE)
 def test_factored_kernel_block_staging(name, bflib, oracle):
     """das_tile.hip (flag 0x100: a 1024-thread block stages the RF windows of its 64 x 16 voxels as cubic polynomials in LDS;
-    automatic on fine grids with tx and rx on one axis -- BASELINE config 2) against the oracle, and against das_factored.hip's
-    gather loop (flag 0x200) within the parity tolerance: the polynomial re-expansion rounds differently, so not bit for bit."""
+    automatic on fine grids with tx and rx on one axis -- BASELINE config 2) against the oracle, and that das_factored.hip's
+    gather loop runs instead under flag 0x200 (the polynomial re-expansion rounds differently: parity tolerance, not bit for bit).
+    Fine-grid cases must really be served from the staged windows, the near-field case by both kinds of chunk; the coarse harness
+    frames exercise the kernel's own fallback."""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()
     try:
         lib.beamformer_hip_set_das_path(0x14 | 0x100)
+        if name in TILE_WINDOW:
+            assert int(bflib.describe_das(acq.bp, acq.filters)[4].tile_window_samples) == TILE_WINDOW[name]
         lib.beamformer_hip_enable_pair_counting(1)         # (the count runs with the general kernel's tiles, not the block's)
         tile = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
         t = last_timings(bflib)
         assert int(t.das_path) == 6
         assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs), (int(t.das_pairs), pairs)
+        staged, gathered = int(t.tile_staged_chunks), int(t.tile_gather_chunks)
+        assert staged + gathered > 0
+        if name in TILE_STAGED_ONLY:
+            assert staged > 0 and gathered == 0, (staged, gathered)
+        if name in TILE_BOTH:
+            assert staged > 0 and gathered > 0, (staged, gathered)
         lib.beamformer_hip_enable_pair_counting(0)
         lib.beamformer_hip_set_das_path(0x14 | 0x200)
         np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters))
