@@ -146,6 +146,42 @@ static float lane_step_samples(const float *voxel_to_xdc, const BfDasArgs &a)
 	return std::sqrt(dx * dx + dy * dy + dz * dz) * a.sampling_frequency * a.inv_speed_of_sound;
 }
 
+/* das_tile.hip: an upper bound of (largest - smallest receive index) + (largest - smallest transmit index) over a tile of
+ * 2^shift voxels, in samples -- what a staged window has to hold.  Per voxel axis, from the derivatives of the two distances:
+ * the receive distance sqrt(lateral^2 + z^2) moves by at most sin(theta) per unit of lateral step, and the f-number test
+ * (|lateral| f / z < 1/2, das.glsl:205-207) keeps sin(theta) under 1 / sqrt(1 + 4 f^2), and by at most 1 per unit of depth; a plane
+ * wave's by |sin a| laterally and by at most 1 in depth; a focused or diverging wave's, and a FORCES transmit element's, by at
+ * most the length of the step.  (The kernel measures the real spread per block and chunk: the estimate only decides whether the
+ * block-staged kernel is worth launching.) */
+static float tile_spread_estimate(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *voxel_to_xdc, const float *voxel_to_world,
+                                  const uint32_t shift[3])
+{
+	const float sin_rx = 1.0f / std::sqrt(1.0f + 4.0f * a.f_number * a.f_number);
+	const float samples_per_metre = a.sampling_frequency * a.inv_speed_of_sound;
+	float spread = 2.0f;                                                   /* the two floors */
+	for (int k = 0; k < 3; k++) {
+		const float n = (float)(a.size[k] > 1 ? a.size[k] - 1 : 1);
+		const float xs[3] = {voxel_to_xdc[4 * k + 0] / n, voxel_to_xdc[4 * k + 1] / n, voxel_to_xdc[4 * k + 2] / n};
+		const float ws[3] = {voxel_to_world[4 * k + 0] / n, voxel_to_world[4 * k + 1] / n, voxel_to_world[4 * k + 2] / n};
+		float receive, transmit = 0.f;
+		if (a.family == BF_DAS_RCA) {
+			const bool rx_rows = !tx.empty() && (tx[0].flags & BF_RX_ROWS);
+			receive = sin_rx * std::fabs(rx_rows ? xs[1] : xs[0]) + std::fabs(xs[2]);
+			for (const BfTransmit &t : tx) {
+				if (t.flags & BF_TX_NONE) continue;
+				const float px = (t.flags & BF_TX_ROWS) ? ws[1] : ws[0];
+				const float step = (t.flags & BF_TX_PLANE) ? std::fabs(px * t.sin_a) + std::fabs(ws[2] * t.cos_a) : std::sqrt(px * px + ws[2] * ws[2]);
+				transmit = step > transmit ? step : transmit;
+			}
+		} else {
+			receive  = sin_rx * std::fabs(xs[0]) + std::fabs(xs[2]);
+			transmit = std::sqrt(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+		}
+		spread += (receive + transmit) * samples_per_metre * (float)((1u << shift[k]) - 1u);
+	}
+	return spread;
+}
+
 /* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
  * receive and one transmit orientation for all transmits, on different transducer axes, a
  * volume whose z axis alone carries depth, and voxel x / y axes that each move only one of
@@ -624,8 +660,8 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 		 * the real spread per block and chunk and falls back to the gather loop itself, so the estimate only decides whether it is worth
 		 * trying); flag 0x100 forces it wherever it is supported, 0x200 forbids it. */
 		{
-			const bool tile_ok = plan.iq_pipeline && a.interpolation == 2 && !a.split_shift && Sd >= 8 && out.das_input_bytes < (1ull << 31) &&
-			                     (uint64_t)ext[0] * ext[1] * ext[2] >= 1024u && A - (a.family == BF_DAS_FORCES && a.sparse ? 1u : 0u) >= 4u;
+			bool tile_ok = plan.iq_pipeline && a.interpolation == 2 && Sd >= 8 && out.das_input_bytes < (1ull << 31) &&
+			               (uint64_t)ext[0] * ext[1] * ext[2] >= 1024u && A - (a.family == BF_DAS_FORCES && a.sparse ? 1u : 0u) >= 4u;
 			/* tile: 64 voxels along x (a wave), the other 16 along the next axis that has voxels */
 			uint32_t shift[3] = {0, 0, 0}, left = 10;
 			for (int k = 0; k < 3 && left; k++) {
@@ -635,15 +671,16 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 				shift[k] = give; left -= give;
 			}
 			for (int k = 0; k < 3 && left; k++) { uint32_t room = ceil_log2(ext[k]) - shift[k]; uint32_t give = room < left ? room : left; shift[k] += give; left -= give; }
-			float spread = 0.f;
-			for (int k = 0; k < 3; k++) {
-				const float n = (float)(a.size[k] > 1 ? a.size[k] - 1 : 1);
-				const float dx = to_xdc[4 * k + 0] / n, dy = to_xdc[4 * k + 1] / n, dz = to_xdc[4 * k + 2] / n;
-				/* a voxel step along this axis moves the receive distance by at most its length, the transmit distance likewise */
-				spread += 2.0f * std::sqrt(dx * dx + dy * dy + dz * dz) * a.sampling_frequency * a.inv_speed_of_sound * (float)((1u << shift[k]) - 1u);
-			}
+			const float spread = tile_spread_estimate(a, tx, to_xdc, plan.das_voxel_transform, shift);
+			/* frames small enough for the channel split (under 4096 voxel waves): one block per CU, so the block-staged kernel is
+			 * only worth it from about three quarters of the CUs (config 2 onto 448 x 448: 196 blocks, 0.66 ms against the split
+			 * kernel's 0.82; onto 384 x 384 the split kernel wins: profiles/r03_tile_threshold.json) */
+			uint64_t tile_blocks = 1;
+			for (int k = 0; k < 3; k++) tile_blocks *= (ext[k] + (1u << shift[k]) - 1) >> shift[k];
+			tile_ok = tile_ok && (!a.split_shift || tile_blocks >= 192u);
 			const bool forced = (mode & 0x100) != 0;
 			if (tile_ok && left == 0 && !(mode & 0x200) && (forced || (spread == spread && spread <= 58.f && lane_step_samples(to_xdc, a) < 1.0f))) {
+				a.split_shift = 0;
 				for (int k = 0; k < 3; k++) a.tile_shift[k] = shift[k];
 				for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 				a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
@@ -655,7 +692,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 				return;
 			}
 			why[DasPath_Tile] = !plan.iq_pipeline || a.interpolation != 2 ? "cubic interpolation of IQ samples only"
-			                  : !tile_ok ? "small frame (channel split), fewer than 4 transmits, or a DAS input of 2 GiB or more"
+			                  : !tile_ok ? "small frame (channel split: fewer than 192 blocks), fewer than 4 transmits, or a DAS input of 2 GiB or more"
 			                  : (mode & 0x200) ? "das path flag 0x200: no block staging"
 			                  : "coarse grid or steep delays: a 64 x 16-voxel tile's estimated spread exceeds a 64-sample window";
 		}

@@ -62,6 +62,12 @@ def test_block_staged_kernel_selection():
         L.beamformer_hip_set_das_path(0x200)
         path, _, _, reasons, d = lib.describe_das(full.bp, full.filters)
         assert path == 3 and "0x200" in reasons[6] and d.tile_window_samples == 0
+        # frames under the channel-split size: from 192 blocks the block-staged kernel runs instead of the split one (480^2: 8 x 30)
+        L.beamformer_hip_set_das_path(0)
+        for points, want in ((480, 6), (384, 3)):
+            full.bp.output_points[0] = full.bp.output_points[1] = points
+            path, _, _, _, d = lib.describe_das(full.bp, full.filters)
+            assert path == want and (d.split_shift == 0) == (want == 6), (points, path, d.split_shift)
         L.beamformer_hip_set_das_path(0)
         small = cases.make("config2_small")
         path, _, _, reasons, _ = lib.describe_das(small.bp, small.filters)
