@@ -31,13 +31,13 @@
 
 namespace {
 
+constexpr int      kTileCH      = 4;            /* channels per register chunk */
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int   lds_i32;
 
-constexpr int      kTileCH      = 4;            /* channels per register chunk */
 constexpr uint32_t kTileThreads = 1024;
 constexpr uint32_t kTileElems   = 2048;         /* window elements per LDS buffer: CH x AT x W; two per thread */
 
@@ -108,6 +108,8 @@ __device__ __forceinline__ uint32_t element_address(uint32_t y_bits)
 template <int FAMILY, bool CW, int WS>
 __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 {
+	/* Four channels per chunk.  (Eight would halve the per-transmit arithmetic a term carries -- about 3 of its 18 VALU instructions --
+	 * but need some 140 registers in the transmit loop: tried, 60 spilled.) */
 	constexpr int      CH = kTileCH;
 	constexpr uint32_t W  = 1u << WS;
 	constexpr uint32_t AT = kTileElems / (CH * W);            /* transmits per staged group: 16 (W = 32) or 8 (W = 64) */
@@ -271,15 +273,17 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			                                           : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
 			r_index[k] = pass ? index : -1.0e9f;
 		}
-		/* block-wide extremes of the receive index over the voxels inside each channel's aperture */
-		float wlo[CH], whi[CH];
+		/* block-wide extremes of the receive index over the voxels inside each channel's aperture; and whether this wave's lanes inside the
+		 * apertures stay inside the RF row for every transmit (one sample of margin for the sum's rounding): lane 63's verdict counts */
+		bool wave_safe = true;
 		__syncthreads();                                               /* (the exchange area's previous readers are done) */
 		#pragma unroll
 		for (int k = 0; k < CH; k++) {
-			const bool pass = r_index[k] > -1.0e8f;
-			wlo[k] = wave64_extreme_lane63<false>(pass ? r_index[k] :  __builtin_inff());       /* (valid in lane 63) */
-			whi[k] = wave64_extreme_lane63<true >(pass ? r_index[k] : -__builtin_inff());
-			if (lane == 63) { *lds_f(exch_at + 4u * ((uint32_t)k * 16u + wave)) = wlo[k]; *lds_f(exch_at + 4u * ((uint32_t)(CH + k) * 16u + wave)) = whi[k]; }
+			const bool  pass = r_index[k] > -1.0e8f;
+			const float wlo = wave64_extreme_lane63<false>(pass ? r_index[k] :  __builtin_inff());       /* (valid in lane 63) */
+			const float whi = wave64_extreme_lane63<true >(pass ? r_index[k] : -__builtin_inff());
+			if (lane == 63) { *lds_f(exch_at + 4u * ((uint32_t)k * 16u + wave)) = wlo; *lds_f(exch_at + 4u * ((uint32_t)(CH + k) * 16u + wave)) = whi; }
+			wave_safe = wave_safe && (wlo > whi || (wlo + t_lo >= 2.0f && whi + t_hi < (float)(S - 3)));
 		}
 		__syncthreads();
 		float rlo[CH], rhi[CH];
@@ -309,7 +313,6 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			/* ---------------- staged path */
 			int   rfl[CH];
 			f32x2 r_rel[CH / 2];
-			bool  wave_safe = true;
 			#pragma unroll
 			for (int k = 0; k < CH; k++) {
 				const bool on = rlo[k] <= rhi[k];
@@ -320,8 +323,6 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				 * window; a channel nobody uses reads from the window's start */
 				const float idx = pass ? r_index[k] : (on ? rlo[k] : 0.f);
 				r_rel[k / 2][k & 1] = idx - flo;                          /* exact */
-				/* this wave's lanes inside the aperture never leave the RF row for any transmit (one sample of margin for the sum's rounding) */
-				wave_safe = wave_safe && (wlo[k] > whi[k] || (wlo[k] + t_lo >= 2.0f && whi[k] + t_hi < (float)(S - 3)));      /* (lane 63's verdict counts) */
 			}
 			const uint32_t chunk_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)c0 * (uint32_t)A));
 			const uint32_t groups = ((uint32_t)(A - first_transmit) + AT - 1u) / AT;
@@ -331,12 +332,16 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 			 * the dynamic segment, whose address 0 this kernel relies on.) */
 			const uint32_t my_j = tid & (W - 1u);
 			const uint32_t e0 = tid, e1 = tid + kTileThreads;
-			const uint32_t k0 = wave / (AT * W / 64u), k1 = k0 + kTileThreads / (AT * W);
+			const uint32_t k0 = wave / (AT * W / 64u), k1 = k0 + kTileThreads / (AT * W);        /* k0 < CH / 2 <= k1 */
 			const uint32_t al0 = (e0 / W) % AT, al1 = (e1 / W) % AT;
-			int rf0 = rfl[0], rf1 = rfl[1], rf2 = rfl[2], rf3 = rfl[3];
-			asm volatile("" : "+v"(rf0), "+v"(rf1), "+v"(rf2), "+v"(rf3));
-			const int rfl_0 = k0 == 0 ? rf0 : rf1;                         /* k0 in {0, 1}, k1 in {2, 3} */
-			const int rfl_1 = k1 == 2 ? rf2 : rf3;
+			int rfl_0 = 0, rfl_1 = 0;
+			#pragma unroll
+			for (int k = 0; k < CH / 2; k++) {
+				int lower = rfl[k], upper = rfl[CH / 2 + k];
+				asm volatile("" : "+v"(lower), "+v"(upper));
+				rfl_0 = k0 == (uint32_t)k ? lower : rfl_0;
+				rfl_1 = k1 == (uint32_t)(CH / 2 + k) ? upper : rfl_1;
+			}
 			auto load_one = [&](uint32_t g, uint32_t kk, uint32_t al, int rk) -> f32x2 {
 				const uint32_t a = (uint32_t)first_transmit + g * AT + al;
 				uint32_t off = 0x80000000u;                                /* transmits past the last (a ragged final group) stage zeros */
@@ -368,28 +373,33 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				*(lds_f32x4 *)(uintptr_t)at         = f32x4{b0.x, b0.y, b1.x, b1.y};
 				*(lds_f32x4 *)(uintptr_t)(at + 16u) = f32x4{b2.x, b2.y, a3.x, a3.y};
 			};
-			/* one transmit of a group: its phase factor, and per channel the LDS address of the term's polynomial and the offset from the
-			 * segment's middle */
-			struct Term { float turns; f32x2 gm[CH / 2]; uint32_t at[CH]; };       /* (the phase as turns: cos and sin are made where they are used) */
-			auto prepare = [&](auto checked, uint32_t g, uint32_t buf, uint32_t al, int tf_lanes, int tfh_lanes) -> Term {
-				constexpr bool CHECK = decltype(checked)::value;
-				Term term;
+			/* a transmit of a group: its index relative to the window start, its phase factor; and for four of the chunk's channels the LDS
+			 * address of the term's polynomial and the offset from the segment's middle */
+			struct Tx   { float t_rel; f32x2 cs; int tf; };
+			struct Four { f32x2 gm[2]; uint32_t at[4]; };
+			auto transmit = [&](uint32_t g, uint32_t al, int tf_lanes, int tfh_lanes) -> Tx {
+				Tx tx;
 				const int a = first_transmit + (int)(g * AT + al);
 				float t_index = transmit_index(a);
 				asm volatile("" : "+v"(t_index));
-				const int   tf = __builtin_amdgcn_readlane(tf_lanes, (int)al);
+				tx.tf = __builtin_amdgcn_readlane(tf_lanes, (int)al);
 				const float turns = hw_fract(turns_per_sample * t_index);
-				term.turns = turns;
+				tx.cs = f32x2{hw_cos_turns(turns), hw_sin_turns(turns)};
 				/* + 1/2: y below rounds to the SEGMENT (the window starts one sample early); exact (multiples of an ulp of t_index, small) */
-				const float t_rel = t_index - __builtin_bit_cast(float, __builtin_amdgcn_readlane(tfh_lanes, (int)al));
+				tx.t_rel = t_index - __builtin_bit_cast(float, __builtin_amdgcn_readlane(tfh_lanes, (int)al));
+				return tx;
+			};
+			auto four = [&](auto checked, const Tx &tx, uint32_t buf, uint32_t al) -> Four {
+				constexpr bool CHECK = decltype(checked)::value;
+				Four f;
 				#pragma unroll
-				for (int h = 0; h < CH / 2; h++) {
+				for (int h = 0; h < 2; h++) {
 					/* element index 2 + buf * 2048 + (k * AT + al) * W + segment in the low mantissa bits of y = p + M */
 					const uint32_t m0 = 0x4B000002u + buf * kTileElems + ((uint32_t)(2 * h) * AT + al) * W, m1 = m0 + AT * W;
 					const f32x2 M = {__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1)};
-					const f32x2 pos = r_rel[h] + t_rel;
+					const f32x2 pos = r_rel[h] + tx.t_rel;
 					const f32x2 yv = pos + M;
-					term.gm[h] = pos - (yv - M);
+					f.gm[h] = pos - (yv - M);
 					/* (copies first: hipcc's __builtin_bit_cast of a vector ELEMENT reads element 0 whichever one is named) */
 					const float    y0 = yv.x, y1 = yv.y;
 					const uint32_t yb[2] = {__builtin_bit_cast(uint32_t, y0), __builtin_bit_cast(uint32_t, y1)};
@@ -398,16 +408,16 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 						/* absolute tap k_abs = segment - 1 + the two floors; valid for 1 <= k_abs < S - 2; and -- the window is the block's own
 						 * construction -- never outside it: a segment beyond [1, W - 3] would be a bug in this kernel, so it reads zeros too */
 						const uint32_t seg[2]   = {yb[0] - m0, yb[1] - m1};
-						const uint32_t k_abs[2] = {(uint32_t)((int)seg[0] - 1 + rfl[2 * h] + tf), (uint32_t)((int)seg[1] - 1 + rfl[2 * h + 1] + tf)};
+						const uint32_t k_abs[2] = {(uint32_t)((int)seg[0] - 1 + rfl[2 * h] + tx.tf), (uint32_t)((int)seg[1] - 1 + rfl[2 * h + 1] + tx.tf)};
 						at[0] = ((k_abs[0] - 1u) < (uint32_t)(S - 3) && (seg[0] - 1u) <= W - 4u) ? at[0] : zero_at;
 						at[1] = ((k_abs[1] - 1u) < (uint32_t)(S - 3) && (seg[1] - 1u) <= W - 4u) ? at[1] : zero_at;
 					}
-					term.at[2 * h] = at[0]; term.at[2 * h + 1] = at[1];
+					f.at[2 * h] = at[0]; f.at[2 * h + 1] = at[1];
 				}
-				return term;
+				return f;
 			};
-			/* one group of AT transmits out of buffer `buf`: the reads of a transmit's four polynomials are in flight while the next transmit's
-			 * addresses are computed */
+			/* one group of AT transmits out of buffer `buf`, four terms (one transmit, four channels) a step: the reads of a step's four
+			 * polynomials are in flight while the addresses of the next step's are computed */
 			auto consume = [&](auto checked, uint32_t g, uint32_t buf) {
 				const uint32_t a0 = (uint32_t)first_transmit + g * AT;
 				const uint32_t n  = (uint32_t)A - a0 < AT ? (uint32_t)A - a0 : AT;            /* block uniform; >= 1 */
@@ -415,31 +425,39 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				a_lane = a_lane < (uint32_t)A ? a_lane : (uint32_t)A - 1u;
 				const int tf_lanes  = *lds_i(tfl_at + 4u * a_lane);      /* lane l: floor of the block's smallest index of transmit a0 + l % AT */
 				const int tfh_lanes = __builtin_bit_cast(int, (float)tf_lanes - 0.5f);
-				/* one transmit: issue its reads, prepare the one after it (if any) into `next` while they fly, then the arithmetic */
-				auto step = [&](const Term &cur, Term &next, uint32_t al) -> bool {
-					f32x4 lo[CH], hi[CH];
+				/* the arithmetic of four terms out of the registers the reads filled */
+				auto reads = [&](const Four &f, f32x4 (&lo)[4], f32x4 (&hi)[4]) {
 					#pragma unroll
-					for (int k = 0; k < CH; k++) { lo[k] = *(lds_f32x4 *)(uintptr_t)cur.at[k]; hi[k] = *(lds_f32x4 *)(uintptr_t)(cur.at[k] + 16u); }
-					const bool more = al + 1u < n;                               /* block uniform */
-					if (more) next = prepare(checked, g, buf, al + 1u, tf_lanes, tfh_lanes);
-					const f32x2 cs = {hw_cos_turns(cur.turns), hw_sin_turns(cur.turns)}, csr = {-cs.y, cs.x};
-					#pragma unroll
-					for (int k = 0; k < CH; k++) {
-						const float gk = cur.gm[k / 2][k & 1];
-						f32x2 sv = f32x2{hi[k].z, hi[k].w} * gk + f32x2{hi[k].x, hi[k].y};
-						sv = sv * gk + f32x2{lo[k].z, lo[k].w};
-						sv = sv * gk + f32x2{lo[k].x, lo[k].y};
-						acc[k] += sv.x * cs;                                     /* s e^{j phi}: the real part times (cos, sin) ... */
-						acc[k] += sv.y * csr;                                    /* ... the imaginary part times (-sin, cos) */
-						if constexpr (CW) part_abs[k] += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
-					}
-					return more;
+					for (int j = 0; j < 4; j++) { lo[j] = *(lds_f32x4 *)(uintptr_t)f.at[j]; hi[j] = *(lds_f32x4 *)(uintptr_t)(f.at[j] + 16u); }
 				};
-				/* (two transmits per turn, their terms in two fixed sets of registers: handing `next` over to `cur` costs six moves a transmit) */
-				Term even = prepare(checked, g, buf, 0, tf_lanes, tfh_lanes), odd = even;
+				auto sums = [&](const Four &f, const Tx &tx, const f32x4 (&lo)[4], const f32x4 (&hi)[4]) {
+					const f32x2 cs = tx.cs, csr = {-cs.y, cs.x};
+					#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const float gk = f.gm[j / 2][j & 1];
+						f32x2 sv = f32x2{hi[j].z, hi[j].w} * gk + f32x2{hi[j].x, hi[j].y};
+						sv = sv * gk + f32x2{lo[j].z, lo[j].w};
+						sv = sv * gk + f32x2{lo[j].x, lo[j].y};
+						acc[j] += sv.x * cs;                             /* s e^{j phi}: the real part times (cos, sin) ... */
+						acc[j] += sv.y * csr;                            /* ... the imaginary part times (-sin, cos) */
+						if constexpr (CW) part_abs[j] += hw_sqrt(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x));
+					}
+				};
+				/* two transmits per turn, their terms in two fixed sets of registers (handing `next` over to `cur` costs six moves a transmit) */
+				Tx   tx   = transmit(g, 0, tf_lanes, tfh_lanes), tx_odd = tx;
+				Four even = four(checked, tx, buf, 0), odd = even;
 				for (uint32_t al = 0; ; al += 2u) {
-					if (!step(even, odd, al)) break;
-					if (!step(odd, even, al + 1u)) break;
+					f32x4 lo[4], hi[4];
+					reads(even, lo, hi);
+					bool more = al + 1u < n;                                     /* block uniform */
+					if (more) { tx_odd = transmit(g, al + 1u, tf_lanes, tfh_lanes); odd = four(checked, tx_odd, buf, al + 1u); }
+					sums(even, tx, lo, hi);
+					if (!more) break;
+					reads(odd, lo, hi);
+					more = al + 2u < n;
+					if (more) { tx = transmit(g, al + 2u, tf_lanes, tfh_lanes); even = four(checked, tx, buf, al + 2u); }
+					sums(odd, tx_odd, lo, hi);
+					if (!more) break;
 				}
 			};
 			/* (the range-checked and the unchecked loops as two copies of the whole group loop -- the same barriers in both: accumulators
@@ -469,39 +487,49 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 				const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)}, csr = {-cs.y, cs.x};
 				const uint32_t row0 = ((uint32_t)c0 * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES;
 				const uint32_t row_step = (uint32_t)A * (uint32_t)S * ES;
-				float frac[CH]; uint32_t off[CH];
-				#pragma unroll
-				for (int k = 0; k < CH; k++) {
-					const float index = t_index + r_index[k];
-					frac[k] = hw_fract(index);
-					const uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
-					off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
-				}
-				f32x4 d0[CH], d1[CH];
-				#pragma unroll
-				for (int k = 0; k < CH; k++) { d0[k] = gather<f32x4_a8>(rf, off[k]); d1[k] = gather<f32x4_a8>(rf, off[k] + 16); }
-				#pragma unroll
-				for (int k = 0; k < CH; k++) {
-					f32x2 s0 = {d0[k].x, d0[k].y}, s1 = {d0[k].z, d0[k].w}, s2 = {d1[k].x, d1[k].y}, s3 = {d1[k].z, d1[k].w};
-					f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
-					f32x2 c3 = (T1 + T2) - 2.0f * D;
-					f32x2 c2 = (D - T1) - c3;
-					float t  = frac[k];
-					f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
-					acc[k] += sv.x * cs;
-					acc[k] += sv.y * csr;
-					if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
+				{
+					float frac[4]; uint32_t off[4];
+					#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const int   k = j;
+						const float index = t_index + r_index[k];
+						frac[j] = hw_fract(index);
+						const uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
+						off[j] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+					}
+					f32x4 d0[4], d1[4];
+					#pragma unroll
+					for (int j = 0; j < 4; j++) { d0[j] = gather<f32x4_a8>(rf, off[j]); d1[j] = gather<f32x4_a8>(rf, off[j] + 16); }
+					#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						f32x2 s0 = {d0[j].x, d0[j].y}, s1 = {d0[j].z, d0[j].w}, s2 = {d1[j].x, d1[j].y}, s3 = {d1[j].z, d1[j].w};
+						f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
+						f32x2 c3 = (T1 + T2) - 2.0f * D;
+						f32x2 c2 = (D - T1) - c3;
+						float t  = frac[j];
+						f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
+						acc[j] += sv.x * cs;
+						acc[j] += sv.y * csr;
+						if constexpr (CW) { f32x2 sq = sv * sv; part_abs[j] += hw_sqrt(sq.x + sq.y); }
+					}
 				}
 			}
 		}
 
-		/* fold the chunk in: sum_a s e^{j phi(T)} times the channel's apod e^{j phi(R)} (das_factored.hip) */
+		/* fold the chunk in: sum_a s e^{j phi(T)} times the channel's apod e^{j phi(R)} (das_factored.hip).  The receive index is worked
+		 * out again (the same expressions, the same value): carried through the transmit loop it would cost a register per channel */
 		#pragma unroll
 		for (int k = 0; k < CH; k++) {
-			const bool  pass  = r_index[k] > -1.0e8f;
-			const float dx    = lateral - (float)(c0 + k) * pitch;
-			const float apod  = pass ? apodize(__builtin_fabsf(dx * f_over_z)) : 0.f;
-			const float turns = hw_fract(turns_per_sample * r_index[k]);
+			const int   channel = c0 + k;
+			float dx = lateral - (float)channel * pitch;
+			asm volatile("" : "+v"(dx));
+			const float a_arg = __builtin_fabsf(dx * f_over_z);
+			const bool  pass  = a_arg < 0.5f && channel < C;
+			const float dist  = hw_sqrt(dx * dx + zz);
+			const float index = FAMILY == BF_DAS_RCA ? div_speed_of_sound(dist, p) * p.sampling_frequency
+			                                         : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+			const float apod  = pass ? apodize(a_arg) : 0.f;
+			const float turns = hw_fract(turns_per_sample * index);
 			const float r_re  = apod * hw_cos_turns(turns), r_im = apod * hw_sin_turns(turns);
 			const f32x2 part  = acc[k];
 			coherent.x += r_re * part.x - r_im * part.y;
