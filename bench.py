@@ -378,7 +378,7 @@ def main():
             "roofline": {
                 # what limits the dominant kernel (`binding` prices it): VALU issue for the LDS-staged kernel, the per-CU texture-address path for
                 # the gather kernels.  achieved / peak / frac keep the contract's HBM formula (see contract_note)
-                "bound": {"das_rca_staged_kernel": "valu-issue", "das_hercules_kernel": "valu-issue"}.get(KERNEL_NAMES[das_path], "texture-address path (per-lane gathers served by L1)"),
+                "bound": {"das_rca_staged_kernel": "valu-issue", "das_hercules_kernel": "valu-issue", "das_tile_kernel": "valu-issue"}.get(KERNEL_NAMES[das_path], "texture-address path (per-lane gathers served by L1)"),
                 "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved * 1e9 / HBM_PEAK,
                 "contract_note": "achieved / peak / frac follow the contract's formula: ALGORITHMIC gather bytes / kernel time / 8 TB/s.  The quotient exceeds 1 "
@@ -465,6 +465,29 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {best['clock_ghz']:.3f} GHz (clock sustained in that probe) / {per_pair:.2f} clk",
                 "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_pair_per_simd": per_pair,
                 "source": f"profiles/{micro_name} hercules_stream (tools/microbench.hip hercules_probe); achieved measured in this run",
+            }
+        elif kernel == "das_tile_kernel":
+            # VALU issue, priced against the kernel's own instruction stream as the committed PMC pass counted it (SQ_ACTIVE_INST_VALU: the
+            # cycles a SIMD spent issuing the kernel's VALU instructions, per executed wave64 term), and next to it the LDS read path: two
+            # ds_read_b128 per term and lane = 2 KiB per wave64 term at 128 B/clk/CU
+            clock = max(g["clock_ghz"] for g in micro["gather"])
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_tile_cfg2.json")) as f:
+                pmc = json.load(f)
+            per_term = pmc["valu_busy_cycles_per_wave_term_per_simd"]
+            peak = cus * 4 * 64 * clock * 1e9 / per_term
+            lds_clk = 16.0
+            lds_peak = cus * 64 * clock * 1e9 / lds_clk
+            out = {
+                "resource": f"VALU issue: {per_term:.1f} clk of VALU-busy time per wave64 (voxel, channel, transmit) term per SIMD "
+                            f"({pmc['valu_instructions_per_wave_term']:.1f} instructions: transmit delay and phase, window position, cubic Horner, rotate-accumulate, "
+                            "plus the staging, reductions and fold around the loop)",
+                "achieved": terms / das_s / 1e12, "unit": "T terms/s (terms that pass the f-number test)", "peak": peak / 1e12,
+                "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {clock:.3f} GHz / {per_term:.1f} clk (every SIMD issuing nothing but this kernel's VALU stream)",
+                "frac": terms / das_s / peak, "probe_clock_ghz": clock, "peak_cycles_per_term_per_simd": per_term,
+                "source": "profiles/r03_pmc_tile_cfg2.json (tools/pmc_das.py, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU over config 2's launch); achieved measured in this run",
+                "lds_read_path": {"cycles_per_term_per_cu": lds_clk, "peak": lds_peak / 1e12, "frac": terms / das_s / lds_peak,
+                                  "model": "two ds_read_b128 per term and lane = 2 KiB per wave64 term at 128 B/clk/CU: the floor under the gathers' 32.6 clk "
+                                           "(two wave64 gather instructions through L1), which is what das_factored.hip waits for on the same frame"},
             }
         elif kernel == "das_rca_staged_kernel":
             best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8 and v["stream"].startswith("das_staged term, shipping form")),

@@ -24,10 +24,11 @@ done
 echo "pmc done"
 python3 tools/summarize_profiles.py --round $R $OUT/pmc_cfg4/summary.json $OUT/pmc_cfg4_ta/summary.json $OUT/pmc_cfg2/summary.json $OUT/pmc_cfg5/summary.json \
         $OUT/pmc_harness_tpw/summary.json $OUT/pmc_harness_hercules/summary.json $OUT/pmc_harness_forces/summary.json
-cp profiles/das_traffic.json profiles/${R}_das_bound.json $OUT/profiles/
+python3 tools/tile_pmc_summary.py $OUT/pmc_cfg2/summary.json profiles/${R}_pmc_tile_cfg2.json
+cp profiles/das_traffic.json profiles/${R}_das_bound.json profiles/${R}_pmc_tile_cfg2.json $OUT/profiles/
 exit 0
 fi
-# ---- part "bench" (expects profiles/r03_microbench.json, das_traffic.json and r03_das_bound.json of part "pmc" in the tree)
+# ---- part "bench" (expects profiles/r03_microbench.json, das_traffic.json, r03_das_bound.json and r03_pmc_tile_cfg2.json of part "pmc" in the tree)
 timeout -k 10 400 python bench.py > $OUT/profiles/${R}_bench.json 2> $OUT/bench.err
 cut -c1-400 $OUT/profiles/${R}_bench.json
 for c in 1 2 3 5; do
@@ -42,6 +43,7 @@ done
 for k in tpw forces; do
   timeout -k 10 200 python bench.py --config harness:$k --das-path 128 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_harness_${k}_gather_loop.json 2> /dev/null
 done
+PYTHONPATH=. timeout -k 10 300 python tools/tile_threshold.py --json $OUT/profiles/${R}_tile_threshold.json > $OUT/tile_threshold.log 2>&1
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
 python3 - <<'PY'
 import json
@@ -75,9 +77,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 for k in tpw hercules forces; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$k -o harness_$k -- python3 $ROOT/bench.py --config harness:$k --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_harness_${k}_rocprof.json 2> $OUT/rocprof_$k.err
 done
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats2 -o cfg2 -- python3 $ROOT/bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_cfg2_rocprof.json 2> $OUT/rocprof2.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats5 -o cfg5 -- python3 $ROOT/bench.py --config 5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg5_rocprof.json 2> $OUT/rocprof5.err
 cd $ROOT
-for n in fast cfg5 harness_tpw harness_hercules harness_forces; do f=$(find $OUT -name "${n}_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/profiles/${R}_${n}_kernel_stats.csv; done
+for n in fast cfg2 cfg5 harness_tpw harness_hercules harness_forces; do f=$(find $OUT -name "${n}_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/profiles/${R}_${n}_kernel_stats.csv; done
 python3 tools/kernel_resources.py --json $OUT/profiles/${R}_kernel_resources.json > $OUT/kernel_resources.log 2>&1 || true
 timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $OUT/profiles/${R}_pytest_gpu.log
 cat $OUT/profiles/${R}_pytest_gpu.log

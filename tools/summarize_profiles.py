@@ -19,7 +19,7 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # as bench.py: the kernel's own file plus the headers every DAS kernel includes, comments and whitespace removed
 KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
-                "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip"}
+                "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_tile_kernel": "das_tile.hip", "das_hercules_kernel": "das_hercules.hip"}
 COMMON_SOURCES = ["das_common.h", "bf_kernels.h", "das_select.cpp"]
 
 
