@@ -661,7 +661,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 		 * trying); flag 0x100 forces it wherever it is supported, 0x200 forbids it. */
 		{
 			bool tile_ok = plan.iq_pipeline && a.interpolation == 2 && Sd >= 8 && out.das_input_bytes < (1ull << 31) &&
-			               (uint64_t)ext[0] * ext[1] * ext[2] >= 1024u && A - (a.family == BF_DAS_FORCES && a.sparse ? 1u : 0u) >= 4u;
+			               A - (a.family == BF_DAS_FORCES && a.sparse ? 1u : 0u) >= 4u;
 			/* tile: 64 voxels along x (a wave), the other 16 along the next axis that has voxels */
 			uint32_t shift[3] = {0, 0, 0}, left = 10;
 			for (int k = 0; k < 3 && left; k++) {
@@ -671,6 +671,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 				shift[k] = give; left -= give;
 			}
 			for (int k = 0; k < 3 && left; k++) { uint32_t room = ceil_log2(ext[k]) - shift[k]; uint32_t give = room < left ? room : left; shift[k] += give; left -= give; }
+			/* (left > 0: a frame -- or a device's slab of it -- that does not even span one 1024-voxel tile) */
 			const float spread = tile_spread_estimate(a, tx, to_xdc, plan.das_voxel_transform, shift);
 			/* frames small enough for the channel split (under 4096 voxel waves): one block per CU, so the block-staged kernel is
 			 * only worth it from about three quarters of the CUs (config 2 onto 448 x 448: 196 blocks, 0.66 ms against the split

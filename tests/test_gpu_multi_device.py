@@ -62,6 +62,27 @@ def test_slabs_stitch_to_the_one_device_frame(name, count, bflib, devices):
     assert np.array_equal(np.array(mm[:]), np.array(mm_one[:]), equal_nan=True)
 
 
+@pytest.mark.parametrize("name, count", [("rca_sep_ragged_cubic", 3), ("rca_staged_cubic", 2)])
+def test_block_staged_kernel_slabs(name, count, bflib, devices):
+    """das_tile.hip (das path 6, asked for with flag 0x100) on z-slabs of a volume: every device context runs it on its planes
+    (z_first, z_count in the kernel's tiling) and the stitched frame is bit-identical to the one-device frame."""
+    acq = cases.make(name)
+    lib = bflib.library()
+    try:
+        lib.beamformer_hip_set_das_path(0x14 | 0x100)
+        devices([0])
+        one = bflib.beamform(acq.bp, acq.rf, acq.filters).copy()
+        t = P.HipFrameTimings()
+        assert lib.beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 6
+        devices([0] * count)
+        many = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        assert same_bits(one, many)
+        for i in range(count):
+            assert lib.beamformer_hip_get_device_frame_timings(i, C.byref(t)) and int(t.das_path) == 6 and int(t.das_voxels) > 0
+    finally:
+        lib.beamformer_hip_set_das_path(0)
+
+
 def test_pipelined_pushes_export_sum_and_display(bflib, devices):
     """Five frames pushed back to back through three RF slots on three device contexts, then the last
     two exported oldest-first, averaged and display-reduced: all equal to the one-device results."""
