@@ -3,9 +3,9 @@
  * array axis: BASELINE config 2), view planes through row-column data, FORCES -- with cubic interpolation of IQ samples.
  *
  * Same arithmetic contract as das_factored.hip (shaders/das.glsl RCA :204-231, FORCES :288-321, cubic :67-97): the sample
- * index of a voxel is a receive term plus a transmit term, so a thread keeps the receive factors {R index, apod e^{j phi(R)},
- * apod} of CH channels in registers, walks the transmits computing {T index, e^{j phi(T)}} once per transmit and chunk, and
- * per (voxel, channel, transmit) term adds the two indices, interpolates and rotate-accumulates.
+ * index of a voxel is a receive term plus a transmit term, so a thread keeps the receive index of CH channels in registers,
+ * walks the transmits computing {T index, e^{j phi(T)}} once per transmit and chunk, per (voxel, channel, transmit) term adds
+ * the two indices, interpolates and rotate-accumulates, and applies the channel's apod e^{j phi(R)} once, when the chunk folds.
  *
  * das_factored.hip gathers the four taps of a term through L1: two wave64 gather instructions, 32.6 clk per CU per term
  * (tools/microbench.hip), which is what config 2 waits for (texture path 0.88 busy; 59 VALU clk per term beside it).  Neither
@@ -23,6 +23,8 @@
  *     does not fit the window (near field, steep grids) takes das_factored.hip's gather loop instead, block-uniformly;
  *   * two LDS buffers of CH x AT windows: the loads of group g + 1 are in flight (registers) while group g is consumed,
  *     converted and written behind it; one barrier per group;
+ *   * the transmit loop is rotated and unrolled by two: a transmit's eight reads are issued, the next transmit's delay, phase and
+ *     addresses are computed while they fly, then the arithmetic;
  *   * sample_rf's range test (1 <= index < S - 2) per wave: waves that cannot leave the RF row run an unchecked loop, the
  *     others test every term and read a zero element instead.
  * One block per CU (131 KB of windows, <= 128 VGPRs).  No MFMA: gather-accumulate.
