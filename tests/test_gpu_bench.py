@@ -39,6 +39,21 @@ def test_single_gpu_line():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "voxels/s" and cpu["sample"]
 
 
+def test_config2_line_names_the_block_staged_kernel():
+    """BASELINE config 2 at full size (2.7 ms a frame): the line's das_plan and roofline name das_tile.hip, `bound` is VALU issue,
+    `binding` prices the launch against the kernel's own VALU stream (committed PMC pass) with the LDS read path beside it"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    roof = d["roofline"]
+    assert d["config"]["das_plan"]["kernel"] == roof["kernel"] == "das_tile_kernel" and d["config"]["das_plan"]["tile_window_samples"] == 64
+    assert roof["bound"] == "valu-issue"
+    b = roof["binding"]
+    assert 0.3 < b["frac"] < 1.0 and b["lds_read_path"]["cycles_per_term_per_cu"] == 16.0 and 0.2 < b["lds_read_path"]["frac"] < 1.0
+    assert 1024 * 1024 / (d["ms_per_step"] * 1e-3) == pytest.approx(d["value"], rel=1e-6)
+
+
 @pytest.mark.parametrize("extra", [[], ["--serial-broadcast"]])
 def test_two_ranks_rehearsed_on_one_gpu(extra):
     with socket.socket() as s:
