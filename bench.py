@@ -565,14 +565,39 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown.
+    A one-GPU box of the pool shows 256 logical CPUs to nproc and sched_getaffinity but runs under `cpu.max = 1600000 100000`:
+    16 CPUs.  Threads beyond the quota are throttled, not parallel -- round 2's 256-thread leg was 16 CPUs time-sliced 16 ways,
+    which is why it lost to the 16-thread one."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            return max(1, quota // period)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(acq, budget_s):
     """The CPU oracle (port of the reference shaders) on a bounded sample of the same frame: all x,
     a few rows, on EVENLY SPACED z-planes (the f-number culling -- and with it the work per voxel --
     varies with depth); voxels are independent, so voxels/s extrapolates linearly.  Legs as
-    BASELINE.md section 3 asks: every core the process may use, half of them, the 16-core share a one-GPU
-    box owns, one thread.  Since round 3 the oracle's DAS hands ROWS of the image to the threads and walks
+    BASELINE.md section 3 asks: every CPU the process may USE (affinity capped by the cgroup's CPU quota), half of them,
+    one thread -- and, when the quota is below the visible CPU count, one oversubscribed leg at twice the quota to show
+    that more threads than the quota buy nothing.  The oracle's DAS hands ROWS of the image to the threads and walks
     the 16-channel chunks inside each (one parallel region; bit-identical to the reference's chunk-by-chunk
-    order, tests/test_oracle.py), so the all-core leg scales instead of losing to the 16-thread one."""
+    order, tests/test_oracle.py)."""
     from oracle import binding as oracle
     bp = acq.bp
     X, Y, Z = (max(1, v) for v in bp.output_points[:3])
@@ -604,18 +629,25 @@ def cpu_baseline(acq, budget_s):
                 "sample": (f"oracle DAS over {X}x{rows}x{planes} voxels ({planes} evenly spaced z-planes from {z_stride // 2} step {z_stride}, {rows} evenly spaced rows each) "
                            f"of the {X}x{Y}x{Z} frame, {pairs} pairs in {das_s:.2f} s DAS time ({wall:.2f} s incl. the single-threaded pre-DAS stages over the whole RF)")}
 
-    share = min(affinity, int(os.environ.get("BENCH_CPU_THREADS", "16")))
-    counts = sorted({affinity, max(1, affinity // 2), share, 1}, reverse=True)
-    weight = {n: (0.3 if n > share else 0.25 if n > 1 else 0.2) for n in counts}
+    quota = cpu_quota()
+    usable = max(1, min(affinity, quota or affinity, int(os.environ.get("BENCH_CPU_THREADS", str(affinity)))))
+    counts = sorted({usable, max(1, usable // 2), 1}, reverse=True)
+    oversubscribed = min(affinity, 2 * usable) if usable < affinity else None
+    weight = {n: (0.4 if n == usable else 0.25) for n in counts}
+    if oversubscribed:
+        weight[oversubscribed] = 0.2
     total = sum(weight.values())
-    legs = {n: sample(n, budget_s * weight[n] / total) for n in counts}
-    best = max(legs.values(), key=lambda leg: leg["value"])
-    # the headline figure is the fastest leg; every leg is listed
-    return {
+    legs = {n: sample(n, budget_s * weight[n] / total) for n in weight}
+    best = max((legs[n] for n in counts), key=lambda leg: leg["value"])
+    # the headline figure is the fastest leg within the quota; every leg is listed
+    out = {
         "value": best["value"], "unit": "voxels/s", "cores": best["cores"], "kind": "port", "sample": best["sample"],
-        "all_cores": legs[affinity], "half_of_them": legs[max(1, affinity // 2)], "box_share": legs[share], "one_thread": legs[1],
-        "nproc": os.cpu_count(), "affinity": affinity,
+        "all_usable_cpus": legs[usable], "half_of_them": legs[max(1, usable // 2)], "one_thread": legs[1],
+        "nproc": os.cpu_count(), "affinity": affinity, "cgroup_cpu_quota": quota,
     }
+    if oversubscribed:
+        out["twice_the_quota"] = legs[oversubscribed]
+    return out
 
 
 if __name__ == "__main__":

@@ -321,7 +321,7 @@ def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits,
     channel for IQ samples, up to 8 for real ones, by the transmit count and the window size); the BASELINE
     configurations only reach two of them.  Config 4's geometry at 128 channels with 24 to 128 transmits, IQ
     (Demodulate; linear and cubic) and real (undecimated: 64-sample windows) samples, one slab: the staged kernel
-    (automatic) against what path 2 runs -- the gather kernel, or the factored kernel for cubic --, which the
+    (automatic) against what path 2 runs -- the gather kernel, or the block-staged factored kernel for cubic --, which the
     oracle-checked tests hold to the oracle."""
     Cn, S = 128, 2048
     half = (Cn - 1) / 2 * 0.15e-3
@@ -333,8 +333,9 @@ def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits,
     staged = run(bflib, acq, shard=(120, 4))
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
     if interp == P.InterpolationMode.Cubic and transmits == 128:
-        # 128 transmits x 32-byte window elements do not fit the LDS: the staged cubic kernel declines, the factored kernel runs
-        assert int(t.das_path) == 3
+        # 128 transmits x 32-byte window elements do not fit the LDS: the staged cubic kernel declines, the factored kernel runs -- in its
+        # block-staged form (das_tile.hip): the slab's grid is fine enough for 64-sample windows
+        assert int(t.das_path) == 6
         return
     assert int(t.das_path) == 2
     bflib.set_hook("STAGED_CHECKED", "1")
@@ -344,8 +345,8 @@ def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits,
     finally:
         bflib.set_hook("STAGED_CHECKED", None)
     assert np.array_equal(checked.view(np.uint32), staged.view(np.uint32))
-    gathered = run(bflib, acq, shard=(120, 4), path=2)          # cubic: the factored kernel
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == (3 if interp == P.InterpolationMode.Cubic else 1)
+    gathered = run(bflib, acq, shard=(120, 4), path=2)          # cubic: the factored kernel (block-staged form)
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == (6 if interp == P.InterpolationMode.Cubic else 1)
     assert np.array_equal(np.isnan(staged), np.isnan(gathered))
     ok = ~np.isnan(gathered)
     assert ok.any() and np.abs(staged[ok] - gathered[ok]).max() / np.abs(gathered[ok]).max() < 1e-4
