@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU-baseline budget (DAS time summed over its three legs)")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 2 auto without the LDS-staged kernel (the gather kernel instead), 3 LDS-staged kernel wherever its window bound holds, 4 factored kernel wherever it applies, 6 HERCULES aligned-grid kernel also on narrow grids")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 2 auto without the LDS-staged kernel (the gather kernel instead), 3 LDS-staged kernel wherever its window bound holds, 4 factored kernel wherever it applies, 6 HERCULES aligned-grid kernel also on narrow grids; flags to add: 16 no channel split, 64 / 128 wave-span staging on / off, 256 / 512 the block-staged factored kernel (das_tile.hip) on / off")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="multi-GPU: broadcast and compute back to back on one stream instead of pipelined")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",

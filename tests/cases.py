@@ -156,6 +156,9 @@ def _cases():
     # ... a grid fine enough for the 32-sample window (16 transmits per staged group) ...
     c["tile_w32"] = lambda: cfg.rca("tile_w32", 16, 20, 768, (128, 32, 1), (-0.5e-3, 0, 8.0e-3), (0.5e-3, 0, 8.3e-3), seed=77,
                                     interp=I.Cubic, orientation=0x22, f_number=1.2, pitch=0.2e-3, angles=np.linspace(-9, 9, 20))
+    # ... a thin volume whose tile takes voxels of two z planes (64 x 8 x 2) ...
+    c["tile_thin_volume"] = lambda: cfg.rca("tile_thin_volume", 16, 8, 768, (96, 6, 6), (-1.4e-3, -0.3e-3, 7.0e-3), (1.4e-3, 0.3e-3, 7.5e-3), seed=78,
+                                            interp=I.Cubic, orientation=0x22, cw=True, f_number=1.0, pitch=0.2e-3, angles=np.linspace(-8, 8, 8))
     # ... diverging and focused transmits (the square root per transmit), steered along the receive axis ...
     c["tile_vls"] = lambda: cfg.rca("tile_vls", 16, 6, 768, (128, 32, 1), (-1.6e-3, 0, 7.0e-3), (1.6e-3, 0, 9.2e-3), seed=73,
                                     interp=I.Cubic, orientation=0x22, kind=K.RCA_VLS, f_number=0.9, pitch=0.2e-3,
