@@ -294,6 +294,18 @@ def test_config4_f32_complex_rows_at_the_edges_of_the_volume(das_mode, kernel, b
     print(f"config 4 geometry, f32 complex RF, {3 * len(selections)} rows: max error {worst[0]:.2e} of the peak, {worst[1]:.2e} of the rows' own maximum")
 
 
+def test_config2_block_staged_frames_repeat_bit_for_bit(bflib):
+    """Config 2 at full size on das_tile.hip, twelve frames of the same push: 1024 blocks on 256 CUs, four rounds of the chip, every
+    block handing 32 x 4 x 2 LDS buffers from its staging threads to its consumers -- a missing barrier shows as a frame that differs."""
+    acq = cfg.config(2)
+    first = run(bflib, acq).copy()
+    t = P.HipFrameTimings()
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 6 and int(t.tile_gather_chunks) == 0
+    for k in range(11):
+        again = run(bflib, acq)
+        assert np.array_equal(first.view(np.uint32), again.view(np.uint32)), f"frame {k + 2} differs from the first"
+
+
 def test_config2_f32_complex_first_and_last_rows(bflib, oracle):
     """Config 2's geometry (128 ch x 31 tx -> 1024^2, cubic, block-staged factored kernel) on Float32Complex RF: the
     first and the last three image rows (depth extremes) and the scatterer's rows against the float oracle."""

@@ -470,3 +470,21 @@ def test_factored_kernel_block_staging(name, bflib, oracle):
         lib.beamformer_hip_enable_pair_counting(0)
         lib.beamformer_hip_set_das_path(0)
     compare(tile, ref, acq, flags)
+
+
+@pytest.mark.parametrize("name", ["tile_near_field", "tile_tpw_cw_short", "tile_thin_volume"])
+def test_block_staged_kernel_is_deterministic(name, bflib):
+    """das_tile.hip hands LDS windows from 1024 staging threads to 1024 consumers across two buffers and four kinds of barrier: a missing
+    one shows as a frame that differs from run to run.  Forty frames of the same push, bit for bit (staged and gathered chunks, the checked
+    loop, a tile over two planes)."""
+    acq = cases.make(name)
+    lib = bflib.library()
+    try:
+        lib.beamformer_hip_set_das_path(0x14 | 0x100)
+        first = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
+        assert last_das_path(bflib) == 6
+        for k in range(39):
+            again = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters))
+            assert np.array_equal(first.view(np.uint32), again.view(np.uint32)), f"frame {k + 2} differs from the first"
+    finally:
+        lib.beamformer_hip_set_das_path(0)
