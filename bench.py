@@ -227,7 +227,7 @@ def main():
                 "tile_walk": int(dd.tile_walk), "span_stage": int(dd.span_stage), "u_axis": int(dd.u_axis), "u_shift": int(dd.u_shift), "v_shift": int(dd.v_shift),
                 "window_samples": int(dd.window_samples), "uniform_tables": int(dd.uniform_tables), "lds_bytes": int(dd.lds_bytes), "threads": int(dd.threads),
                 "channel_chunk": int(dd.channel_chunk), "hercules_prepared_copy": int(dd.hercules_prepared_copy),
-                "tile_window_samples": int(dd.tile_window_samples),
+                "tile_window_samples": int(dd.tile_window_samples), "tile_spread_estimate": round(float(dd.tile_spread_estimate), 2),
                 "declined": {str(k): bytes(dd.declined[k]).split(b"\0")[0].decode() for k in range(8) if bytes(dd.declined[k]).split(b"\0")[0]}}
 
     # one untimed frame with the geometry-only pair count: G of BASELINE.md section 4

@@ -219,6 +219,7 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
  * and, read ONCE into the hook table (beamformer_hip_set_hook changes them at run time; measurement and test aids):
  *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major (=column: view planes walked depth
  *                                    fastest instead of in XCD-balanced bands)
+ *   BEAMFORMER_HIP_TILE_WINDOW=32    das_tile.hip with the 32- (or =64: 64-) sample window whatever the estimated spread: chunks that do not fit run its gather loop
  *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
  *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernels' range-checked loop for every wave; it also counts window violations
  *                                    (BeamformerHipFrameTimings::staged_window_violations)
@@ -307,6 +308,9 @@ typedef struct {
 	uint32_t u_axis, u_shift, v_shift, window_samples, uniform_tables, lds_bytes, threads, channel_chunk;   /* separable-delay kernels: the tile is 2^u_shift voxels
 	                                   along the receive axis (voxel axis u_axis) by 2^v_shift along the transmit axis, one plane thick */
 	uint32_t hercules_prepared_copy;/* HERCULES kernel: reads the {sample, difference} / polynomial copy of the DAS input */
+	float    tile_spread_estimate;  /* factored-kernel frames: the host's upper bound of a 1024-voxel tile's delay spread in samples (what decides
+	                                   for or against path 6; the kernel measures the real spread per block and chunk); 0 where not computed */
+	uint32_t tile_estimate_shift[3];/* ... and the tile it was computed for */
 } BeamformerHipDasDescription;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDescription *out);
 

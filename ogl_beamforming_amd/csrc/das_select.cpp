@@ -37,7 +37,7 @@ const char *das_kernel_name(int path)
 
 static Hooks g_hooks;
 static const char *const g_hook_names[] = {"STAGED_SHAPE", "STAGED_CHECKED", "STAGED_NOUNIFORM", "STAGED_W48", "STAGED_WALK", "STAGED_TABLE_CAP",
-                                           "TILE_WALK", "HERCULES_FRACT", "HERCULES_NOPAIRS", "DEBUG", nullptr};
+                                           "TILE_WALK", "TILE_WINDOW", "HERCULES_FRACT", "HERCULES_NOPAIRS", "DEBUG", nullptr};
 const char *const *hook_names() { return g_hook_names; }
 
 static bool apply_hook(Hooks &h, const char *name, const char *value)
@@ -54,6 +54,7 @@ static bool apply_hook(Hooks &h, const char *name, const char *value)
 	else if (!std::strcmp(name, "STAGED_WALK"))      h.staged_walk_column = on && value[0] == 'c';
 	else if (!std::strcmp(name, "STAGED_TABLE_CAP")) h.staged_table_cap = on ? std::strtoull(value, nullptr, 0) : (2ull << 30);
 	else if (!std::strcmp(name, "TILE_WALK"))        h.tile_walk = on ? value[0] : 0;
+	else if (!std::strcmp(name, "TILE_WINDOW"))      h.tile_window = on ? std::atoi(value) : 0;
 	else if (!std::strcmp(name, "HERCULES_FRACT"))   h.hercules_fract = on;
 	else if (!std::strcmp(name, "HERCULES_NOPAIRS")) h.hercules_nopairs = on;
 	else if (!std::strcmp(name, "DEBUG"))            h.debug = on;
@@ -180,6 +181,80 @@ static float tile_spread_estimate(const BfDasArgs &a, const std::vector<BfTransm
 		spread += (receive + transmit) * samples_per_metre * (float)((1u << shift[k]) - 1u);
 	}
 	return spread;
+}
+
+/* das_tile.hip: the spread the kernel itself would measure -- (floor max R_c - floor min R_c over the voxels inside channel c's aperture) +
+ * max over the transmits of (floor max T_a - floor min T_a) -- evaluated in double precision over a 5 x 5 x 2 lattice of voxels (the
+ * corners among them) of up to 27 tiles: first, middle and last along every axis, where the extremes of an image lie.  Sharper than
+ * tile_spread_estimate's derivative bound (config 2: 24 against 27.9), not an upper bound (lattice, sampled tiles): the kernel still
+ * decides per block and chunk, and a chunk that does not fit runs its gather loop.  Returns the largest such sum (+ 1 for the lattice). */
+static float tile_spread_sampled(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const ParameterBlock &pb, const float *voxel_to_world,
+                                 const uint32_t ext[3], const uint32_t shift[3], uint32_t zfirst)
+{
+	if (tx.empty() && a.family == BF_DAS_RCA) return 0.f;
+	const double fs_over_c = (double)a.sampling_frequency * (double)a.inv_speed_of_sound;
+	const int C = a.channel_count, A = a.acquisition_count;
+	const int first_transmit = a.family == BF_DAS_RCA ? 0 : (a.sparse != 0);
+	const bool rx_rows = a.family == BF_DAS_RCA && (tx[0].flags & BF_RX_ROWS);
+	auto point = [](const float *m, double x, double y, double z, double o[3]) {
+		for (int r = 0; r < 3; r++) o[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r];
+	};
+	uint32_t tiles[3][3], tile_count[3];
+	for (int k = 0; k < 3; k++) {
+		const uint32_t n = (ext[k] + (1u << shift[k]) - 1) >> shift[k];
+		tiles[k][0] = 0; tiles[k][1] = n / 2; tiles[k][2] = n - 1;
+		tile_count[k] = n >= 3 ? 3 : n == 2 ? 2 : 1;
+		if (n == 2) tiles[k][1] = 1;
+	}
+	double worst = 0;
+	std::vector<double> rlo((size_t)C), rhi((size_t)C), tlo((size_t)A), thi((size_t)A);
+	for (uint32_t iz = 0; iz < tile_count[2]; iz++) for (uint32_t iy = 0; iy < tile_count[1]; iy++) for (uint32_t ix = 0; ix < tile_count[0]; ix++) {
+		const uint32_t t0[3] = {tiles[0][ix] << shift[0], tiles[1][iy] << shift[1], tiles[2][iz] << shift[2]};
+		std::fill(rlo.begin(), rlo.end(), 1e30); std::fill(rhi.begin(), rhi.end(), -1e30);
+		std::fill(tlo.begin(), tlo.end(), 1e30); std::fill(thi.begin(), thi.end(), -1e30);
+		for (int sz = 0; sz < 2; sz++) for (int sy = 0; sy < 5; sy++) for (int sx = 0; sx < 5; sx++) {
+			uint32_t v[3];
+			const int step[3] = {sx, sy, sz * 4};
+			for (int k = 0; k < 3; k++) {
+				const uint32_t span = (1u << shift[k]) - 1u;
+				v[k] = t0[k] + (uint32_t)((uint64_t)span * (uint32_t)step[k] / 4u);
+				if (v[k] >= ext[k]) v[k] = ext[k] - 1;                       /* ragged tiles: threads outside the grid repeat its last voxel */
+			}
+			const double px = (double)v[0] / std::fmax(1.0, (double)a.size[0] - 1.0), py = (double)v[1] / std::fmax(1.0, (double)a.size[1] - 1.0);
+			const double pz = (double)(v[2] + zfirst) / std::fmax(1.0, (double)a.size[2] - 1.0);
+			double w[3], x[3];
+			point(voxel_to_world, px, py, pz, w);
+			if (a.family == BF_DAS_RCA) point(a.xdc_transform, w[0], w[1], w[2], x); else { x[0] = w[0]; x[1] = w[1]; x[2] = w[2]; }
+			const double lateral = rx_rows ? x[1] : x[0], pitch = rx_rows ? a.pitch[1] : a.pitch[0];
+			for (int c = 0; c < C; c++) {
+				const double dx = lateral - c * pitch;
+				if (!(std::fabs(dx * a.f_number / std::fabs(x[2])) < 0.5)) continue;
+				const double r = std::sqrt(dx * dx + x[2] * x[2]) * fs_over_c;
+				rlo[(size_t)c] = std::fmin(rlo[(size_t)c], r); rhi[(size_t)c] = std::fmax(rhi[(size_t)c], r);
+			}
+			for (int t = first_transmit; t < A; t++) {
+				double d = 0;
+				if (a.family == BF_DAS_RCA) {
+					const BfTransmit &q = tx[(size_t)t];
+					if (!(q.flags & BF_TX_NONE)) {
+						const double p = (q.flags & BF_TX_ROWS) ? w[1] : w[0];
+						d = (q.flags & BF_TX_PLANE) ? p * q.sin_a + w[2] * q.cos_a : std::sqrt((p - q.focus_x) * (p - q.focus_x) + (w[2] - q.focus_z) * (w[2] - q.focus_z));
+					}
+				} else {
+					const double element = a.sparse ? (double)pb.sparse_elements[t - first_transmit] : (double)t;
+					const double dy = x[1] - a.pitch[1] * C * 0.5, tdx = x[0] - a.pitch[0] * element;
+					d = std::sqrt(dy * dy + x[2] * x[2] + tdx * tdx);
+				}
+				d *= fs_over_c;
+				tlo[(size_t)t] = std::fmin(tlo[(size_t)t], d); thi[(size_t)t] = std::fmax(thi[(size_t)t], d);
+			}
+		}
+		double ts = 0, rs = 0;
+		for (int t = first_transmit; t < A; t++) ts = std::fmax(ts, std::floor(thi[(size_t)t]) - std::floor(tlo[(size_t)t]));
+		for (int c = 0; c < C; c++) if (rlo[(size_t)c] <= rhi[(size_t)c]) rs = std::fmax(rs, std::floor(rhi[(size_t)c]) - std::floor(rlo[(size_t)c]));
+		worst = std::fmax(worst, rs + ts);
+	}
+	return (float)(worst + 1.0);
 }
 
 /* Can this RCA frame use the separable-delay fast path (das_separable.hip)?  Needs one
@@ -672,7 +747,15 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 			}
 			for (int k = 0; k < 3 && left; k++) { uint32_t room = ceil_log2(ext[k]) - shift[k]; uint32_t give = room < left ? room : left; shift[k] += give; left -= give; }
 			/* (left > 0: a frame -- or a device's slab of it -- that does not even span one 1024-voxel tile) */
-			const float spread = tile_spread_estimate(a, tx, to_xdc, plan.das_voxel_transform, shift);
+			/* the derivative bound first (cheap, a true upper bound); where it does not already say "32 samples", what the kernel would measure
+			 * on the image's extreme tiles */
+			float spread = tile_spread_estimate(a, tx, to_xdc, plan.das_voxel_transform, shift);
+			if (left == 0 && spread == spread && spread > 26.f && spread < 400.f) {
+				const float sampled = tile_spread_sampled(a, tx, pb, plan.das_voxel_transform, ext, shift, zfirst);
+				if (sampled == sampled && sampled < spread) spread = sampled;
+			}
+			out.tile_spread = left == 0 ? spread : 0.f;
+			for (int k = 0; k < 3; k++) out.tile_estimate_shift[k] = shift[k];
 			/* frames small enough for the channel split (under 4096 voxel waves): one block per CU, so the block-staged kernel is
 			 * only worth it from about three quarters of the CUs (config 2 onto 448 x 448: 196 blocks, 0.66 ms against the split
 			 * kernel's 0.82; onto 384 x 384 the split kernel wins: profiles/r03_tile_threshold.json) */
@@ -686,6 +769,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 				for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 				a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
 				a.tile_window_shift = spread <= 26.f ? 5u : 6u;
+				if (hooks().tile_window == 32 || hooks().tile_window == 64) a.tile_window_shift = hooks().tile_window == 32 ? 5u : 6u;
 				out.path = DasPath_Tile;
 				why[DasPath_Factored] = "superseded by its block-staged form (das_tile.hip)";
 				why[DasPath_General] = "a specialised kernel applies";

@@ -39,6 +39,7 @@ struct Hooks {
 	bool        staged_walk_column = false;    /* STAGED_WALK=column: plain depth-major walk for the wave-uniform form */
 	uint64_t    staged_table_cap = 2ull << 30; /* STAGED_TABLE_CAP=bytes: largest global transmit table taken (test: 0 forces the fallback) */
 	char        tile_walk = 0;                 /* TILE_WALK=plane / column: 'p' x, y, z; 'c' view planes walked depth fastest */
+	int         tile_window = 0;               /* TILE_WINDOW=32 / 64: das_tile.hip with that window whatever the estimated spread (measurement aid) */
 	bool        hercules_fract = false;        /* HERCULES_FRACT: v_fract per pair instead of the per-lane phase reduction */
 	bool        hercules_nopairs = false;      /* HERCULES_NOPAIRS: never read the prepared copy of the DAS input */
 	bool        debug = false;                 /* DEBUG: one line per staged plan on stderr */
@@ -52,6 +53,8 @@ struct DasDecision {
 	uint64_t generation = 0, hooks_version = 0;              /* what it was computed for */
 	uint32_t z_first = 0, z_count = 0, mode = 0;
 	BfDasArgs a{};                      /* everything but the device pointers */
+	float     tile_spread = 0.f;         /* das_tile.hip: the estimated spread of a tile of 2^tile_estimate_shift voxels (0: not a factored-kernel frame) */
+	uint32_t  tile_estimate_shift[3] = {0, 0, 0};
 	BfDasArgs general{};                /* the same with the general kernel's tile geometry (no channel split): what the pair count runs with */
 	int      path = DasPath_General;
 	int      depth_axis = 2;

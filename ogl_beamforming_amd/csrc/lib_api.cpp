@@ -605,6 +605,8 @@ uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDe
 		out->uniform_tables = d.sep.uniform; out->lds_bytes = d.sep.lds_bytes; out->threads = d.sep.threads; out->channel_chunk = d.sep.channel_chunk;
 	}
 	out->hercules_prepared_copy = d.hercules_prepared;
+	out->tile_spread_estimate = d.tile_spread;
+	for (int k = 0; k < 3; k++) out->tile_estimate_shift[k] = d.tile_estimate_shift[k];
 	return 1;
 }
 

@@ -148,6 +148,10 @@ def _cases():
     # config 2's class): a 25 um x 69 um view-plane grid, ragged in both directions (160 = 2.5 tiles of 64, 48 = 3 of 16) ...
     c["tile_tpw"] = lambda: cfg.rca("tile_tpw", 24, 9, 768, (160, 48, 1), (-2.0e-3, 0, 6.0e-3), (2.0e-3, 0, 9.3e-3), seed=71,
                                     interp=I.Cubic, orientation=0x22, f_number=1.0, pitch=0.2e-3, angles=np.linspace(-10, 10, 9))
+    # ... the same over twice the depth range: a 64 x 16 tile's delays spread over about 50 samples (64-sample windows, 8 transmits a group;
+    # tile_tpw's 25 fit the 32-sample window) ...
+    c["tile_tpw_w64"] = lambda: cfg.rca("tile_tpw_w64", 24, 9, 768, (160, 48, 1), (-2.0e-3, 0, 6.0e-3), (2.0e-3, 0, 13.0e-3), seed=79,
+                                        interp=I.Cubic, orientation=0x22, f_number=1.0, pitch=0.2e-3, angles=np.linspace(-10, 10, 9))
     # ... coherency weighting over rows that end inside the image (index 396 at the deepest voxels, 384 samples: the range-checked
     # loop, zeros past the end), 7 transmits (a ragged group of 8), 18 channels (a ragged chunk of 4) ...
     c["tile_tpw_cw_short"] = lambda: cfg.rca("tile_tpw_cw_short", 18, 7, 384, (96, 40, 1), (-1.2e-3, 0, 9.5e-3), (1.2e-3, 0, 12.2e-3),

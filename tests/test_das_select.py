@@ -50,7 +50,7 @@ def test_forced_paths_and_reasons():
 
 def test_block_staged_kernel_selection():
     """das_tile.hip (path 6): automatic for BASELINE config 2 at full size (fine grid, cubic IQ, tx and rx on one axis: 64 x 16 tiles,
-    64-sample windows, the banded plane walk), declined with its reason on small frames (channel split), under flag 0x200, for other
+    32-sample windows -- the derivative bound says 27.9 samples, the spread sampled on the image's extreme tiles 26 --, the banded plane walk), declined with its reason on small frames (channel split), under flag 0x200, for other
     sample kinds; flag 0x100 asks for it wherever the kernel is able to run, with the 32-sample window on very fine grids."""
     L = lib.library()
     try:
@@ -58,7 +58,8 @@ def test_block_staged_kernel_selection():
         full = cfg.config(2)
         path, kernel, _, reasons, d = lib.describe_das(full.bp, full.filters)
         assert (path, kernel) == (6, "das_tile_kernel") and "block-staged" in reasons[3]
-        assert list(d.tile_shift) == [6, 4, 0] and list(d.blocks) == [16, 64, 1] and d.tile_window_samples == 64 and d.tile_walk == 3
+        assert list(d.tile_shift) == [6, 4, 0] and list(d.blocks) == [16, 64, 1] and d.tile_window_samples == 32 and d.tile_walk == 3
+        assert 20.0 <= d.tile_spread_estimate <= 26.0 and list(d.tile_estimate_shift) == [6, 4, 0]
         L.beamformer_hip_set_das_path(0x200)
         path, _, _, reasons, d = lib.describe_das(full.bp, full.filters)
         assert path == 3 and "0x200" in reasons[6] and d.tile_window_samples == 0

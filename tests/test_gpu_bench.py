@@ -47,7 +47,7 @@ def test_config2_line_names_the_block_staged_kernel():
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     roof = d["roofline"]
-    assert d["config"]["das_plan"]["kernel"] == roof["kernel"] == "das_tile_kernel" and d["config"]["das_plan"]["tile_window_samples"] == 64
+    assert d["config"]["das_plan"]["kernel"] == roof["kernel"] == "das_tile_kernel" and d["config"]["das_plan"]["tile_window_samples"] == 32
     assert roof["bound"] == "valu-issue"
     b = roof["binding"]
     assert 0.3 < b["frac"] < 1.0 and b["lds_read_path"]["cycles_per_term_per_cu"] == 16.0 and 0.2 < b["lds_read_path"]["frac"] < 1.0

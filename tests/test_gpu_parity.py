@@ -427,9 +427,9 @@ TILE = tile_candidates()
 
 # what the block does with its (block, chunk of four channels) pairs -- staged windows, or the kernel's own gather loop where the
 # spread of the chunk does not fit the window (BeamformerHipFrameTimings::tile_staged_chunks / tile_gather_chunks)
-TILE_STAGED_ONLY = {"tile_tpw", "tile_tpw_cw_short", "tile_vls", "tile_w32", "tile_forces", "tile_uforces_cw", "tile_thin_volume"}
+TILE_STAGED_ONLY = {"tile_tpw", "tile_tpw_w64", "tile_tpw_cw_short", "tile_vls", "tile_w32", "tile_forces", "tile_uforces_cw", "tile_thin_volume"}
 TILE_BOTH        = {"tile_near_field"}
-TILE_WINDOW      = {"tile_w32": 32, "tile_tpw": 64}
+TILE_WINDOW      = {"tile_w32": 32, "tile_tpw": 32, "tile_tpw_w64": 64, "tile_near_field": 64}
 
 
 def test_block_staging_candidates():
