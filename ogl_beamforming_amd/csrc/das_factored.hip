@@ -47,6 +47,11 @@
  * 2 -> 172 ms, 4 -> 160, 6 -> 154, 8 -> 154 with spills; cubic holds twice the gather data
  * per triple and is best at 4 (108 VGPRs). */
 #ifndef BF_FACTORED_CHUNK
+/* Every gather of a transmit's CH terms is issued before the first of them is consumed.  hipcc's scheduler otherwise decides by
+ * itself whether to interleave (load, load, wait, arithmetic, load ...) or to batch, and flips with changes as remote as the order
+ * of BfDasArgs' fields: on the harness's coarse grid, where a gather misses L1 more often than not, the batched form measured
+ * 15.8 ms against the interleaved one's 18.9 on the same frame (profiles/r03_harness.json, round 3) -- so it is pinned. */
+#define BF_ALL_GATHERS_ISSUED() __builtin_amdgcn_sched_barrier(0)
 #define BF_FACTORED_CHUNK(interp) ((interp) == BF_INTERP_LINEAR ? 6 : 4)
 #endif
 /* ... and per chunk of the wave-span variant (its loop waits for LDS-DMA and LDS reads, not for gathers: occupancy counts) */
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						f32x4 d[CH];
 						#pragma unroll
 						for (int k = 0; k < CH; k++) d[k] = gather<f32x4_a8>(rf, off[k]);
+						BF_ALL_GATHERS_ISSUED();
 						#pragma unroll
 						for (int k = 0; k < CH; k++) {
 							f32x2 s0 = {d[k].x, d[k].y}, s1 = {d[k].z, d[k].w};
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						f32x4 d0[CH], d1[CH];
 						#pragma unroll
 						for (int k = 0; k < CH; k++) { d0[k] = gather<f32x4_a8>(rf, off[k]); d1[k] = gather<f32x4_a8>(rf, off[k] + 16); }
+						BF_ALL_GATHERS_ISSUED();
 						#pragma unroll
 						for (int k = 0; k < CH; k++) {
 							/* Catmull-Rom Hermite (das.glsl:67-97) as a cubic in t by Horner:

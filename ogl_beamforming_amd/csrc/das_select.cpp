@@ -781,13 +781,14 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 			                  : (mode & 0x200) ? "das path flag 0x200: no block staging"
 			                  : "coarse grid or steep delays: a 64 x 16-voxel tile's estimated spread exceeds a 64-sample window";
 		}
-		/* wave-span staging (das_factored.hip): on COARSE grids -- a voxel step along x of a sample of delay or more, as the
-		 * reference harness's 0.23 mm pixels have (tests/throughput.c:20-23) -- the lanes of a gather land in 64 different
-		 * places and the per-wave LDS-DMA copy of the span is cheaper (harness frames: 0.90-0.93 of the gather loop's time;
-		 * on config 2's fine grid 1.13: not taken there).  das path bit 0x40 forces it wherever the kernel supports it, 0x80
-		 * keeps the gather loop (tests: the two frames are bit-identical). */
+		/* wave-span staging (das_factored.hip): per-wave LDS-DMA copies of the RF span a wave touches, built for COARSE grids -- a voxel step
+		 * along x of a sample of delay or more, as the reference harness's 0.23 mm pixels have (tests/throughput.c:20-23).  It measured
+		 * 0.90-0.93 of the gather loop's time there while hipcc interleaved that loop's gathers with their arithmetic; with all gathers of a
+		 * transmit issued before the first is consumed (BF_ALL_GATHERS_ISSUED, pinned since) the gather loop is the faster one on every harness
+		 * frame (15.7-16.8 ms against 17.3-20.1: profiles/r03_harness.json), so span staging runs on request only: das path bit 0x40 wherever
+		 * the kernel supports it (tests: its frames are bit-identical to the gather loop's), 0x80 never. */
 		const bool span_ok = plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && out.das_input_bytes < (1ull << 32);
-		if (span_ok && !(mode & 0x80) && ((mode & 0x40) || lane_step_samples(to_xdc, a) >= 1.0f)) {
+		if (span_ok && !(mode & 0x80) && (mode & 0x40)) {
 			a.span_stage = 1;
 			/* a wave = 64 voxels along the first lateral axis, the block's four waves stacked along depth */
 			uint32_t lat = a.tile_shift[0] >= a.tile_shift[1] ? 0u : 1u;

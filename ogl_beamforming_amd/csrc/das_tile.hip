@@ -502,6 +502,7 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 					f32x4 d0[4], d1[4];
 					#pragma unroll
 					for (int j = 0; j < 4; j++) { d0[j] = gather<f32x4_a8>(rf, off[j]); d1[j] = gather<f32x4_a8>(rf, off[j] + 16); }
+					__builtin_amdgcn_sched_barrier(0);                            /* all eight issued before the first is consumed (das_factored.hip) */
 					#pragma unroll
 					for (int j = 0; j < 4; j++) {
 						f32x2 s0 = {d0[j].x, d0[j].y}, s1 = {d0[j].z, d0[j].w}, s2 = {d1[j].x, d1[j].y}, s3 = {d1[j].z, d1[j].w};

@@ -404,12 +404,13 @@ def test_config5_rows_at_the_edges_of_the_volume(bflib, oracle):
 def test_reference_harness_frame_at_full_size(kind, path, span, bflib, oracle):
     """The frame the reference's own throughput harness beamforms (tests/throughput.c:20-23, :443-491): 256 channels x 128
     transmits x 4096 samples -> the 512 x 1024 XZ view plane, cubic, F# 0.5, {Demodulate, Decode, DAS}.  The automatic path
-    (factored kernel with wave-span staging on this coarse grid; HERCULES: the aligned-grid kernel reading raw taps) against
-    oracle rows at the first, a middle and the last depths, and -- RCA / FORCES -- bit-for-bit against the gather loop."""
+    (factored kernel, gather loop with all gathers of a transmit issued together; HERCULES: the aligned-grid kernel reading raw taps)
+    against oracle rows at the first, a middle and the last depths, and -- RCA / FORCES -- bit-for-bit against the same kernel with
+    wave-span staging (flag 0x40: automatic until the gather loop's schedule was pinned, on request since)."""
     from tests import cases
     acq = cfg.harness(kind)
     p, kernel, _, reasons, d = bflib.describe_das(acq.bp, acq.filters)
-    assert p == path and int(d.span_stage) == span, (kernel, reasons)
+    assert p == path and int(d.span_stage) == 0, (kernel, reasons)
     if kind == "hercules":
         assert int(d.hercules_prepared_copy) == 0
     frame = run(bflib, acq)
@@ -426,5 +427,10 @@ def test_reference_harness_frame_at_full_size(kind, path, span, bflib, oracle):
     assert delta / peak <= cases.tolerance(acq), delta / peak
     assert delta / np.abs(ref[ok]).max() <= 4 * cases.tolerance(acq), delta / np.abs(ref[ok]).max()
     if span:
-        gather = run(bflib, acq, path=0x80)
-        assert np.array_equal(gather.view(np.uint32), frame.view(np.uint32)), "wave-span staging and the gather loop differ"
+        bflib.library().beamformer_hip_set_das_path(0x40)
+        try:
+            assert int(bflib.describe_das(acq.bp, acq.filters)[4].span_stage) == 1
+        finally:
+            bflib.library().beamformer_hip_set_das_path(0)
+        staged = run(bflib, acq, path=0x40)
+        assert np.array_equal(staged.view(np.uint32), frame.view(np.uint32)), "wave-span staging and the gather loop differ"
