@@ -41,7 +41,7 @@ for k in tpw tpw_swapped vls hercules forces; do
   timeout -k 10 200 python bench.py --config harness:$k --das-path 1 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_harness_${k}_general.json 2> /dev/null
 done
 for k in tpw forces; do
-  timeout -k 10 200 python bench.py --config harness:$k --das-path 128 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_harness_${k}_gather_loop.json 2> /dev/null
+  timeout -k 10 200 python bench.py --config harness:$k --das-path 64 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_harness_${k}_span_staging.json 2> /dev/null
 done
 PYTHONPATH=. timeout -k 10 300 python tools/tile_threshold.py --json $OUT/profiles/${R}_tile_threshold.json > $OUT/tile_threshold.log 2>&1
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
@@ -68,7 +68,7 @@ for k in ("tpw", "tpw_swapped", "vls", "hercules", "forces"):
     try: e["general_kernel_das_path_1"] = brief(line(f"gpurun_out/r03/bench_harness_{k}_general.json"))
     except Exception as x: e["general_kernel_das_path_1"] = str(x)[:100]
     if k in ("tpw", "forces"):
-        e["factored_kernel_gather_loop_das_path_0x80"] = brief(line(f"gpurun_out/r03/bench_harness_{k}_gather_loop.json"))
+        e["factored_kernel_wave_span_staging_das_path_0x40"] = brief(line(f"gpurun_out/r03/bench_harness_{k}_span_staging.json"))
     h[f"harness:{k}"] = e
 json.dump(h, open("gpurun_out/r03/profiles/r03_harness.json", "w"), indent=1)
 PY
