@@ -205,9 +205,9 @@ typedef enum {
 	BeamformerHipDasPath_NoChannelSplit   = 0x10, /* flag: general kernel at one thread per voxel for small frames too */
 	BeamformerHipDasPath_DenseDecode      = 0x20, /* flag: Decode on the O(T^2) kernel, not the Walsh-Hadamard form */
 	BeamformerHipDasPath_SpanStaging      = 0x40, /* flag: das_factored.hip's wave-span staging (per-wave LDS-DMA copy of the RF span a wave touches)
-	                                                 wherever the kernel supports it -- automatic only on coarse grids (a voxel step along x of a
-	                                                 sample of delay or more, like the reference harness's view plane) */
-	BeamformerHipDasPath_NoSpanStaging    = 0x80, /* flag: never (the gather loop; the two give bit-identical frames) */
+	                                                 wherever the kernel supports it.  Never automatic: the gather loop with all gathers of a
+	                                                 transmit issued together is faster on every frame measured */
+	BeamformerHipDasPath_NoSpanStaging    = 0x80, /* flag: never (the gather loop: the default; the two give bit-identical frames) */
 	BeamformerHipDasPath_TileStaging      = 0x100,/* flag: das_tile.hip (factored kernel, block-wide LDS staging of cubic polynomials) wherever it is supported --
 	                                                 automatic on fine grids only */
 	BeamformerHipDasPath_NoTileStaging    = 0x200,/* flag: never */
