@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	static_assert(!PD || (CPLX && INTERP != BF_INTERP_NEAREST), "prepared data: linear or cubic interpolation of complex samples");
 	constexpr bool POLY = PD && INTERP == BF_INTERP_CUBIC;       /* q.pairs holds the cubic segment polynomials (hercules_cubic_kernel) */
 	constexpr uint32_t ES = POLY ? 32 : PD ? 16 : CPLX ? 8 : 4;
+	/* cubic interpolation of IQ samples out of the RF itself (coarse grids, where the prepared polynomial copy costs more in memory traffic
+	 * than it saves -- the reference harness's view plane): index arithmetic as for the prepared forms, Catmull-Rom as a Horner cubic
+	 * (das_factored.hip: 12 packed operations) instead of four Hermite weights per pair */
+	constexpr bool RAWC = !PD && CPLX && INTERP == BF_INTERP_CUBIC;
 	using VT = sample_t<CPLX>;
 
 	/* blockIdx -> tile with each XCD walking a contiguous run of tiles (das.hip) */
@@ -312,13 +316,14 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				ap[k]     = (k & 1) ? apod[k >> 1].y : apod[k >> 1].x;
 				if (k == 0) ap[k] *= first_weight;
 				uint32_t row = row0 + (uint32_t)(n + k) * inner_stride;
-				if constexpr (INTERP == BF_INTERP_LINEAR || POLY) {
+				if constexpr (INTERP == BF_INTERP_LINEAR || POLY || RAWC) {
 					frac[k] = hw_fract(idx);
 					uint32_t ki = (uint32_t)cvt_floor_i32(idx);
-					off[k] = CHECK ? row + ki * ES : ki * ES;
+					const uint32_t first = RAWC ? ki - 1u : ki;              /* raw cubic taps start one sample early */
+					off[k] = CHECK ? row + first * ES : first * ES;
 					if constexpr (CHECK) {
 						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124) */
-						bool ok = (POLY ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test);
+						bool ok = ((POLY || RAWC) ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test);
 						off[k] = ok ? off[k] : q.zero_offset;
 						ap[k]  = ok ? ap[k] : 0.f;
 					}
@@ -335,6 +340,10 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					const char *rowp = CHECK ? rf : rf + (row0 + (uint32_t)(n + k) * inner_stride);
 					d[k].a = gather<f32x4>(rowp, off[k]);
 					d[k].b = gather<f32x4>(rowp, off[k] + 16u);
+				} else if constexpr (RAWC) {
+					const char *rowp = CHECK ? rf : rf + (row0 + (uint32_t)(n + k) * inner_stride);
+					d[k].a = gather<f32x4_a8>(rowp, off[k]);
+					d[k].b = gather<f32x4_a8>(rowp, off[k] + 16u);
 				} else if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
 					/* the row (wave uniform) rides in the load's scalar base and the lane offset is one full-rate shift: a
 					 * three-operand v_lshl_add_u32 is a half-rate instruction (tools/microbench.hip) */
@@ -352,6 +361,14 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					sv = f32x2{d[k].b.z, d[k].b.w} * t + f32x2{d[k].b.x, d[k].b.y};
 					sv = sv * t + f32x2{d[k].a.z, d[k].a.w};
 					sv = sv * t + f32x2{d[k].a.x, d[k].a.y};
+				} else if constexpr (RAWC) {
+					/* p = s1 + t (T1 + t (c2 + t c3)),  T1 = (s2 - s0) / 2, T2 = (s3 - s1) / 2, c3 = T1 + T2 - 2 (s2 - s1), c2 = (s2 - s1) - T1 - c3 */
+					const f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}, s2 = {d[k].b.x, d[k].b.y}, s3 = {d[k].b.z, d[k].b.w};
+					const f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
+					const f32x2 c3 = (T1 + T2) - 2.0f * D;
+					const f32x2 c2 = (D - T1) - c3;
+					const float t = frac[k];
+					sv = s1 + t * (T1 + t * (c2 + t * c3));
 				} else if constexpr (INTERP == BF_INTERP_LINEAR) {
 					if constexpr (PD)        { f32x2 s0 = {d[k].a.x, d[k].a.y}, ds = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * ds; }
 					else if constexpr (CPLX) { f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * (s1 - s0); }
