@@ -392,7 +392,7 @@ def main():
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
                          "compulsory HBM traffic is ~1e4x smaller (BASELINE.md section 4)",
-                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s, pairs_local),
+                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s, pairs_local, das_plan),
             },
         }
         if not args.no_cpu_baseline and n_gpus == 1:
@@ -437,7 +437,7 @@ def measured_traffic(config, kernel):
                                           f"`{entry.get('command', 'bench.py')}`, kernel sources {entry.get('kernel_source_sha16')}")
 
 
-def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, terms):
+def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, terms, das_plan=None):
     """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
         to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
@@ -466,6 +466,10 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_pair_per_simd": per_pair,
                 "source": f"profiles/{micro_name} hercules_stream (tools/microbench.hip hercules_probe); achieved measured in this run",
             }
+            if cubic and das_plan is not None and not das_plan.get("hercules_prepared_copy"):
+                out["stream_note"] = ("the probe's cubic stream evaluates the PREPARED segment polynomial (three packed fmas per pair); this frame is on a coarse grid, gathers the "
+                                      "four raw taps with two gather instructions per pair and builds the Catmull-Rom cubic per pair (nine more packed operations), and a share "
+                                      "of the executed pairs fails the f-number test: `frac` is measured against a lighter stream than the one that ran and counts passing pairs only")
         elif kernel == "das_tile_kernel":
             # VALU issue, priced against the kernel's own instruction stream as the committed PMC pass counted it (SQ_ACTIVE_INST_VALU: the
             # cycles a SIMD spent issuing the kernel's VALU instructions, per executed wave64 term), and next to it the LDS read path: two
