@@ -220,6 +220,7 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
  *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major (=column: view planes walked depth
  *                                    fastest instead of in XCD-balanced bands)
  *   BEAMFORMER_HIP_TILE_WINDOW=32    das_tile.hip with the 32- (or =64: 64-) sample window whatever the estimated spread: chunks that do not fit run its gather loop
+ *   BEAMFORMER_HIP_SPLIT_TARGET=waves  the channel split of the per-voxel kernels aims at this many waves per launch (default 4096)
  *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
  *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernels' range-checked loop for every wave; it also counts window violations
  *                                    (BeamformerHipFrameTimings::staged_window_violations)

@@ -37,7 +37,7 @@ const char *das_kernel_name(int path)
 
 static Hooks g_hooks;
 static const char *const g_hook_names[] = {"STAGED_SHAPE", "STAGED_CHECKED", "STAGED_NOUNIFORM", "STAGED_W48", "STAGED_WALK", "STAGED_TABLE_CAP",
-                                           "TILE_WALK", "TILE_WINDOW", "HERCULES_FRACT", "HERCULES_NOPAIRS", "DEBUG", nullptr};
+                                           "TILE_WALK", "TILE_WINDOW", "SPLIT_TARGET", "HERCULES_FRACT", "HERCULES_NOPAIRS", "DEBUG", nullptr};
 const char *const *hook_names() { return g_hook_names; }
 
 static bool apply_hook(Hooks &h, const char *name, const char *value)
@@ -55,6 +55,7 @@ static bool apply_hook(Hooks &h, const char *name, const char *value)
 	else if (!std::strcmp(name, "STAGED_TABLE_CAP")) h.staged_table_cap = on ? std::strtoull(value, nullptr, 0) : (2ull << 30);
 	else if (!std::strcmp(name, "TILE_WALK"))        h.tile_walk = on ? value[0] : 0;
 	else if (!std::strcmp(name, "TILE_WINDOW"))      h.tile_window = on ? std::atoi(value) : 0;
+	else if (!std::strcmp(name, "SPLIT_TARGET"))     h.split_target = on ? std::strtoull(value, nullptr, 0) : 0;
 	else if (!std::strcmp(name, "HERCULES_FRACT"))   h.hercules_fract = on;
 	else if (!std::strcmp(name, "HERCULES_NOPAIRS")) h.hercules_nopairs = on;
 	else if (!std::strcmp(name, "DEBUG"))            h.debug = on;
@@ -627,7 +628,8 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	 * frame by target wave count: 2048 -> 19.9, 4096 -> 15.2, 8192 -> 15.1, 16384 -> 17.1). */
 	const uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
 	a.split_shift = 0;
-	while (!(mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < 4096 && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
+	const uint64_t split_target = hooks().split_target ? hooks().split_target : 4096;
+	while (!(mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < split_target && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
 	out.depth_axis = choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
 	for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 	a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);

@@ -40,6 +40,7 @@ struct Hooks {
 	uint64_t    staged_table_cap = 2ull << 30; /* STAGED_TABLE_CAP=bytes: largest global transmit table taken (test: 0 forces the fallback) */
 	char        tile_walk = 0;                 /* TILE_WALK=plane / column: 'p' x, y, z; 'c' view planes walked depth fastest */
 	int         tile_window = 0;               /* TILE_WINDOW=32 / 64: das_tile.hip with that window whatever the estimated spread (measurement aid) */
+	uint64_t    split_target = 0;              /* SPLIT_TARGET=waves: split the channel loop over the waves of a block until the launch has this many (default 4096) */
 	bool        hercules_fract = false;        /* HERCULES_FRACT: v_fract per pair instead of the per-lane phase reduction */
 	bool        hercules_nopairs = false;      /* HERCULES_NOPAIRS: never read the prepared copy of the DAS input */
 	bool        debug = false;                 /* DEBUG: one line per staged plan on stderr */
