@@ -23,8 +23,8 @@ const char *das_path_name(int path);      /* "LDS-staged kernel", ... */
 const char *das_kernel_name(int path);    /* "das_rca_staged_kernel", ... */
 
 constexpr uint32_t kStagedMinTransmits = 6;      /* das_staged.hip by default from this many transmits per channel (tools/staged_threshold.py,
-                                                    profiles/r02_staged_threshold.json: 1.15 of the gather kernel's time at 4 transmits, 0.91 at 8,
-                                                    0.84 at 12, 0.75 at 16, 0.69-0.71 at 32-75) */
+                                                    profiles/r03_staged_threshold.json: 1.29 of the gather kernel's time at 4 transmits, 1.01 at 6,
+                                                    1.0 at 8, 0.88 at 12, 0.75 at 16, 0.69-0.71 at 32-75; round 2's pass: 1.15, -, 0.91, 0.84, 0.75) */
 
 /* Test and measurement hooks (none is needed in production).  Read from the environment (BEAMFORMER_HIP_<NAME>) when first
  * needed and never again; beamformer_hip_set_hook changes one at run time.  `version` counts changes: cached decisions carry it. */

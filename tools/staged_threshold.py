@@ -13,7 +13,7 @@ import torch
 from ogl_beamforming_amd import configs, lib, params as P
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--transmits", default="4,8,12,16,24,32,48,75,128")
+ap.add_argument("--transmits", default="4,6,8,12,16,24,32,48,75,128")
 ap.add_argument("--planes", type=int, default=16)
 ap.add_argument("--json", default="")
 ap.add_argument("--cubic", action="store_true", help="cubic interpolation of IQ samples: das_staged_cubic.hip against the factored kernel (what path 2 runs for cubic)")
