@@ -75,20 +75,80 @@ def parse():
     ap.add_argument("--interpolation", choices=["nearest", "linear", "cubic"], default=None,
                     help="override the configuration's interpolation mode (config 5 with cubic = the reference harness's own setting)")
     ap.add_argument("--planes", type=int, default=0, help="profiling aid: beamform only this many centre z-planes (value is then NOT the metric)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.gpus_given = any(a == "--gpus" or a.startswith("--gpus=") for a in sys.argv[1:])
+    return args
+
+
+def resolve_gpus(args, environ, visible_devices):
+    """What `--gpus N` means in this invocation -- decided BEFORE anything touches the GPU (a process that has initialised HIP must not be
+    replaced, and a scaling harness that quietly ran on one GPU wastes the lease).  Returns (mode, n_gpus, ordinals):
+      "single"      this process, one GPU;
+      "in-process"  this process, N devices through beamformer_hip_set_devices (`--in-process`);
+      "rank"        this process is one of N ranks started by torch.distributed.run (WORLD_SIZE must equal --gpus);
+      "spawn"       `--gpus N > 1` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+                    and relay its JSON line and exit code.
+    Raises SystemExit with a message instead of ever reporting fewer GPUs than asked for."""
+    world = int(environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}: at least one GPU")
+    if world:
+        if args.in_process:
+            raise SystemExit("bench.py: --in-process inside a torch.distributed.run launch: one or the other")
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line for the wrong GPU count")
+        if not args.rehearse_on_one_gpu and visible_devices < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {visible_devices} GPU(s) visible (one process per GPU)")
+        return ("rank" if world > 1 else "single"), world, [int(environ.get("LOCAL_RANK", "0"))]
+    if args.in_process:
+        ordinals = [int(v) for v in args.devices.split(",") if v != ""]
+        if ordinals:
+            if args.gpus_given and len(ordinals) != args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but --devices names {len(ordinals)} ordinal(s)")
+        else:
+            ordinals = list(range(args.gpus))
+        if max(ordinals) >= visible_devices or min(ordinals) < 0:
+            raise SystemExit(f"bench.py: --devices {ordinals}: only {visible_devices} GPU(s) visible")
+        return "in-process", len(ordinals), ordinals
+    if args.devices:
+        raise SystemExit("bench.py: --devices goes with --in-process")
+    if args.gpus == 1:
+        return "single", 1, [0]
+    if args.rehearse_on_one_gpu:
+        if visible_devices < 1:
+            raise SystemExit("bench.py: no GPU visible")
+    elif visible_devices < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {visible_devices} GPU(s) visible: refusing to print a line that says n_gpus {args.gpus}")
+    return "spawn", args.gpus, list(range(args.gpus))
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: one process per GPU under torch.distributed.run, as a child of this
+    (GPU-untouched) process; its stdout -- rank 0's one JSON line -- and its exit code pass through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # torch.cuda.device_count() reads the driver's device list without creating a HIP context (what makes the child launch below legal)
+    mode, n_gpus, ordinals = resolve_gpus(args, os.environ, torch.cuda.device_count())
+    if mode == "spawn":
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    world = n_gpus if mode == "rank" else 1
+    rank = int(os.environ.get("RANK", "0")) if mode == "rank" else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if mode == "rank" else 0
+    distributed = mode == "rank"
     rehearse = args.rehearse_on_one_gpu
-    in_process = args.in_process and not distributed
-    ordinals = [0]
-    if in_process:
-        ordinals = [int(v) for v in args.devices.split(",") if v != ""] or list(range(max(1, args.gpus)))
+    in_process = mode == "in-process"
     if distributed:
         import torch.distributed as dist
         if rehearse:
@@ -102,7 +162,6 @@ def main():
         dist = None
         torch.cuda.set_device(ordinals[0])
     device = torch.device("cuda", local_rank if distributed else ordinals[0])
-    n_gpus = len(ordinals) if in_process else world
 
     from ogl_beamforming_amd import configs, lib, params as P, sharding
     L = lib.library()
@@ -397,6 +456,7 @@ def main():
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(acq, args.cpu_seconds)
+        assert out["n_gpus"] == (args.gpus if (args.gpus_given or not in_process) else len(ordinals)), (out["n_gpus"], args.gpus)
         print(json.dumps(out), flush=True)
 
     if distributed:

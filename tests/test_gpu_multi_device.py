@@ -202,3 +202,50 @@ def test_pipeline_without_das_on_several_devices_exports_one_zero_frame(bflib, d
     devices([0, 0])
     two = bflib.beamform(acq.bp, acq.rf, acq.filters)
     assert same_bits(one, two)
+
+
+# ---- the same two properties across PHYSICAL devices: these run wherever two or more GPUs are visible (an 8-GPU node at round
+# end) and skip on a one-GPU box, where every list above names ordinal 0 several times and nothing crosses a link
+
+def _visible_devices():
+    import torch
+    return torch.cuda.device_count()           # reads the driver's list; creates no context
+
+
+@pytest.mark.parametrize("name, count", [("config4_small", 2), ("config5_small", 4), ("rca_vls_cw", 8)])
+def test_slabs_stitch_across_distinct_devices(name, count, bflib, devices):
+    """ordinals 0..N-1: hipMemcpyPeerAsync between real devices, checked peer-access enable, cross-device stream waits -- the
+    stitched frame must still be bit-identical to the one-device frame"""
+    if _visible_devices() < count:
+        pytest.skip(f"{count} distinct GPUs needed, {_visible_devices()} visible")
+    acq = cases.make(name)
+    devices([0])
+    one = bflib.beamform(acq.bp, acq.rf, acq.filters).copy()
+    devices(list(range(count)))
+    many = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    assert same_bits(one, many)
+    # and again in the other direction of the ring: the LAST device ingests, device 0 is a peer
+    devices(list(reversed(range(count))))
+    many = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    assert same_bits(one, many)
+
+
+def test_device_info_across_distinct_devices(bflib, devices):
+    """beamformer_hip_get_device_info on two physical GPUs: distinct ordinals, the peer's copy travels over a link (direct peer
+    access or staged through the host -- never 'same GPU'), and both read the same RF bytes"""
+    if _visible_devices() < 2:
+        pytest.skip(f"2 distinct GPUs needed, {_visible_devices()} visible")
+    acq = cases.make("config4_small")
+    devices([0, 1])
+    frame = bflib.beamform(acq.bp, acq.rf, acq.filters)
+    lib = bflib.library()
+    infos = []
+    for i in range(2):
+        di = P.HipDeviceInfo()
+        assert lib.beamformer_hip_get_device_info(i, C.byref(di))
+        infos.append(di)
+    assert [int(d.ordinal) for d in infos] == [0, 1]
+    assert int(infos[0].peer_access) == 2 and int(infos[1].peer_access) in (0, 1)
+    assert sum(int(d.slab_count) for d in infos) == frame.shape[0]
+    assert infos[1].peer_copy_ms > 0
+    assert int(infos[0].rf_checksum) == int(infos[1].rf_checksum) and all(int(d.rf_bytes) == acq.rf.nbytes for d in infos)
