@@ -34,6 +34,7 @@ struct FrameRecord {
 	int      data_kind = BeamformerDataKind_Float32;
 	uint32_t id = 0, block = 0;
 	int      timing_slot = -1;
+	bool     failed = false;         /* tombstone of a push that did not complete (executor.cpp, Lockstep) */
 };
 
 /* one RF frame in flight on the upload side (beamformer_rf_upload's slot, beamformer_core.c:1756-1805) */
@@ -58,6 +59,7 @@ struct TimingSlot {
 	bool       counted = false;
 	uint64_t   frame_id = 0;
 	uint64_t   violations_slot = ~0ull;   /* staged kernels: index of this frame's window-violation counter, or ~0 */
+	bool       failed = false;            /* the push that owns this slot did not complete */
 };
 
 struct PlanState {
@@ -118,7 +120,8 @@ struct Device {
 	hipEvent_t   peer_copy_begin[BeamformerMaxRawDataFramesInFlight]{}, peer_copy_end[BeamformerMaxRawDataFramesInFlight]{};   /* timed */
 	uint32_t     last_rf_slot = 0;                             /* RF slot of the newest frame */
 	uint64_t     last_rf_bytes = 0;
-	const void  *last_rf = nullptr;                            /* what the newest frame's first stage read */
+	const void  *last_rf = nullptr;                            /* what the newest frame's first stage read: the library's own RF slot, never a caller's pointer */
+	bool         last_rf_sum_ready = false;                    /* a borrowed device buffer: its checksum was taken inside the push */
 	/* frame graphs (beamformer_hip_enable_frame_graphs): one instantiated hipGraph per parameter block, updated
 	 * in place from each frame's capture; graph_generation = the plan generation it was warmed up for */
 	hipGraphExec_t frame_exec[BeamformerMaxParameterBlocks]{};
@@ -161,6 +164,7 @@ bool ensure_device();                               /* SharedMemory error when n
 uint64_t default_frame_ring_bytes();
 bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool data_on_device);
 bool wait_for_frames(int32_t timeout_ms);
+const FrameRecord *newest_record(const Device &d);     /* null: the newest push did not complete */
 bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms);
 bool last_frame_timings(BeamformerHipFrameTimings *out);
 bool device_frame_timings(uint32_t device_index, BeamformerHipFrameTimings *out);

@@ -310,7 +310,7 @@ static FrameRecord *next_frame(const uint32_t points[3], bool complex_frame, uin
 		if (old.bytes && old.offset < d.ring_next_offset + bytes && d.ring_next_offset < old.offset + old.bytes) old.bytes = 0;
 	f->offset = d.ring_next_offset; f->bytes = bytes;
 	f->points[0] = points[0]; f->points[1] = points[1]; f->points[2] = points[2];
-	f->data_kind = kind; f->id = (uint32_t)id; f->block = block;
+	f->data_kind = kind; f->id = (uint32_t)id; f->block = block; f->failed = false;
 	d.ring_next_offset += bytes;
 	return f;
 }
@@ -353,6 +353,7 @@ static bool run_frame(uint32_t block, const void *rf, int64_t rf_bytes, bool ing
 	}
 	hipStream_t s = d.stream;
 	TimingSlot &t = d.timing[d.frame_counter % kTimingSlots];
+	t.failed = false;
 	if (!t.created) {
 		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
 		t.created = true;
@@ -402,6 +403,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 	hipStream_t s = d.stream;
 
 	TimingSlot &t = d.timing[d.frame_counter % kTimingSlots];
+	t.failed = false;
 	if (!t.created) {
 		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
 		t.created = true;
@@ -600,7 +602,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 				if (c.count_pairs) {
 					/* geometry-only recount of the apodization test; its own segment so that it
 					 * stays out of the DAS time */
-					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 1));
+					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 2));
 					BfDasArgs count = dd.general;              /* the general kernel's own tiles: the specialised kernels reshape them */
 					count.rf = a.rf; count.out = a.out; count.transmits = a.transmits; count.sparse_elements = a.sparse_elements;
 					count.readi_hadamard = a.readi_hadamard;
@@ -686,7 +688,7 @@ static bool run_peers(uint32_t block, const void *src, uint64_t rf_size, uint32_
 		p.last_rf = p.rf[slot].ptr; p.last_rf_bytes = rf_size; p.last_rf_slot = slot;
 		ok &= HIP_OK(hipStreamWaitEvent(p.stream, p.rf_landed[slot], 0));
 		TimingSlot &t = p.timing[p.frame_counter % kTimingSlots];
-		t.sampled = true; t.events_slot = (uint32_t)(p.frame_counter % kTimingSlots);
+		t.sampled = true; t.failed = false; t.events_slot = (uint32_t)(p.frame_counter % kTimingSlots);
 		ok = ok && run_frame(block, p.rf[slot].ptr, (int64_t)p.rf[slot].size, false);
 		p.consumed_pending[slot] = ok && HIP_OK(hipEventRecord(p.rf_consumed[slot], p.stream));
 	}
@@ -726,7 +728,23 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	 * the frames that are incomplete instead of skipping every frame from then on */
 	const uint64_t sequence = c.push_sequence++;
 	for (uint32_t i = 0; i < c.device_count; i++) c.devices[i].frame_counter = sequence;
-	struct Lockstep { Context &c; uint64_t next; ~Lockstep() { for (uint32_t i = 0; i < c.device_count; i++) c.devices[i].frame_counter = next; } } lockstep{c, sequence + 1};
+	/* ... and a push that does not complete leaves a TOMBSTONE under its id on every device (no bytes, no voxels, no stage timings): the readers
+	 * below refuse it -- "the newest frame is missing" -- instead of serving whatever record sat in that ring slot
+	 * BeamformerMaxBacklogFrames pushes ago */
+	struct Lockstep {
+		Context &c; uint64_t id; bool complete;
+		~Lockstep() {
+			for (uint32_t i = 0; i < c.device_count; i++) {
+				Device &p = c.devices[i];
+				p.frame_counter = id + 1;
+				if (complete) continue;
+				FrameRecord &f = p.frames[id % p.frames.size()];
+				f = FrameRecord{}; f.points[0] = f.points[1] = f.points[2] = 0; f.id = (uint32_t)id; f.failed = true;
+				TimingSlot &t = p.timing[id % kTimingSlots];
+				t.count = 0; t.counted = false; t.violations_slot = ~0ull; t.das_voxels = 0; t.frame_id = id; t.failed = true;
+			}
+		}
+	} lockstep{c, sequence, false};
 	if (multi) {
 		/* every peer replans before the ingest device does (its commit clears the dirty bits) */
 		for (uint32_t i = 1; i < c.device_count; i++) {
@@ -742,6 +760,7 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 
 	TimingSlot &t = d.timing[d.frame_counter % kTimingSlots];
+	t.failed = false;
 	if (!t.created) {
 		for (auto &e : t.events) if (!HIP_OK(hipEventCreate(&e))) return set_error(BeamformerLibErrorKind_SharedMemory);
 		t.created = true;
@@ -870,7 +889,12 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	}
 	c.last_push_time = now;
 
-	d.last_rf = borrowed ? data : d.rf[slot].ptr; d.last_rf_bytes = rf_size; d.last_rf_slot = slot;
+	/* what beamformer_hip_get_device_info checksums later.  A caller's device buffer is only borrowed for the duration of the frame: its
+	 * pointer is NOT kept -- with several devices the checksum of what the ingest device read is taken here, on the stream, while the
+	 * buffer is guaranteed live; with one device a borrowed frame reports no checksum */
+	d.last_rf = borrowed ? nullptr : d.rf[slot].ptr; d.last_rf_bytes = rf_size; d.last_rf_slot = slot; d.last_rf_sum_ready = false;
+	if (multi && borrowed && d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 2)))
+		d.last_rf_sum_ready = HIP_OK(bf_launch_rf_checksum(data, rf_size, (unsigned long long *)d.pair_counter.ptr + kTimingSlots + 1, s));
 	if (multi && !run_peers(block, borrowed ? data : d.rf[slot].ptr, rf_size, slot)) return false;
 	bool done = borrowed ? run_frame(block, data, (int64_t)rf_size, true)
 	                     : run_frame(block, d.rf[slot].ptr, (int64_t)d.rf[slot].size, true);
@@ -880,6 +904,7 @@ bool push_rf_and_compute(uint32_t block, const void *data, uint32_t size, bool d
 	 * later on the library's stream, so that stream also waits for the peer copies out of it */
 	if (multi && borrowed)
 		for (uint32_t i = 1; i < c.device_count; i++) (void)hipStreamWaitEvent(s, c.devices[i].rf_landed[slot], 0);
+	lockstep.complete = done;
 	return done;
 }
 
@@ -908,6 +933,16 @@ bool wait_for_frames(int32_t timeout_ms)
 	return ok;
 }
 
+/* The record of device d's newest frame -- or null when the newest push did not complete (its slot holds a tombstone) or the slot still
+ * holds an older frame's record: every reader of "the last frame" goes through here and fails instead of serving a stale record. */
+const FrameRecord *newest_record(const Device &d)
+{
+	if (d.frame_counter == 0 || d.frames.empty()) return nullptr;
+	const uint64_t id = d.frame_counter - 1;
+	const FrameRecord &f = d.frames[id % d.frames.size()];
+	return (f.id == (uint32_t)id && !f.failed) ? &f : nullptr;
+}
+
 /* BeamformerExportKind_BeamformedData (beamformer_core.c:1474-1494) */
 bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t timeout_ms)
 {
@@ -923,7 +958,11 @@ bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t ti
 	if (c.device_count == 1) {
 		for (uint64_t n = 0; n < req; n++, index++) {
 			const FrameRecord &f = d.frames[index % d.frames.size()];
-			if (f.bytes && exported + f.bytes <= out_size) {
+			const bool present = f.id == (uint32_t)index && !f.failed && f.bytes;
+			/* older frames that are gone (storage reused, a push that failed) are skipped; the NEWEST one missing is an error, not a
+			 * success that leaves the caller's buffer unwritten */
+			if (!present) { if (n + 1 == req) ok = false; continue; }
+			if (exported + f.bytes <= out_size) {
 				ok &= HIP_OK(hipMemcpyAsync((char *)out + exported, (const char *)d.ring.ptr + f.offset, f.bytes,
 				                            hipMemcpyDeviceToHost, d.stream));
 				exported += f.bytes;
@@ -939,7 +978,7 @@ bool export_last_frames(void *out, uint64_t out_size, uint32_t count, int32_t ti
 		uint64_t voxels = 0, elem = 0; bool valid = true;
 		for (uint32_t i = 0; i < c.device_count; i++) {
 			const FrameRecord &f = c.devices[i].frames[index % c.devices[i].frames.size()];
-			if (f.id != (uint32_t)index) { valid = false; break; }
+			if (f.id != (uint32_t)index || f.failed) { valid = false; break; }
 			uint64_t v = (uint64_t)f.points[0] * f.points[1] * f.points[2];
 			if (v && !f.bytes) { valid = false; break; }              /* storage reused by a newer frame */
 			voxels += v; if (v) elem = (uint64_t)bf_kind_byte_size[f.data_kind];
@@ -979,6 +1018,7 @@ static bool timings_of(Device &d, BeamformerHipFrameTimings *out)
 	if (d.frame_counter == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	if (!HIP_OK(hipSetDevice(d.device)) || !HIP_OK(hipStreamSynchronize(d.stream))) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	TimingSlot &t = d.timing[(d.frame_counter - 1) % kTimingSlots];
+	if (t.failed) return set_error(BeamformerLibErrorKind_InvalidAccess);          /* the newest push did not complete: no timings of an older frame in its place */
 	TimingSlot &e = d.timing[t.events_slot];       /* t itself, or the newest sampled frame of the same plan */
 	out->stage_count = t.count;
 	for (uint32_t i = 0; i < t.count; i++) {
@@ -1037,11 +1077,17 @@ bool device_info(uint32_t device_index, BeamformerHipDeviceInfo *out)
 			(void)hipGetLastError();
 		}
 		if (d.last_rf && d.last_rf_bytes) {
-			ok = d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 1));
+			ok = d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 2));
 			unsigned long long *sum = ok ? (unsigned long long *)d.pair_counter.ptr + kTimingSlots : nullptr;
 			unsigned long long host = 0;
 			ok = ok && HIP_OK(bf_launch_rf_checksum(d.last_rf, d.last_rf_bytes, sum, d.stream)) &&
 			     HIP_OK(hipMemcpyAsync(&host, sum, sizeof(host), hipMemcpyDeviceToHost, d.stream)) && HIP_OK(hipStreamSynchronize(d.stream));
+			out->rf_checksum = host; out->rf_bytes = d.last_rf_bytes;
+		} else if (d.last_rf_sum_ready && d.pair_counter.ptr) {
+			/* a borrowed device buffer: summed inside the push (the caller may have freed it since) */
+			unsigned long long host = 0;
+			ok = HIP_OK(hipMemcpyAsync(&host, (unsigned long long *)d.pair_counter.ptr + kTimingSlots + 1, sizeof(host), hipMemcpyDeviceToHost, d.stream)) &&
+			     HIP_OK(hipStreamSynchronize(d.stream));
 			out->rf_checksum = host; out->rf_bytes = d.last_rf_bytes;
 		}
 	}
@@ -1087,6 +1133,7 @@ bool fill_stats_table(BeamformerComputeStatsTable *out)
 		for (uint64_t n = 0; n < frames; n++) {
 			uint64_t id = d.frame_counter - frames + n;
 			TimingSlot &t = d.timing[id % kTimingSlots];
+			if (t.failed) continue;                    /* a push that did not complete: its row stays zero */
 			TimingSlot &e = d.timing[t.events_slot];
 			uint32_t col = 0;
 			for (uint32_t i = 0; i < t.count; i++) {
@@ -1113,8 +1160,9 @@ static bool newest_layout(Context &c, uint64_t offsets[kMaxDevices], uint64_t pe
 	total = 0;
 	for (uint32_t i = 0; i < c.device_count; i++) {
 		Device &p = c.devices[i];
-		if (p.frame_counter == 0) return false;
-		const FrameRecord &f = p.frames[(p.frame_counter - 1) % p.frames.size()];
+		const FrameRecord *fp = newest_record(p);
+		if (!fp) return false;
+		const FrameRecord &f = *fp;
 		offsets[i] = total;
 		total += (uint64_t)f.points[0] * f.points[1] * f.points[2] * per_voxel;
 	}
@@ -1129,7 +1177,9 @@ bool frame_min_max(float out[2])
 	float lo = 0.f, hi = 0.f;
 	for (uint32_t i = 0; i < c.device_count && ok; i++) {
 		Device &d = c.devices[i];
-		const FrameRecord &f = d.frames[(d.frame_counter - 1) % d.frames.size()];
+		const FrameRecord *fp = newest_record(d);
+		if (!fp) { ok = false; break; }
+		const FrameRecord &f = *fp;
 		uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
 		if (!voxels) continue;
 		ok &= HIP_OK(hipSetDevice(d.device));
@@ -1164,21 +1214,20 @@ bool sum_last_frames(uint32_t count, void *out, uint64_t out_size)
 	if (!c.device_ready || c.devices[0].frame_counter == 0 || count == 0) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	uint64_t offsets[kMaxDevices], total = 0;
 	{
-		const Device &d0 = c.devices[0];
-		const FrameRecord &f0 = d0.frames[(d0.frame_counter - 1) % d0.frames.size()];
-		if (!newest_layout(c, offsets, (uint64_t)bf_kind_byte_size[f0.data_kind], total)) return set_error(BeamformerLibErrorKind_InvalidAccess);
+		const FrameRecord *f0 = newest_record(c.devices[0]);
+		if (!f0 || !newest_layout(c, offsets, (uint64_t)bf_kind_byte_size[f0->data_kind], total)) return set_error(BeamformerLibErrorKind_InvalidAccess);
 	}
 	if (out_size < round_up(total, 64)) return set_error(BeamformerLibErrorKind_ExportSpaceOverflow);
 	bool ok = true;
 	for (uint32_t i = 0; i < c.device_count && ok; i++) {
 		Device &d = c.devices[i];
 		if (count > d.frame_counter || count > d.frames.size()) return set_error(BeamformerLibErrorKind_InvalidAccess);
-		const FrameRecord &newest = d.frames[(d.frame_counter - 1) % d.frames.size()];
+		const FrameRecord &newest = *newest_record(d);          /* (present: newest_layout checked every device) */
 		uint64_t slab_bytes = (uint64_t)newest.points[0] * newest.points[1] * newest.points[2] * (uint64_t)bf_kind_byte_size[newest.data_kind];
 		if (!slab_bytes) continue;
 		for (uint64_t id = d.frame_counter - count; id < d.frame_counter; id++) {
 			const FrameRecord &f = d.frames[id % d.frames.size()];
-			if (!f.bytes || f.bytes != newest.bytes || f.data_kind != newest.data_kind ||
+			if (f.id != (uint32_t)id || f.failed || !f.bytes || f.bytes != newest.bytes || f.data_kind != newest.data_kind ||
 			    f.points[0] != newest.points[0] || f.points[1] != newest.points[1] || f.points[2] != newest.points[2])
 				return set_error(BeamformerLibErrorKind_DataSizeMismatch);
 		}
@@ -1213,7 +1262,7 @@ bool display_last_frame(float threshold_db, float gamma, float db_cutoff, float 
 	bool ok = true;
 	for (uint32_t i = 0; i < c.device_count && ok; i++) {
 		Device &d = c.devices[i];
-		const FrameRecord &f = d.frames[(d.frame_counter - 1) % d.frames.size()];
+		const FrameRecord &f = *newest_record(d);               /* (present: newest_layout checked every device) */
 		uint64_t voxels = (uint64_t)f.points[0] * f.points[1] * f.points[2];
 		if (!voxels) continue;
 		ok &= HIP_OK(hipSetDevice(d.device));

@@ -472,8 +472,9 @@ uint32_t beamformer_hip_get_last_frame_info(BeamformerHipFrameInfo *out)
 {
 	Context &c = ctx();
 	const Device &d = c.devices[0];      /* with several devices: the ingest device's slab */
-	if (!check(c.device_ready && d.frame_counter > 0, BeamformerLibErrorKind_InvalidAccess)) return 0;
-	const FrameRecord &f = d.frames[(d.frame_counter - 1) % d.frames.size()];
+	const FrameRecord *newest = c.device_ready ? newest_record(d) : nullptr;      /* null after a push that did not complete */
+	if (!check(newest != nullptr, BeamformerLibErrorKind_InvalidAccess)) return 0;
+	const FrameRecord &f = *newest;
 	out->device_pointer = (char *)d.ring.ptr + f.offset;
 	out->size_bytes = f.bytes;
 	out->points[0] = f.points[0]; out->points[1] = f.points[1]; out->points[2] = f.points[2];

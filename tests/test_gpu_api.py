@@ -280,3 +280,42 @@ def test_frame_graphs_replay_bit_identical_frames(name, bflib):
     L.beamformer_hip_frame_graph_counts(C.byref(replayed), C.byref(built))
     assert replayed.value - replayed0.value >= 2 * 6                    # all but each plan's first frame(s)
     assert 1 <= built.value - built0.value <= 4                         # one graph per plan, updated in place
+
+
+def test_a_push_that_fails_leaves_no_stale_last_frame(bflib):
+    """A push that fails after it has taken its frame id (here: the plan is refused at commit time) leaves a tombstone under that id.
+    Every reader of "the newest frame" -- get_last_frames, the frame info, the timings, min/max, the rolling sum, the display reduction --
+    then FAILS instead of serving the record that sat in the same ring slot BeamformerMaxBacklogFrames pushes ago (or returning
+    success with the caller's buffer unwritten); the next good push is served normally and older good frames stay exportable."""
+    from tests.test_hilbert import acquisitions
+    L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)
+    good = cases.make("rca_cubic_real")
+    first = bflib.beamform(good.bp, good.rf, good.filters).copy()
+    # a pipeline the library accepts while the Hilbert stage is enabled and can no longer plan once it is not
+    bad = acquisitions()["rca_i16"]
+    assert L.beamformer_hip_enable_hilbert(1)
+    try:
+        assert L.beamformer_push_simple_parameters(C.byref(bad.bp)), bflib.last_error()
+    finally:
+        assert L.beamformer_hip_enable_hilbert(0)
+    rf = np.ascontiguousarray(bad.rf)
+    assert not L.beamformer_push_data_with_compute(rf.ctypes.data_as(C.c_void_p), rf.nbytes, 0, 0)
+    assert bflib.last_error()[0] == E.InvalidComputeStage
+    sentinel = np.full(first.size + 64, -7.0, np.float32)
+    assert not L.beamformer_get_last_frames(sentinel.ctypes.data_as(C.c_void_p), sentinel.nbytes, 1)
+    assert bflib.last_error()[0] == E.InvalidAccess and (sentinel == -7.0).all()
+    assert not L.beamformer_hip_get_last_frame_info(C.byref(P.HipFrameInfo()))
+    assert not L.beamformer_hip_get_last_frame_timings(C.byref(P.HipFrameTimings()))
+    assert not L.beamformer_hip_frame_min_max((C.c_float * 2)())
+    assert not L.beamformer_hip_sum_last_frames(1, sentinel.ctypes.data_as(C.c_void_p), sentinel.nbytes)
+    assert not L.beamformer_hip_display_last_frame(55.0, 1.0, 50.0, sentinel.ctypes.data_as(C.POINTER(C.c_float)), sentinel.size)
+    assert (sentinel == -7.0).all()
+    # the last TWO frames: the older, good one is still exported; the call reports the missing newest one
+    assert not L.beamformer_get_last_frames(sentinel.ctypes.data_as(C.c_void_p), sentinel.nbytes, 2)
+    assert np.array_equal(sentinel[: first.size].reshape(first.shape), first)
+    # and the library is not wedged: the next good push is the newest frame again, with its timings
+    again = bflib.beamform(good.bp, good.rf, good.filters)
+    assert np.array_equal(again.view(np.uint32), first.view(np.uint32))
+    t = P.HipFrameTimings()
+    assert L.beamformer_hip_get_last_frame_timings(C.byref(t)) and t.stage_count > 0
