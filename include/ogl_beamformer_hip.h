@@ -216,21 +216,13 @@ BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_das_path(uint32_t mode);
 /* Environment variables the library reads (none is needed in production):
  *   BEAMFORMER_HIP_DEVICE            HIP ordinal of the one-device mode (else LOCAL_RANK, else 0)
  *   BEAMFORMER_HIP_FRAME_RING_BYTES  size of the beamformed-frame ring (default 4 GiB)
- * and, read ONCE into the hook table (beamformer_hip_set_hook changes them at run time; measurement and test aids):
- *   BEAMFORMER_HIP_TILE_WALK=plane   DAS tiles walked x, y, z instead of depth-major (=column: view planes walked depth
- *                                    fastest instead of in XCD-balanced bands)
- *   BEAMFORMER_HIP_TILE_WINDOW=32    das_tile.hip with the 32- (or =64: 64-) sample window whatever the estimated spread: chunks that do not fit run its gather loop
- *   BEAMFORMER_HIP_SPLIT_TARGET=waves  the channel split of the per-voxel kernels aims at this many waves per launch (default 4096)
- *   BEAMFORMER_HIP_STAGED_SHAPE=u,v,w  the LDS-staged kernel only with 2^u x 2^v voxel tiles and 2^w-sample windows
- *   BEAMFORMER_HIP_STAGED_CHECKED    the LDS-staged kernels' range-checked loop for every wave; it also counts window violations
- *                                    (BeamformerHipFrameTimings::staged_window_violations)
- *   BEAMFORMER_HIP_STAGED_NOUNIFORM  transmit tables in LDS also where the wave-uniform (global table) form applies
- *   BEAMFORMER_HIP_STAGED_W48        the wave-uniform form's 48-sample window where 32 samples are too few
- *   BEAMFORMER_HIP_STAGED_WALK=column  plain depth-major walk for the wave-uniform form (default: paired walk)
- *   BEAMFORMER_HIP_STAGED_TABLE_CAP=bytes  largest global transmit table taken (default 2 GiB; 0: always the LDS-table fallback)
- *   BEAMFORMER_HIP_HERCULES_FRACT    the HERCULES kernel reduces the demodulation phase per pair (v_fract) as before round 2's last pass
- *   BEAMFORMER_HIP_HERCULES_NOPAIRS  the HERCULES kernel gathers from the DAS input itself, not from its prepared copy
- *   BEAMFORMER_HIP_DEBUG             one line per staged plan on stderr */
+ * Diagnostic switches (beamformer_hip_set_hook only -- no environment variable; they select among code paths that ship anyway):
+ *   STAGED_SHAPE=u,v,w      the LDS-staged kernels only with 2^u x 2^v voxel tiles and 2^w-sample windows
+ *   STAGED_CHECKED          the LDS-staged kernels' range-checked loop for every wave; it also counts window violations
+ *                           (BeamformerHipFrameTimings::staged_window_violations)
+ *   STAGED_NOUNIFORM        transmit tables in LDS also where the wave-uniform (global table) form applies
+ *   STAGED_TABLE_CAP=bytes  largest global transmit table taken (default 2 GiB; 0: always the LDS-table fallback)
+ *   DEBUG                   one line per staged plan on stderr */
 
 /* ---- ZBP acquisition files (external/zemp_bp.h; loader tests/throughput.c:135-374) ----
  * Host only, no device needed.  The reference keeps this loader in its throughput harness;
@@ -315,9 +307,8 @@ typedef struct {
 } BeamformerHipDasDescription;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDescription *out);
 
-/* Test and measurement hooks (none is needed in production; csrc/das_select.h lists what each does).  Each is read from the
- * environment variable BEAMFORMER_HIP_<NAME> ONCE, when the library first needs it; this call changes one at run time
- * (value NULL or "" = off) and is what the test-suite uses.  Returns 0 for an unknown name. */
+/* Diagnostic switches (none is needed in production; listed above, csrc/das_select.h says what each does): set and cleared
+ * (value NULL or "") through this call only -- the library reads no environment variable for them.  Returns 0 for an unknown name. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_set_hook(const char *name, const char *value);
 
 /* Free every device resource; the next call re-initialises. */

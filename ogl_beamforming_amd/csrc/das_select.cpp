@@ -36,8 +36,7 @@ const char *das_kernel_name(int path)
 /* ---------------------------------------------------------------- hooks */
 
 static Hooks g_hooks;
-static const char *const g_hook_names[] = {"STAGED_SHAPE", "STAGED_CHECKED", "STAGED_NOUNIFORM", "STAGED_W48", "STAGED_WALK", "STAGED_TABLE_CAP",
-                                           "TILE_WALK", "TILE_WINDOW", "SPLIT_TARGET", "HERCULES_FRACT", "HERCULES_NOPAIRS", "DEBUG", nullptr};
+static const char *const g_hook_names[] = {"STAGED_SHAPE", "STAGED_CHECKED", "STAGED_NOUNIFORM", "STAGED_TABLE_CAP", "DEBUG", nullptr};
 const char *const *hook_names() { return g_hook_names; }
 
 static bool apply_hook(Hooks &h, const char *name, const char *value)
@@ -50,30 +49,13 @@ static bool apply_hook(Hooks &h, const char *name, const char *value)
 	}
 	else if (!std::strcmp(name, "STAGED_CHECKED"))   h.staged_checked = on;
 	else if (!std::strcmp(name, "STAGED_NOUNIFORM")) h.staged_nouniform = on;
-	else if (!std::strcmp(name, "STAGED_W48"))       h.staged_w48 = on;
-	else if (!std::strcmp(name, "STAGED_WALK"))      h.staged_walk_column = on && value[0] == 'c';
 	else if (!std::strcmp(name, "STAGED_TABLE_CAP")) h.staged_table_cap = on ? std::strtoull(value, nullptr, 0) : (2ull << 30);
-	else if (!std::strcmp(name, "TILE_WALK"))        h.tile_walk = on ? value[0] : 0;
-	else if (!std::strcmp(name, "TILE_WINDOW"))      h.tile_window = on ? std::atoi(value) : 0;
-	else if (!std::strcmp(name, "SPLIT_TARGET"))     h.split_target = on ? std::strtoull(value, nullptr, 0) : 0;
-	else if (!std::strcmp(name, "HERCULES_FRACT"))   h.hercules_fract = on;
-	else if (!std::strcmp(name, "HERCULES_NOPAIRS")) h.hercules_nopairs = on;
 	else if (!std::strcmp(name, "DEBUG"))            h.debug = on;
 	else return false;
 	return true;
 }
 
-Hooks &hooks()
-{
-	if (!g_hooks.loaded) {
-		g_hooks.loaded = true;
-		for (const char *const *n = g_hook_names; *n; n++) {
-			std::string env = std::string("BEAMFORMER_HIP_") + *n;
-			if (const char *v = std::getenv(env.c_str())) apply_hook(g_hooks, *n, v);
-		}
-	}
-	return g_hooks;
-}
+Hooks &hooks() { return g_hooks; }
 
 bool set_hook(const char *name, const char *value)
 {
@@ -130,10 +112,8 @@ static int choose_tile(const float *voxel_to_xdc, const uint32_t size[3], uint32
 static uint32_t tile_walk(int depth_axis, uint32_t zcount, uint32_t tile_rows, uint32_t &band_rows)
 {
 	band_rows = 1;
-	const char walk = hooks().tile_walk;      /* 'p': x -> y -> z, 'c': y fastest on view planes (measurement aids) */
-	if (walk == 'p') return 0u;
 	if (depth_axis != 1) return 1u;
-	if (zcount != 1 || walk == 'c') return 2u;
+	if (zcount != 1) return 2u;
 	/* view plane: ~32 bands, four per XCD (bf_plane_walk) */
 	band_rows = tile_rows / 32u ? tile_rows / 32u : 1u;
 	return 3u;
@@ -324,7 +304,7 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
 	}
 	if (!best_waves) return false;
 	q.u_axis = (uint32_t)u_axis;
-	q.depth_major = hooks().tile_walk == 'p' ? 0u : 1u;        /* TILE_WALK=plane restores the x -> y -> z walk (measurement aid) */
+	q.depth_major = 1u;
 	const uint32_t best_u = q.u_shift, best_v = q.v_shift;
 	uint32_t nu = a.size[u_axis], nv = a.size[1 - u_axis];
 	q.tiles[0] = (nu + (1u << best_u) - 1) >> best_u;
@@ -377,31 +357,24 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 			uint32_t need = (uint32_t)std::ceil(spread * 1.001f) + (cubic ? 6 : 4);   /* + taps (k - 1 .. k + 2 for cubic), floors, rounding slack */
 			uint32_t ws = need <= 32 ? 5 : need <= 64 ? 6 : 0;
 			if (!ws) continue;
-			/* BEAMFORMER_HIP_STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
-			 * a window larger than needed is legal, a smaller one is not taken; ws = 48: the uniform variant's 48-sample window) */
-			bool force_w48 = false;
+			/* hook STAGED_SHAPE="us,vs,ws": only this tile / window shape (testing every template instance;
+			 * a window larger than needed is legal, a smaller one is not taken) */
 			if (hk.staged_shape_set) {
 				const unsigned fu = (unsigned)hk.staged_shape[0], fv = (unsigned)hk.staged_shape[1], fw = (unsigned)hk.staged_shape[2];
 				if (fu != us || fv != vs) continue;
-				if (fw == 48) { if (need > 48) continue; force_w48 = true; }
-				else { if (fw < ws || fw > 6) continue; ws = fw; }
+				if (fw < ws || fw > 6) continue;
+				ws = fw;
 			}
 			/* complex samples, linear interpolation, x along the receive axis and a 64 x 16 tile: a wave's lanes share one row of the
 			 * transmit axis, the transmit tables leave the LDS for a global table read through scalar loads (das_staged.hip, UNI).
-			 * Measured faster than every other shape, so it is preferred wherever its window fits -- with a
-			 * 48-sample window where 32 samples are too few (64-sample windows of 64 and more transmits leave no room for two
-			 * blocks per CU): 63 elements per wave and pass, at most 4 passes of the 16 waves */
+			 * Measured faster than every other shape, so it is preferred wherever its window fits.  (An in-between
+			 * 48-sample window for this form existed through round 3: 0.7 % faster at config 4 for 4 x the HBM-side traffic; removed.) */
 			const bool uniform = allow_uniform && cplx && !cubic && u_axis == 0 && threads_shift == 10 && us == 6 && vs == 4 &&
 			                     !hk.staged_nouniform;
-			uint32_t window = 1u << ws;
-			/* (the 48-sample window is opt-in -- BEAMFORMER_HIP_STAGED_W48, or the shape hook: at config 4 it measured 799.0 ms against
-			 * 804.5 ms for the 32 x 32 tiles with the tables in LDS, but 726 GB of HBM-side traffic per launch against 176 GB) */
-			const bool want_w48 = force_w48 || (hk.staged_w48 && need > 32 && need <= 48);
-			if (uniform && want_w48 && (A4 * 48u + 62u) / 63u <= 64u) window = 48;
-			else if (force_w48) continue;
+			const uint32_t window = 1u << ws;
 			/* window elements a thread stages per channel: 4 (complex: registers), 8 (real).  The linear kernels also rest their
 			 * tap address on it -- one 16-bit shift of the element index: 4096 x 16 B and 8192 x 8 B both end at 64 KB */
-			if (window != 48 && ((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
+			if (((uint64_t)A4 << ws) > ((uint64_t)(cplx ? 4 : 8) << threads_shift)) continue;
 			const uint64_t stage_elements = (uint64_t)A4 * window;
 			for (uint32_t chunk = 8; chunk <= 64; chunk *= 2) {
 				uint32_t cc = chunk < C ? chunk : C;
@@ -416,7 +389,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 				uint32_t waves = blocks << (threads_shift - 6);
 				uint32_t balance = us > vs ? us - vs : vs - us;
 				uint32_t score = (blocks >= 2 ? 1000u : 0u) + (cc << 2) + (8 - balance) + (window == 32 ? 500u : 0u) +
-				                 (uniform && window == 32 ? 2000u : uniform && window == 48 ? 1500u : 0u);
+				                 (uniform && window == 32 ? 2000u : 0u);
 				if (waves > best_waves || (waves == best_waves && score > best_score)) {
 					best_waves = waves; best_score = score;
 					best.u_shift = us; best.v_shift = vs; best.threads = 1u << threads_shift;
@@ -429,9 +402,8 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 		}
 	}
 	if (hk.staged_checked) best.depth_major |= 2u;       /* test hook: the range-checked loop for every wave */
-	/* uniform variant: the two blocks of a CU are neighbours along u in one plane (shared rows of the global transmit table);
-	 * STAGED_WALK=column keeps the plain depth-major walk (measurement aid) */
-	if (best.uniform && (best.depth_major & 1u) && !hk.staged_walk_column) best.depth_major |= 4u;
+	/* uniform variant: the two blocks of a CU are neighbours along u in one plane (shared rows of the global transmit table) */
+	if (best.uniform && (best.depth_major & 1u)) best.depth_major |= 4u;
 	if (hk.debug)
 		std::fprintf(stderr, "[beamformer] staged plan: step_u %.3f step_v %.3f waves %u u %u v %u w %u chunk %u lds %u uniform %u\n",
 		             step_u, step_v, best_waves, best.u_shift, best.v_shift, best.window_samples, best.channel_chunk, best.lds_bytes, best.uniform);
@@ -524,8 +496,7 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 		/* distances to two elements of the inner axis differ by at most their separation: at most 255 pitches (dense or
 		 * sparse element indices alike), i.e. this many turns of demodulation phase inside one inner loop */
 		const float span_turns = std::fabs(a.turns_per_sample) * 255.0f * std::fabs(a.pitch[inner]) * a.sampling_frequency * a.inv_speed_of_sound;
-		q.phase_local = a.complex_data && span_turns < 400.0f &&       /* (false for a NaN) */
-		                !hooks().hercules_fract;                         /* measurement aid: v_fract per pair */
+		q.phase_local = a.complex_data && span_turns < 400.0f;         /* (false for a NaN) */
 	}
 	return true;
 }
@@ -628,7 +599,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	 * frame by target wave count: 2048 -> 19.9, 4096 -> 15.2, 8192 -> 15.1, 16384 -> 17.1). */
 	const uint64_t voxel_waves = ((uint64_t)ext[0] * ext[1] * ext[2] + 63) / 64;
 	a.split_shift = 0;
-	const uint64_t split_target = hooks().split_target ? hooks().split_target : 4096;
+	const uint64_t split_target = 4096;
 	while (!(mode & 0x10) && a.split_shift < 4 && (voxel_waves << a.split_shift) < split_target && (C >> (a.split_shift + 1)) >= 4) a.split_shift++;
 	out.depth_axis = choose_tile(to_xdc, a.size, zcount, a.tile_shift, a.split_shift ? 6 : 8);
 	for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
@@ -717,7 +688,7 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 			 * plane with cubic polynomials: 28.1 ms, 158 GB from beyond L2 per frame; with the taps gathered from the RF itself 25.2 ms */
 			const uint64_t prepared = out.das_input_bytes * (a.interpolation == 2 ? 4u : 2u);
 			out.hercules_prepared = plan.iq_pipeline && (a.interpolation == 1 || a.interpolation == 2) && prepared + 64 < (1ull << 32) &&
-			                        lane_step_samples(to_xdc, a) < 1.0f && !hooks().hercules_nopairs;
+			                        lane_step_samples(to_xdc, a) < 1.0f;
 			out.herc = hq;
 			out.path = DasPath_Hercules;
 			why[DasPath_General] = "a specialised kernel applies";
@@ -771,7 +742,6 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 				for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
 				a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
 				a.tile_window_shift = spread <= 26.f ? 5u : 6u;
-				if (hooks().tile_window == 32 || hooks().tile_window == 64) a.tile_window_shift = hooks().tile_window == 32 ? 5u : 6u;
 				out.path = DasPath_Tile;
 				why[DasPath_Factored] = "superseded by its block-staged form (das_tile.hip)";
 				why[DasPath_General] = "a specialised kernel applies";

@@ -1,7 +1,6 @@
 /* das_select.h -- which DAS kernel a frame runs, and why: ONE table of rules, host only (no HIP call), shared by the executor
  * (which launches what it says), beamformer_hip_describe_das (which reports it, also without a device) and the tests (which ask
- * instead of restating the rules).  Also the library's test / measurement hooks: the former BEAMFORMER_HIP_* environment reads,
- * now one table filled from the environment ONCE and settable through beamformer_hip_set_hook. */
+ * instead of restating the rules).  Also the library's five diagnostic switches (beamformer_hip_set_hook). */
 #ifndef BF_DAS_SELECT_H
 #define BF_DAS_SELECT_H
 
@@ -26,27 +25,21 @@ constexpr uint32_t kStagedMinTransmits = 6;      /* das_staged.hip by default fr
                                                     profiles/r03_staged_threshold.json: 1.29 of the gather kernel's time at 4 transmits, 1.01 at 6,
                                                     1.0 at 8, 0.88 at 12, 0.75 at 16, 0.69-0.71 at 32-75; round 2's pass: 1.15, -, 0.91, 0.84, 0.75) */
 
-/* Test and measurement hooks (none is needed in production).  Read from the environment (BEAMFORMER_HIP_<NAME>) when first
- * needed and never again; beamformer_hip_set_hook changes one at run time.  `version` counts changes: cached decisions carry it. */
+/* Diagnostic switches (none is needed in production, all default off): set through beamformer_hip_set_hook ONLY -- the library
+ * reads no environment variable.  They select among code paths that ship anyway (the range-checked loop every boundary wave takes,
+ * the LDS-table form every non-64 x 16 tile takes, ...) so that the tests can aim at each of them.  `version` counts changes:
+ * cached decisions carry it. */
 struct Hooks {
-	bool        loaded = false;
 	uint64_t    version = 1;
-	int         staged_shape[3] = {0, 0, 0};   /* STAGED_SHAPE="u,v,w": only 2^u x 2^v tiles with 2^w-sample windows (w = 48: the 48-sample window) */
+	int         staged_shape[3] = {0, 0, 0};   /* STAGED_SHAPE="u,v,w": only 2^u x 2^v tiles with 2^w-sample windows */
 	bool        staged_shape_set = false;
 	bool        staged_checked = false;        /* STAGED_CHECKED: the range-checked loop for every wave (it also counts window violations) */
 	bool        staged_nouniform = false;      /* STAGED_NOUNIFORM: transmit tables in LDS also where the wave-uniform form applies */
-	bool        staged_w48 = false;            /* STAGED_W48: the wave-uniform form's 48-sample window where 32 samples are too few */
-	bool        staged_walk_column = false;    /* STAGED_WALK=column: plain depth-major walk for the wave-uniform form */
-	uint64_t    staged_table_cap = 2ull << 30; /* STAGED_TABLE_CAP=bytes: largest global transmit table taken (test: 0 forces the fallback) */
-	char        tile_walk = 0;                 /* TILE_WALK=plane / column: 'p' x, y, z; 'c' view planes walked depth fastest */
-	int         tile_window = 0;               /* TILE_WINDOW=32 / 64: das_tile.hip with that window whatever the estimated spread (measurement aid) */
-	uint64_t    split_target = 0;              /* SPLIT_TARGET=waves: split the channel loop over the waves of a block until the launch has this many (default 4096) */
-	bool        hercules_fract = false;        /* HERCULES_FRACT: v_fract per pair instead of the per-lane phase reduction */
-	bool        hercules_nopairs = false;      /* HERCULES_NOPAIRS: never read the prepared copy of the DAS input */
+	uint64_t    staged_table_cap = 2ull << 30; /* STAGED_TABLE_CAP=bytes: largest global transmit table taken (0 forces the fallback) */
 	bool        debug = false;                 /* DEBUG: one line per staged plan on stderr */
 };
 Hooks &hooks();
-bool   set_hook(const char *name, const char *value);       /* name without the BEAMFORMER_HIP_ prefix; value null or "" = unset; false: unknown name */
+bool   set_hook(const char *name, const char *value);       /* value null or "" = unset; false: unknown name */
 const char *const *hook_names();                             /* null-terminated */
 
 struct DasDecision {

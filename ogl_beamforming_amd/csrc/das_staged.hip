@@ -82,10 +82,8 @@ template <bool CW, int VS, int WS, int NL, bool UNI>
 __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs p, const BfSeparableArgs q)
 {
 	extern __shared__ __attribute__((aligned(16))) f32x4 staged_lds[];
-	/* WS: log2 of the window length (5, 6), or 48 itself: the 48-sample window of the UNI variant (64-voxel tiles whose delay
-	 * spread overflows 32 samples while 64-sample windows overflow the LDS of two blocks per CU) */
-	constexpr bool W48 = WS == 48;
-	constexpr uint32_t V = 1u << VS, W = W48 ? 48u : 1u << (WS & 7);
+	/* WS: log2 of the window length (5, 6) */
+	constexpr uint32_t V = 1u << VS, W = 1u << WS;
 	const uint32_t U = 1u << q.u_shift;
 	const int C = p.channel_count, A = p.acquisition_count, S = p.sample_count;
 	const int A4 = (A + 3) & ~3;
@@ -255,22 +253,11 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 	const __amdgpu_buffer_rsrc_t rf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		const_cast<void *>(p.rf), 0, (int)((uint32_t)C * (uint32_t)A * (uint32_t)S * 8u), 0x00020000);
 	uint32_t stage_inv[NL];
-	[[maybe_unused]] uint32_t stage_js = 0;              /* W48: the in-window index j of the thread's element of pass n in byte n */
-	if constexpr (W48) {
-		/* windows do not fill whole waves: a wave stages 63 consecutive elements per pass (element = slot * 63 + lane, slot =
-		 * wave + n * waves), its last lane only lends its sample to lane 62's line */
+	{
+		const uint32_t windows_per_pass = nthreads >> WS;
 		#pragma unroll
 		for (int n = 0; n < NL; n++) {
-			const uint32_t e = ((tid >> 6) + (uint32_t)n * (nthreads >> 6)) * 63u + (tid & 63u);
-			const uint32_t a = e / 48u, j = e - a * 48u;
-			stage_inv[n] = a < (uint32_t)A ? (a * (uint32_t)S + (uint32_t)(tfl[a] + (int)j)) * 8u : 0x80000000u;
-			stage_js |= j << (8 * n);
-		}
-	} else {
-		const uint32_t windows_per_pass = nthreads >> (WS & 7);
-		#pragma unroll
-		for (int n = 0; n < NL; n++) {
-			uint32_t a = (tid >> (WS & 7)) + (uint32_t)n * windows_per_pass;
+			uint32_t a = (tid >> WS) + (uint32_t)n * windows_per_pass;
 			/* transmits of the padding (a >= A) point far outside the buffer: they stage zeros */
 			stage_inv[n] = a < (uint32_t)A ? (a * (uint32_t)S + (uint32_t)(tfl[a] + (int)(tid & (W - 1)))) * 8u : 0x80000000u;
 		}
@@ -299,14 +286,8 @@ __global__ __launch_bounds__(1024, 8) void das_rca_staged_kernel(const BfDasArgs
 			const float nx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x130, 0xf, 0xf, true));
 			const float ny = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sy), 0x130, 0xf, 0xf, true));
 			const float dx = nx - sx, dy = ny - sy;
-			if constexpr (W48) {
-				const uint32_t e = ((tid >> 6) + (uint32_t)n * (nthreads >> 6)) * 63u + (tid & 63u);
-				const float hmj = 0.5f - (float)((stage_js >> (8 * n)) & 0xffu);
-				if ((tid & 63u) != 63u && e < stage_elements) stage[e] = f32x4{__builtin_fmaf(hmj, dx, sx), __builtin_fmaf(hmj, dy, sy), dx, dy};
-			} else {
-				const uint32_t e = tid + (uint32_t)n * nthreads;
-				if (e < stage_elements) stage[e] = f32x4{__builtin_fmaf(half_minus_j, dx, sx), __builtin_fmaf(half_minus_j, dy, sy), dx, dy};
-			}
+			const uint32_t e = tid + (uint32_t)n * nthreads;
+			if (e < stage_elements) stage[e] = f32x4{__builtin_fmaf(half_minus_j, dx, sx), __builtin_fmaf(half_minus_j, dy, sy), dx, dy};
 		}
 	};
 
@@ -516,9 +497,8 @@ template <bool CW, int VS, int WS, bool UNI>
 static hipError_t launch_staged_loads(const BfDasArgs *a, const BfSeparableArgs *q, hipStream_t s)
 {
 	const uint32_t A4 = ((uint32_t)a->acquisition_count + 3u) & ~3u;
-	/* passes a thread stages per channel: whole windows per wave, or (48-sample windows) 63 elements per wave */
-	const uint32_t passes = WS == 48 ? ((A4 * 48u + 62u) / 63u + (q->threads >> 6) - 1) / (q->threads >> 6)
-	                                 : ((A4 << (WS & 7)) + q->threads - 1) / q->threads;
+	/* passes a thread stages per channel: whole windows per wave */
+	const uint32_t passes = ((A4 << WS) + q->threads - 1) / q->threads;
 	switch (passes) {
 	case 1: return launch_staged<CW, VS, WS, 1, UNI>(a, q, s);
 	case 2: return launch_staged<CW, VS, WS, 2, UNI>(a, q, s);
@@ -535,7 +515,6 @@ static hipError_t launch_staged_shape(const BfDasArgs *a, const BfSeparableArgs 
 		/* wave-uniform transmit tables: a 64 x 16 tile with x along the receive axis, 1024 threads, tables written by bf_launch_das_staged_tables */
 		if (q->u_axis != 0 || q->u_shift != 6 || q->v_shift != 4 || q->threads != 1024 || !q->tables) return hipErrorInvalidValue;
 		if (q->window_samples == 32) return launch_staged_loads<CW, 4, 5, true>(a, q, s);
-		if (q->window_samples == 48) return launch_staged_loads<CW, 4, 48, true>(a, q, s);
 		if (q->window_samples == 64) return launch_staged_loads<CW, 4, 6, true>(a, q, s);
 		return hipErrorInvalidValue;
 	}

@@ -82,9 +82,9 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
         assert subprocess.run([str(exe)]).returncode == 0
 
 
-def test_every_environment_variable_the_library_reads_is_documented():
-    """include/ogl_beamformer_hip.h lists the BEAMFORMER_HIP_* variables: every getenv in csrc/ and every name of the hook table
-    (csrc/das_select.cpp, read from the environment once) is there"""
+def test_every_environment_variable_and_switch_is_documented_and_hooks_read_no_environment():
+    """include/ogl_beamformer_hip.h lists what the library reads from the environment (every getenv in csrc/) and every diagnostic
+    switch of the hook table (csrc/das_select.cpp); the switches are reachable through beamformer_hip_set_hook ONLY"""
     import glob
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -92,14 +92,14 @@ def test_every_environment_variable_the_library_reads_is_documented():
     read = set()
     for path in glob.glob(os.path.join(root, "ogl_beamforming_amd", "csrc", "*")):
         if path.endswith((".cpp", ".hip", ".h", ".c")):
-            read |= set(re.findall(r'getenv\("(BEAMFORMER_HIP_[A-Z0-9_]+)"\)', open(path, errors="replace").read()))
-    assert read, "no getenv found: the pattern is stale"
+            read |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(path, errors="replace").read()))
+    assert read == {"BEAMFORMER_HIP_DEVICE", "BEAMFORMER_HIP_FRAME_RING_BYTES", "LOCAL_RANK"}, read
     select = open(os.path.join(root, "ogl_beamforming_amd", "csrc", "das_select.cpp")).read()
+    assert "getenv" not in select
     table = re.search(r"g_hook_names\[\] = \{(.*?)nullptr\}", select, flags=re.S)
     hooks = re.findall(r'"([A-Z0-9_]+)"', table.group(1))
-    assert len(hooks) >= 8
-    read |= {"BEAMFORMER_HIP_" + h for h in hooks}
-    missing = sorted(v for v in read if v not in header)
+    assert sorted(hooks) == ["DEBUG", "STAGED_CHECKED", "STAGED_NOUNIFORM", "STAGED_SHAPE", "STAGED_TABLE_CAP"]
+    missing = sorted(v for v in (read | set(hooks)) if v not in header)
     assert not missing, missing
 
 
