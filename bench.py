@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink factor for rehearsal runs (metric is scale 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU-baseline budget (DAS time summed over its three legs)")
-    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 2 auto without the LDS-staged kernel (the gather kernel instead), 3 LDS-staged kernel wherever its window bound holds, 4 factored kernel wherever it applies, 6 HERCULES aligned-grid kernel also on narrow grids; flags to add: 16 no channel split, 64 / 128 wave-span staging on / off, 256 / 512 the block-staged factored kernel (das_tile.hip) on / off")
+    ap.add_argument("--das-path", type=int, default=0, help="0 auto, 1 general DAS kernel, 2 auto without the LDS-staged kernel (the gather kernel instead), 3 LDS-staged kernel wherever its window bound holds, 4 factored kernel wherever it applies, 6 HERCULES aligned-grid kernel also on narrow grids; flags to add: 16 no channel split, 256 / 512 the block-staged factored kernel (das_tile.hip) on / off")
     ap.add_argument("--serial-broadcast", action="store_true",
                     help="multi-GPU: broadcast and compute back to back on one stream instead of pipelined")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -283,7 +283,7 @@ def main():
     dd = P.HipDasDescription()
     assert L.beamformer_hip_describe_das(0, C.byref(dd)), lib.last_error()
     das_plan = {"kernel": dd.kernel.decode(), "tile_shift": list(dd.tile_shift), "blocks": list(dd.blocks), "split_shift": int(dd.split_shift),
-                "tile_walk": int(dd.tile_walk), "span_stage": int(dd.span_stage), "u_axis": int(dd.u_axis), "u_shift": int(dd.u_shift), "v_shift": int(dd.v_shift),
+                "tile_walk": int(dd.tile_walk), "u_axis": int(dd.u_axis), "u_shift": int(dd.u_shift), "v_shift": int(dd.v_shift),
                 "window_samples": int(dd.window_samples), "uniform_tables": int(dd.uniform_tables), "lds_bytes": int(dd.lds_bytes), "threads": int(dd.threads),
                 "channel_chunk": int(dd.channel_chunk), "hercules_prepared_copy": int(dd.hercules_prepared_copy),
                 "tile_window_samples": int(dd.tile_window_samples), "tile_spread_estimate": round(float(dd.tile_spread_estimate), 2),

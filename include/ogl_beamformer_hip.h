@@ -106,6 +106,11 @@ typedef struct {
 	uint32_t tile_staged_chunks;         /* das path 6 (das_tile.hip): (block, chunk of four channels) pairs whose terms were read from the windows the
 	                                        block staged in LDS ... */
 	uint32_t tile_gather_chunks;         /* ... and those whose spread did not fit the window: the block ran das_factored.hip's gather loop for them */
+	uint32_t das_row_end_planes;         /* z-planes of the frame the ROW-END rule handed to the kernel behind the staged one (LDS-staged -> gather /
+	                                        factored; block-staged factored -> factored): planes on which a term can come within reach of an end of
+	                                        its RF row, where sample_rf's range test is decided by the shader's own index, evaluated exactly
+	                                        (csrc/das_exact.h).  0 on acquisitions whose rows do not end inside the image; das_path then names the
+	                                        kernel that took the most planes */
 } BeamformerHipFrameTimings;
 /* Timings of the newest frame; waits for it to finish. */
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_get_last_frame_timings(BeamformerHipFrameTimings *out);
@@ -204,10 +209,6 @@ typedef enum {
 	BeamformerHipDasPath_HerculesAnyWidth = 6,    /* das_hercules.hip also on grids narrower than 32 voxels */
 	BeamformerHipDasPath_NoChannelSplit   = 0x10, /* flag: general kernel at one thread per voxel for small frames too */
 	BeamformerHipDasPath_DenseDecode      = 0x20, /* flag: Decode on the O(T^2) kernel, not the Walsh-Hadamard form */
-	BeamformerHipDasPath_SpanStaging      = 0x40, /* flag: das_factored.hip's wave-span staging (per-wave LDS-DMA copy of the RF span a wave touches)
-	                                                 wherever the kernel supports it.  Never automatic: the gather loop with all gathers of a
-	                                                 transmit issued together is faster on every frame measured */
-	BeamformerHipDasPath_NoSpanStaging    = 0x80, /* flag: never (the gather loop: the default; the two give bit-identical frames) */
 	BeamformerHipDasPath_TileStaging      = 0x100,/* flag: das_tile.hip (factored kernel, block-wide LDS staging of cubic polynomials) wherever it is supported --
 	                                                 automatic on fine grids only */
 	BeamformerHipDasPath_NoTileStaging    = 0x200,/* flag: never */
@@ -296,7 +297,7 @@ typedef struct {
 	char     declined[8][160];      /* by path number: why that kernel does not run ("" for the one that does) */
 	uint32_t tile_shift[3], blocks[3], split_shift;      /* per-voxel kernels (general, factored): block shape and count */
 	uint32_t tile_walk;             /* 0 x,y,z; 1 z fastest; 2 y fastest; 3 view plane in XCD-balanced bands; staged kernels: + their flag bits */
-	uint32_t span_stage;            /* factored kernel: wave-span staging */
+	uint32_t row_end_planes;        /* planes of the shard the row-end rule hands to the kernel behind the staged one (BeamformerHipFrameTimings::das_row_end_planes) */
 	uint32_t tile_window_samples;   /* block-staged factored kernel (path 6): staged window length */
 	uint32_t u_axis, u_shift, v_shift, window_samples, uniform_tables, lds_bytes, threads, channel_chunk;   /* separable-delay kernels: the tile is 2^u_shift voxels
 	                                   along the receive axis (voxel axis u_axis) by 2^v_shift along the transmit axis, one plane thick */

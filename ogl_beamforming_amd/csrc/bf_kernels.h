@@ -64,8 +64,8 @@ typedef struct {
 	uint32_t zero_offset;             /* factored kernel: byte offset (from rf) of >= 32 zero bytes the host keeps
 	                                     behind the DAS input, the gather target of out-of-range lanes */
 	uint32_t tile_window_shift;       /* das_tile.hip: log2 of the staged window length (5 or 6) */
-	uint32_t span_stage;              /* factored kernel, IQ + linear / cubic: 1 = wave-span staging (every wave copies the span of
-	                                     each RF row its 64 voxels touch into its own LDS slot by LDS-DMA; coarse grids) */
+	float    edge_margin;             /* samples: a term whose index comes this close to an end of sample_rf's valid range is decided by the
+	                                     shader's own expression, evaluated exactly (das_exact.h); 2^-18 of the largest index magnitude */
 } BfDasArgs;
 
 /* tile geometry of the separable-delay fast path (das_separable.hip) */

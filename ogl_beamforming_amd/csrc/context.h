@@ -59,6 +59,7 @@ struct TimingSlot {
 	bool       counted = false;
 	uint64_t   frame_id = 0;
 	uint64_t   violations_slot = ~0ull;   /* staged kernels: index of this frame's window-violation counter, or ~0 */
+	uint32_t   das_row_end_planes = 0;    /* planes the row-end rule sent to the kernel behind the staged one */
 	bool       failed = false;            /* the push that owns this slot did not complete */
 };
 
@@ -72,8 +73,9 @@ struct PlanState {
 	std::vector<BfTransmit>   transmit_table;
 	std::vector<uint16_t>     readi_bits;
 	std::string  error;
-	DasDecision  das;                     /* the DAS kernel and geometry of this plan's frames (das_select.cpp), reused until the plan, the shard,
-	                                         the path mode or a hook changes */
+	std::vector<DasDecision> das_parts;   /* the DAS kernel(s) and geometry of this plan's frames (das_select.cpp: decide_das_parts), reused until
+	                                         the plan, the shard, the path mode or a hook changes */
+	uint32_t     das_z_first = 0, das_z_count = 0;
 };
 
 constexpr uint32_t kTimingSlots = 32;    /* beamformer_compute_stats.c: 32-frame table */

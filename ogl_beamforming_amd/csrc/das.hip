@@ -23,75 +23,7 @@
  *     with the argument reduced by v_fract (Q3 in oracle/oracle.h).
  * The gather-accumulate is memory/VALU bound: no MFMA.
  */
-#include "das_common.h"
-
-/* das.glsl:54-61 with the angle in turns, reduced to [0,1) */
-__device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const BfDasArgs &p)
-{
-	float turns = hw_fract(index * p.turns_per_sample);
-	float c = hw_cos_turns(turns), s = hw_sin_turns(turns);
-	return f32x2{c * iq.x - s * iq.y, s * iq.x + c * iq.y};
-}
-
-/* das.glsl:99-124 (+ cubic :67-97).  rf_offset is the element index of the row's sample 0.
- * The general kernel keeps the reference's test-then-load form: it runs at 8 waves per SIMD and
- * is VALU bound, so the extra select/clamp work of the branch-free form (das_common.h, used by
- * the fast path) costs more than the serialised gathers do. */
-template <int INTERP, bool CPLX>
-__device__ __forceinline__ sample_t<CPLX> sample_rf(const char *rf, int rf_offset, float index, const BfDasArgs &p)
-{
-	constexpr uint32_t ES = CPLX ? 8 : 4;
-	sample_t<CPLX> result = zero_sample<CPLX>();
-	const float S = (float)p.sample_count;
-	if constexpr (INTERP == BF_INTERP_NEAREST) {
-		if (index >= 0.f && index < S - 0.5f) {
-			int k = (int)__builtin_roundf(index);
-			result = gather<sample_t<CPLX>>(rf, (uint32_t)(rf_offset + k) * ES);
-			if constexpr (CPLX) result = rotate_iq(result, index, p);
-		}
-	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
-		/* 0 <= index < S-1  <=>  (unsigned)floor(index) < S-1: one convert and one compare */
-		uint32_t k = (uint32_t)cvt_floor_i32(index);
-		if (k < (uint32_t)(p.sample_count - 1)) {
-			float t = hw_fract(index);
-			uint32_t off = ((uint32_t)rf_offset + k) * ES;
-			if constexpr (CPLX) {
-				f32x4 v = gather<f32x4_a8>(rf, off);
-				f32x2 a = {v.x, v.y}, b = {v.z, v.w};
-				result = a + t * (b - a);
-				result = rotate_iq(result, index, p);
-			} else {
-				f32x2 v = gather<f32x2_a4>(rf, off);
-				result = v.x + t * (v.y - v.x);
-			}
-		}
-	} else {
-		/* 1 <= index < S-2  <=>  (unsigned)(floor(index) - 1) < S-3 */
-		uint32_t k = (uint32_t)(cvt_floor_i32(index) - 1);
-		if (k < (uint32_t)(p.sample_count - 3)) {
-			float t = hw_fract(index);
-			uint32_t off = ((uint32_t)rf_offset + k) * ES;
-			float t2 = t * t, t3 = t2 * t;
-			/* Hermite basis with tangents 0.5 (P2 - P0), 0.5 (P3 - P1) */
-			float b0 =  2.f * t3 - 3.f * t2 + 1.f;
-			float b1 = -2.f * t3 + 3.f * t2;
-			float b2 =        t3 - 2.f * t2 + t;
-			float b3 =        t3 -       t2;
-			if constexpr (CPLX) {
-				f32x4 lo = gather<f32x4_a8>(rf, off), hi = gather<f32x4_a8>(rf, off + 16);
-				f32x2 s0 = {lo.x, lo.y}, s1 = {lo.z, lo.w}, s2 = {hi.x, hi.y}, s3 = {hi.z, hi.w};
-				f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1);
-				result = b0 * s1 + b1 * s2 + b2 * T1 + b3 * T2;
-				result = rotate_iq(result, index, p);
-			} else {
-				f32x4 v = gather<f32x4_a4>(rf, off);
-				float T1 = 0.5f * (v.z - v.x), T2 = 0.5f * (v.w - v.y);
-				result = b0 * v.y + b1 * v.z + b2 * T1 + b3 * T2;
-			}
-		}
-	}
-	return result;
-}
+#include "das_exact.h"
 
 template <bool CPLX, bool CW, bool COUNT>
 struct Accumulator {
@@ -132,9 +64,23 @@ __device__ __forceinline__ float sample_index(float distance, const BfDasArgs &p
 	return (div_speed_of_sound(distance, p) + p.time_offset) * p.sampling_frequency;
 }
 
+/* A term at an end of its RF row (das_exact.h): this kernel's index -- hardware square root, fused multiply-adds -- may differ
+ * from the shader's by an ulp, and sample_rf's range test is a step.  Within p.edge_margin of either end the index is therefore
+ * formed again, exactly as the shader's text forms it; everything else about the term stays as it is.  (Nearest interpolation:
+ * the index decides the tap at every half-integer, not only at the row ends -- the parity tests budget those flips per voxel.) */
+template <int FAMILY, int INTERP>
+__device__ __forceinline__ float settle_index(float index, const BfDasArgs &p, uint32_t x, uint32_t y, uint32_t z, int channel, int transmit)
+{
+	if constexpr (INTERP != BF_INTERP_NEAREST) {
+		if (bfx::edge_near<INTERP>(index, p.sample_count, p.edge_margin))
+			index = bfx::exact_index<FAMILY>(p, bfx::exact_voxel<FAMILY>(p, x, y, z), channel, transmit);
+	}
+	return index;
+}
+
 /* das.glsl:204-231 */
 template <int INTERP, bool CPLX, bool CW, bool COUNT>
-__device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, float wx, float wy, float wz,
+__device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, float wx, float wy, float wz, uint32_t x, uint32_t y, uint32_t z,
                                         int ch0, int ch1, Accumulator<CPLX, CW, COUNT> &acc)
 {
 	float xx, xy, xz;
@@ -160,6 +106,7 @@ __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, floa
 				acc.pairs += pass;
 			} else if (pass) {
 				float sidx = sample_index(tx_dist + hw_sqrt(dx * dx + zz), p);
+				sidx = settle_index<BF_DAS_RCA, INTERP>(sidx, p, x, y, z, channel, acquisition);
 				acc.add(apodize(a_arg) * sample_rf<INTERP, CPLX>(rf, rf_offset, sidx, p));
 			}
 			rf_offset += S * A;
@@ -169,7 +116,7 @@ __device__ __forceinline__ void das_rca(const BfDasArgs &p, const char *rf, floa
 
 /* das.glsl:233-286 */
 template <int INTERP, bool CPLX, bool CW, bool COUNT>
-__device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf, float wx, float wy, float wz,
+__device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf, float wx, float wy, float wz, uint32_t x, uint32_t y, uint32_t z,
                                              int ch0, int ch1, Accumulator<CPLX, CW, COUNT> &acc)
 {
 	float xx, xy, xz;
@@ -205,6 +152,7 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 				const float weight = transmit == 0 ? p.first_transmit_weight : 1.0f;
 				float apodization = weight * apodize(f_number_over_z * hw_sqrt(element_delta_squared));
 				float index = transmit_index + div_speed_of_sound(hw_sqrt(z_delta_squared + element_delta_squared) * p.sampling_frequency, p);   /* das.glsl:277 */
+				index = settle_index<BF_DAS_HERCULES, INTERP>(index, p, x, y, z, channel, transmit);
 				acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 			}
 			rf_offset += S;
@@ -215,7 +163,7 @@ __device__ __forceinline__ void das_hercules(const BfDasArgs &p, const char *rf,
 /* das.glsl:288-321 and :323-366.  (wx, wy, wz) is already in transducer space: the host
  * pre-multiplies the voxel transform (beamformer_core.c:913-915). */
 template <int INTERP, bool CPLX, bool CW, bool COUNT, bool READI>
-__device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, float xx, float xy, float xz,
+__device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, float xx, float xy, float xz, uint32_t x, uint32_t y, uint32_t z,
                                            int ch0, int ch1, Accumulator<CPLX, CW, COUNT> &acc)
 {
 	const int S = p.sample_count, A = p.acquisition_count, C = p.channel_count;
@@ -244,7 +192,8 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 					float tx_channel       = sparse ? (float)p.sparse_elements[transmit - sparse] : (float)transmit;
 					float transmit_x_delta = xx - p.pitch[0] * tx_channel;
 					float transmit_index   = div_speed_of_sound(hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * p.sampling_frequency, p);
-					acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, receive_index + transmit_index, p));
+					const float index = settle_index<BF_DAS_FORCES, INTERP>(receive_index + transmit_index, p, x, y, z, channel, transmit);
+					acc.add(apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 				}
 				rf_offset += S;
 			}
@@ -261,7 +210,8 @@ __device__ __forceinline__ void das_forces(const BfDasArgs &p, const char *rf, f
 						float tx_element       = (float)tx_group * (float)A + (float)tx_event;
 						float transmit_x_delta = xx - p.pitch[0] * tx_element;
 						float transmit_index   = div_speed_of_sound(hw_sqrt(transmit_yz_squared + transmit_x_delta * transmit_x_delta) * p.sampling_frequency, p);
-						acc.add(group_apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, receive_index + transmit_index, p));
+						const float index = settle_index<BF_DAS_READI, INTERP>(receive_index + transmit_index, p, x, y, z, channel, tx_group * A + tx_event);
+						acc.add(group_apodization * sample_rf<INTERP, CPLX>(rf, rf_offset, index, p));
 					}
 					rf_offset += S;
 				}
@@ -340,10 +290,10 @@ __global__ __launch_bounds__(BF_DAS_MAX_THREADS) void das_kernel(const BfDasArgs
 		const int ch0 = (int)split * per;
 		const int ch1 = ch0 + per < C ? ch0 + per : C;
 
-		if constexpr (FAMILY == BF_DAS_RCA)           das_rca<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, ch0, ch1, acc);
-		else if constexpr (FAMILY == BF_DAS_HERCULES) das_hercules<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, ch0, ch1, acc);
-		else if constexpr (FAMILY == BF_DAS_FORCES)   das_forces<INTERP, CPLX, CW, COUNT, false>(p, rf, wx, wy, wz, ch0, ch1, acc);
-		else                                          das_forces<INTERP, CPLX, CW, COUNT, true>(p, rf, wx, wy, wz, ch0, ch1, acc);
+		if constexpr (FAMILY == BF_DAS_RCA)           das_rca<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, x, y, z, ch0, ch1, acc);
+		else if constexpr (FAMILY == BF_DAS_HERCULES) das_hercules<INTERP, CPLX, CW, COUNT>(p, rf, wx, wy, wz, x, y, z, ch0, ch1, acc);
+		else if constexpr (FAMILY == BF_DAS_FORCES)   das_forces<INTERP, CPLX, CW, COUNT, false>(p, rf, wx, wy, wz, x, y, z, ch0, ch1, acc);
+		else                                          das_forces<INTERP, CPLX, CW, COUNT, true>(p, rf, wx, wy, wz, x, y, z, ch0, ch1, acc);
 	}
 
 	if constexpr (!COUNT) {

@@ -232,4 +232,73 @@ __device__ __forceinline__ sample_t<CPLX> interpolate(const char *rf, uint32_t r
 	return tap_finish<INTERP, CPLX>(tap, d);
 }
 
+/* das.glsl:54-61 with the angle in turns, reduced to [0,1) */
+template <typename P>
+__device__ __forceinline__ f32x2 rotate_iq(f32x2 iq, float index, const P &p)
+{
+	float turns = hw_fract(index * p.turns_per_sample);
+	float c = hw_cos_turns(turns), s = hw_sin_turns(turns);
+	return f32x2{c * iq.x - s * iq.y, s * iq.x + c * iq.y};
+}
+
+/* das.glsl:99-124 (+ cubic :67-97), with the IQ rotation.  rf_offset is the element index of the row's sample 0.
+ * The reference's test-then-load form: what the general kernel (das.hip) runs -- at 8 waves per SIMD and VALU bound, the extra
+ * select / clamp work of the branch-free form above costs it more than the serialised gathers do -- and what the row-end
+ * fix-up of every fast kernel evaluates its few terms with (das_exact.h). */
+template <int INTERP, bool CPLX, typename P>
+__device__ __forceinline__ sample_t<CPLX> sample_rf(const char *rf, int rf_offset, float index, const P &p)
+{
+	constexpr uint32_t ES = CPLX ? 8 : 4;
+	sample_t<CPLX> result = zero_sample<CPLX>();
+	const float S = (float)p.sample_count;
+	if constexpr (INTERP == BF_INTERP_NEAREST) {
+		if (index >= 0.f && index < S - 0.5f) {
+			int k = (int)__builtin_roundf(index);
+			result = gather<sample_t<CPLX>>(rf, (uint32_t)(rf_offset + k) * ES);
+			if constexpr (CPLX) result = rotate_iq(result, index, p);
+		}
+	} else if constexpr (INTERP == BF_INTERP_LINEAR) {
+		/* 0 <= index < S-1  <=>  (unsigned)floor(index) < S-1: one convert and one compare */
+		uint32_t k = (uint32_t)cvt_floor_i32(index);
+		if (k < (uint32_t)(p.sample_count - 1)) {
+			float t = hw_fract(index);
+			uint32_t off = ((uint32_t)rf_offset + k) * ES;
+			if constexpr (CPLX) {
+				f32x4 v = gather<f32x4_a8>(rf, off);
+				f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+				result = a + t * (b - a);
+				result = rotate_iq(result, index, p);
+			} else {
+				f32x2 v = gather<f32x2_a4>(rf, off);
+				result = v.x + t * (v.y - v.x);
+			}
+		}
+	} else {
+		/* 1 <= index < S-2  <=>  (unsigned)(floor(index) - 1) < S-3 */
+		uint32_t k = (uint32_t)(cvt_floor_i32(index) - 1);
+		if (k < (uint32_t)(p.sample_count - 3)) {
+			float t = hw_fract(index);
+			uint32_t off = ((uint32_t)rf_offset + k) * ES;
+			float t2 = t * t, t3 = t2 * t;
+			/* Hermite basis with tangents 0.5 (P2 - P0), 0.5 (P3 - P1) */
+			float b0 =  2.f * t3 - 3.f * t2 + 1.f;
+			float b1 = -2.f * t3 + 3.f * t2;
+			float b2 =        t3 - 2.f * t2 + t;
+			float b3 =        t3 -       t2;
+			if constexpr (CPLX) {
+				f32x4 lo = gather<f32x4_a8>(rf, off), hi = gather<f32x4_a8>(rf, off + 16);
+				f32x2 s0 = {lo.x, lo.y}, s1 = {lo.z, lo.w}, s2 = {hi.x, hi.y}, s3 = {hi.z, hi.w};
+				f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1);
+				result = b0 * s1 + b1 * s2 + b2 * T1 + b3 * T2;
+				result = rotate_iq(result, index, p);
+			} else {
+				f32x4 v = gather<f32x4_a4>(rf, off);
+				float T1 = 0.5f * (v.z - v.x), T2 = 0.5f * (v.w - v.y);
+				result = b0 * v.y + b1 * v.z + b2 * T1 + b3 * T2;
+			}
+		}
+	}
+	return result;
+}
+
 #endif

@@ -25,25 +25,8 @@
  * for any lane of the wave is skipped.  Summation order differs from the shader's (per channel
  * over transmits, then over channels): results agree to float rounding, tests state the
  * tolerance.  Channel split for small frames as in das.hip.
- *
- * WAVE-SPAN STAGING (template parameter SPAN, round 3; IQ samples, linear / cubic).  On a COARSE grid -- the
- * reference harness's own 512 x 1024 view plane has 0.23 mm pixels, 1.5 samples of delay per voxel along x -- the
- * 64 lanes of a gather instruction land in 64 different places of an RF row: the texture path serves such a wave
- * in ~25 clocks instead of 16 and a cubic term needs two (rocprofv3: 210 clocks per wave-term per SIMD, VALU 57 %
- * busy).  But the span a wave touches is short: for one (channel, transmit) row the indices of its 64 voxels lie
- * within [min R + min T, max R + max T], ~30-100 samples.  So the wave copies that span -- ONE coalesced
- * 1 KB LDS-DMA load (`buffer_load_dwordx4 ... lds`: 128 samples, no VGPR, no address arithmetic: the row and the
- * window start are scalars) -- into its own LDS slot and every lane reads its taps from there (4 x ds_read_b64 for
- * Catmull-Rom).  No block barrier: the slot is the wave's own; the loads of transmit a + 1 are in flight while
- * transmit a is consumed (two buffers of CH slots, counted s_waitcnt).  The window start is exact, not estimated:
- * per channel the wave reduces min / max of the receive index over the lanes inside the aperture, per transmit
- * (once per wave, kept in LDS) the floor of the minimum transmit index; a chunk whose spread does not fit 128
- * samples takes the gather loop instead, so nothing depends on a host-side bound.  Same arithmetic as the gather
- * loop: frames are bit-identical (tests/test_gpu_parity.py).  On request only (das path flag 0x40) since the end of
- * round 3: with all gathers of a transmit issued before the first is consumed (BF_ALL_GATHERS_ISSUED below) the
- * gather loop itself runs the harness planes at 15.7-17.0 ms against 17.3-20.1 with span staging.
  */
-#include "das_common.h"
+#include "das_exact.h"
 
 /* channels per register-resident chunk.  Measured on MI355X (config 4 geometry, 64 planes):
  * 2 -> 172 ms, 4 -> 160, 6 -> 154, 8 -> 154 with spills; cubic holds twice the gather data
@@ -56,11 +39,6 @@
 #define BF_ALL_GATHERS_ISSUED() __builtin_amdgcn_sched_barrier(0)
 #define BF_FACTORED_CHUNK(interp) ((interp) == BF_INTERP_LINEAR ? 6 : 4)
 #endif
-/* ... and per chunk of the wave-span variant (its loop waits for LDS-DMA and LDS reads, not for gathers: occupancy counts) */
-#ifndef BF_SPAN_CHUNK
-#define BF_SPAN_CHUNK(interp) ((interp) == BF_INTERP_LINEAR ? 6 : 4)
-#endif
-
 namespace {
 
 template <bool CPLX, bool CW>
@@ -68,7 +46,6 @@ struct ChannelFactor {
 	float index;           /* receive part of the sample index; -1e9 when the channel fails the f-number test */
 	float re, im;          /* apod * e^{j phi(R)} (CPLX) -- re alone holds apod for real data */
 	float apod;            /* for the incoherent sum */
-	float spare;           /* wave-span staging, unchecked loop: the index with lanes outside the aperture parked inside the window */
 };
 
 /* das.glsl:187-202 with the per-transmit constants precomputed (same as das.hip) */
@@ -87,36 +64,11 @@ __device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx
 	return result;
 }
 
-/* wave-wide minimum / maximum as scalars (DPP row shifts: 4 VALU ops + 4 v_readlane, no LDS) */
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)       /* lanes with no source lane keep their own value */
-{
-	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-template <bool MAX>
-__device__ __forceinline__ float wave_extreme(float v)
-{
-	auto pick = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
-	v = pick(v, dpp_f<0x111>(v));      /* row_shr:1 */
-	v = pick(v, dpp_f<0x112>(v));      /* row_shr:2 */
-	v = pick(v, dpp_f<0x114>(v));      /* row_shr:4 */
-	v = pick(v, dpp_f<0x118>(v));      /* row_shr:8: lane 15 of every row of 16 holds the row's extreme */
-	float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
-	float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
-	float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
-	float r4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-	return pick(pick(r1, r2), pick(r3, r4));
-}
-
-constexpr uint32_t kSpanSamples = 128;                      /* one LDS-DMA wave instruction: 64 lanes x 16 bytes */
-constexpr uint32_t kSpanSlotBytes = kSpanSamples * 8;
-
-template <int FAMILY, int INTERP, bool CPLX, bool CW, bool SPAN = false>
+template <int FAMILY, int INTERP, bool CPLX, bool CW>
 __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 {
-	constexpr int      CH = SPAN ? BF_SPAN_CHUNK(INTERP) : BF_FACTORED_CHUNK(INTERP);
+	constexpr int      CH = BF_FACTORED_CHUNK(INTERP);
 	constexpr uint32_t ES = CPLX ? 8 : 4;
-	static_assert(!SPAN || (CPLX && INTERP != BF_INTERP_NEAREST), "wave-span staging: linear or cubic interpolation of IQ samples");
 	extern __shared__ __attribute__((aligned(16))) unsigned char factored_lds[];
 
 	/* blockIdx -> tile and thread -> voxel exactly as das.hip */
@@ -157,16 +109,6 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 	uint32_t y = (by << p.tile_shift[1]) + ly;
 	uint32_t zl = (bz << p.tile_shift[2]) + lz;
 	bool inside = x < p.size[0] && y < p.size[1] && zl < p.z_count;
-	[[maybe_unused]] const bool store = inside;
-	if constexpr (SPAN) {
-		/* the LDS-DMA loads and the wave reductions need every lane: lanes outside the grid repeat its last voxel (and
-		 * store nothing); a wave with no voxel at all leaves (SPAN launches have no channel split, hence no barrier) */
-		if (__builtin_amdgcn_ballot_w64(inside) == 0) return;
-		x = x < p.size[0] ? x : p.size[0] - 1u;
-		y = y < p.size[1] ? y : p.size[1] - 1u;
-		zl = zl < p.z_count ? zl : p.z_count - 1u;
-		inside = true;
-	}
 
 	sample_t<CPLX> coherent = zero_sample<CPLX>();
 	float          incoherent = 0.f;
@@ -238,32 +180,32 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			}
 		};
 
-		/* SPAN: this wave's LDS -- 64 zero bytes (where invalid taps read), floor(min over the lanes of the transmit index) per
-		 * transmit, two buffers of CH one-KB slots */
-		[[maybe_unused]] uint32_t span_lds = 0, span_tfloor = 0, span_slots = 0;
-		[[maybe_unused]] int span_tspread = 0;
-		[[maybe_unused]] float span_tlo = 0.f, span_thi = 0.f;       /* extremes of the transmit index over the wave's lanes and all transmits */
-		if constexpr (SPAN) {
-			const uint32_t A_pad = ((uint32_t)A + 15u) & ~15u;
-			const uint32_t per_wave = 64u + 4u * A_pad + 2u * CH * kSpanSlotBytes;
-			span_lds    = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)factored_lds +
-			              (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * per_wave;
-			span_tfloor = span_lds + 64u;
-			span_slots  = span_tfloor + 4u * A_pad;
-			const uint32_t lane = tid & 63u;
-			if (lane < 16u) *(__attribute__((address_space(3))) float *)(uintptr_t)(span_lds + 4u * lane) = 0.f;
-			float spread = 0.f;
-			span_tlo = __builtin_inff(); span_thi = -__builtin_inff();
+		/* the receive part of the sample index of channel `channel` for this lane's voxel (RCA: the time offset rides with the transmit
+		 * term; FORCES: with the receive term -- sample_index, das.glsl:126-130).  One function, explicit fmas: the row-end pass at the end
+		 * of the kernel forms the same value again, bit for bit */
+		auto receive_index = [&](int channel, float &dx) -> float {
+			dx = __builtin_fmaf(-(float)channel, pitch, lateral);
+			const float dist = hw_sqrt(__builtin_fmaf(dx, dx, zz));
+			return FAMILY == BF_DAS_RCA ? div_speed_of_sound(dist, p) * p.sampling_frequency
+			                            : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
+		};
+
+		/* Row ends (das_exact.h).  This kernel's index is a rounded receive term plus a rounded transmit term: within p.edge_margin of an
+		 * end of sample_rf's valid range it is not trusted to decide keep-or-drop.  One pass over the transmits gives the lane the
+		 * extremes of its transmit term; a chunk in which no lane of the wave can come that close to an end for any transmit (nearly
+		 * every chunk of nearly every frame) runs the loops below as they are; otherwise the EDGE forms of the same loops leave the terms
+		 * inside the margin out, and a pass at the END of the kernel (its registers are not the loops') evaluates those with the shader's
+		 * own index. */
+		constexpr bool EDGES = INTERP != BF_INTERP_NEAREST;      /* (nearest flips at every half-integer: budgeted per voxel by the tests) */
+		const float edge_margin = p.edge_margin;
+		float t_lo = 0.f, t_hi = 0.f;
+		unsigned long long edge_lanes = 0;                       /* lanes of this wave with a term left out (a scalar) */
+		if constexpr (EDGES) {
+			t_lo = __builtin_inff(); t_hi = -__builtin_inff();
 			for (int a = first_transmit; a < A; a++) {
-				const float t  = transmit_index(a);
-				const float tmin = wave_extreme<false>(t), tmax = wave_extreme<true>(t);
-				const float lo = __builtin_floorf(tmin), hi = __builtin_floorf(tmax);
-				if (lane == 0) *(__attribute__((address_space(3))) int *)(uintptr_t)(span_tfloor + 4u * (uint32_t)a) = (int)lo;
-				spread = fmaxf(spread, hi - lo);
-				span_tlo = fminf(span_tlo, tmin); span_thi = fmaxf(span_thi, tmax);
+				const float t = transmit_index(a);
+				t_lo = fminf(t_lo, t); t_hi = fmaxf(t_hi, t);
 			}
-			span_tspread = spread < 1.0e6f ? (int)spread : 1000000;       /* (wave uniform; a NaN index never fits) */
-			if (!(spread == spread)) span_tspread = 1000000;
 		}
 
 		for (int c0 = ch_begin; c0 < ch_end; c0 += CH) {
@@ -272,14 +214,10 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			#pragma unroll
 			for (int k = 0; k < CH; k++) {
 				int   channel = c0 + k;
-				float dx      = lateral - (float)channel * pitch;
+				float dx;
+				float index   = receive_index(channel, dx);
 				float a_arg   = __builtin_fabsf(dx * f_over_z);
 				bool  pass    = a_arg < 0.5f && channel < ch_end;
-				float dist    = hw_sqrt(dx * dx + zz);
-				/* RCA: the time offset rides with the transmit term; FORCES: with the receive term
-				 * (sample_index, das.glsl:126-130) */
-				float index   = FAMILY == BF_DAS_RCA ? div_speed_of_sound(dist, p) * p.sampling_frequency
-				                                     : (div_speed_of_sound(dist, p) + p.time_offset) * p.sampling_frequency;
 				float apod    = pass ? apodize(a_arg) : 0.f;
 				R[k].index = pass ? index : -1.0e9f;
 				R[k].apod  = apod;
@@ -293,6 +231,15 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				any |= pass;
 			}
 			if (!__builtin_amdgcn_ballot_w64(any)) continue;          /* wave-uniform */
+			bool edges = false;                                       /* wave-uniform: some lane of the wave can come within the margin of a row end in this chunk */
+			if constexpr (EDGES) {
+				bool lane_safe = true;
+				#pragma unroll
+				for (int k = 0; k < CH; k++)
+					lane_safe = lane_safe && (R[k].index < -1.0e8f || (R[k].index + t_lo >= bfx::edge_lo<INTERP>() + edge_margin &&
+					                                                   R[k].index + t_hi <  bfx::edge_hi<INTERP>(S) - edge_margin));
+				edges = __builtin_amdgcn_ballot_w64(!lane_safe) != 0ull;
+			}
 
 			sample_t<CPLX> part[CH];
 			float          part_abs[CH];
@@ -306,147 +253,9 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			#pragma unroll
 			for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; }
 
-			/* ---- wave-span staging: the taps of this chunk come out of the wave's LDS slots */
-			bool span_done = false;
-			if constexpr (SPAN) {
-				int  rfl[CH], rsp[CH];
-				bool fits = true, safe = true;
-				#pragma unroll
-				for (int k = 0; k < CH; k++) {
-					const bool  pass = R[k].index > -1.0e8f;
-					const float lo = wave_extreme<false>(pass ? R[k].index :  __builtin_inff());
-					const float hi = wave_extreme<true >(pass ? R[k].index : -__builtin_inff());
-					const bool  on = lo <= hi;                           /* some lane of the wave is inside this channel's aperture */
-					const float flo = __builtin_floorf(lo);
-					rfl[k] = on ? (int)flo : 0;
-					rsp[k] = on ? (int)(__builtin_floorf(hi) - flo) : 0;
-					/* taps floor - 1 .. floor + 2 of every lane inside [window start, + 128): receive spread + the wave's largest
-					 * transmit spread + 6 (two floors, the sum's rounding, the taps) */
-					fits = fits && (!on || (__builtin_floorf(hi) - flo) + (float)span_tspread <= (float)(kSpanSamples - 7));
-					/* no lane inside the aperture can leave the RF row for any transmit (one sample of margin for the sum's rounding):
-					 * the loop then runs without the range test of sample_rf, and lanes OUTSIDE the aperture -- their weight is zero
-					 * and stays zero -- take the index of one inside it instead of being steered to the zero block */
-					safe = safe && on && lo + span_tlo >= (INTERP == BF_INTERP_CUBIC ? 2.0f : 1.0f) &&
-					       hi + span_thi < (float)(S - (INTERP == BF_INTERP_CUBIC ? 3 : 2));      /* (a chunk with a channel NO lane uses: checked loop) */
-					if (on && !pass) R[k].spare = lo;
-					else             R[k].spare = R[k].index;
-				}
-				if (fits && S >= (int)kSpanSamples) {
-					const uint32_t lane16 = (tid & 63u) * 16u;
-					const uint32_t chunk_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)c0 * (uint32_t)A) * (uint32_t)S * ES));
-					int ws[CH], ws_next[CH];
-					/* lanes that load: 2 samples each.  The unchecked loop needs exactly [window start, + spread + taps): lanes beyond it are
-					 * switched off for the load (the texture path charges a wave's LDS-DMA by its bytes), and its window is not clamped into the
-					 * row -- what it may hold of a neighbouring row is never read.  The checked loop loads all 128 samples of a clamped window. */
-					unsigned long long lanes_on[CH];
-					#pragma unroll
-					for (int k = 0; k < CH; k++) {
-						int need = safe ? (rsp[k] + span_tspread + 8) / 2 : 64;
-						need = need < 1 ? 1 : (need > 64 ? 64 : need);
-						lanes_on[k] = need >= 64 ? ~0ull : ((1ull << need) - 1ull);
-					}
-					typedef int i32x4 __attribute__((ext_vector_type(4)));
-					/* buffer resource over the whole DAS input, by hand for the asm statement: base, stride 0, bytes, raw 32-bit data format */
-					const uint64_t rf_address = (uint64_t)(uintptr_t)p.rf;
-					const i32x4 rsrc_words = {__builtin_amdgcn_readfirstlane((int)(uint32_t)rf_address), __builtin_amdgcn_readfirstlane((int)((uint32_t)(rf_address >> 32) & 0xffffu)),
-					                          __builtin_amdgcn_readfirstlane((int)((uint32_t)C * (uint32_t)A * (uint32_t)S * ES)), 0x00020000};
-					auto issue = [&](int a, int buf, int (&ws_out)[CH]) {
-						const int tf = __builtin_amdgcn_readfirstlane(*(__attribute__((address_space(3))) int *)(uintptr_t)(span_tfloor + 4u * (uint32_t)a));
-						#pragma unroll
-						for (int k = 0; k < CH; k++) {
-							int w = rfl[k] + tf - 2;
-							if (!safe) w = w < 0 ? 0 : (w > S - (int)kSpanSamples ? S - (int)kSpanSamples : w);
-							ws_out[k] = w;
-							/* rows past the last channel lie behind the buffer: the DMA writes zeros, nobody reads them (a channel no lane
-							 * of the wave uses is loaded all the same: the counted wait below wants CH loads per transmit) */
-							const uint32_t soff = chunk_rows + ((uint32_t)k * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES + (uint32_t)w * ES;
-							const uint32_t dst  = span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes;
-							uint32_t keep_m0;
-							/* M0 = LDS address of the slot; EXEC = the lanes that load; both restored (the kernel runs with every lane on here) */
-							asm volatile("s_mov_b32 %0, m0\n\t"
-							             "s_mov_b32 m0, %1\n\t"
-							             "s_mov_b64 exec, %2\n\t"
-							             "s_nop 0\n\t"
-							             "buffer_load_dwordx4 %3, %4, %5 offen lds\n\t"
-							             "s_mov_b64 exec, -1\n\t"
-							             "s_mov_b32 m0, %0"
-							             : "=&s"(keep_m0) : "s"(dst), "s"(lanes_on[k]), "v"(lane16), "s"(rsrc_words), "s"(soff) : "memory");
-						}
-					};
-					typedef __attribute__((address_space(3))) f32x2 lds2;
-					auto consume = [&](auto checked, int buf, float t_index, f32x2 cs) {
-						constexpr bool CHECK = decltype(checked)::value;
-						float frac[CH]; uint32_t at[CH];
-						#pragma unroll
-						for (int k = 0; k < CH; k++) {
-							const float index = t_index + (CHECK ? R[k].index : R[k].spare);
-							frac[k] = hw_fract(index);
-							const uint32_t ki = (uint32_t)(cvt_floor_i32(index) - (INTERP == BF_INTERP_CUBIC ? 1 : 0));
-							const uint32_t slot = span_slots + (uint32_t)(buf * CH + k) * kSpanSlotBytes;
-							if constexpr (CHECK) {
-								/* valid: 0 <= index < S - 1 (linear), 1 <= index < S - 2 (cubic); inside the staged window by construction
-								 * (the second test only keeps a violated bound from reading a neighbour's slot) */
-								const uint32_t rel = ki - (uint32_t)ws[k];
-								const bool ok = ki < (uint32_t)(INTERP == BF_INTERP_CUBIC ? S - 3 : S - 1) && rel <= kSpanSamples - (INTERP == BF_INTERP_CUBIC ? 4u : 2u);
-								at[k] = ok ? slot + rel * ES : span_lds;
-							} else {
-								at[k] = (ki << 3) + (slot - (uint32_t)ws[k] * ES);   /* one v_lshl_add_u32: the bracket is a scalar */
-							}
-						}
-						/* every read of the batch is issued before the first is consumed */
-						if constexpr (INTERP == BF_INTERP_LINEAR) {
-							f32x2 s0[CH], s1[CH];
-							#pragma unroll
-							for (int k = 0; k < CH; k++) { s0[k] = *(lds2 *)(uintptr_t)at[k]; s1[k] = *(lds2 *)(uintptr_t)(at[k] + 8u); }
-							#pragma unroll
-							for (int k = 0; k < CH; k++) {
-								f32x2 sv = s0[k] + frac[k] * (s1[k] - s0[k]);
-								acc1[k] += sv.x * cs;
-								acc2[k] += sv.y * cs;
-								if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
-							}
-						} else {
-							f32x2 q0[CH], q1[CH], q2[CH], q3[CH];
-							#pragma unroll
-							for (int k = 0; k < CH; k++) {
-								q0[k] = *(lds2 *)(uintptr_t)at[k];          q1[k] = *(lds2 *)(uintptr_t)(at[k] + 8u);
-								q2[k] = *(lds2 *)(uintptr_t)(at[k] + 16u);  q3[k] = *(lds2 *)(uintptr_t)(at[k] + 24u);
-							}
-							#pragma unroll
-							for (int k = 0; k < CH; k++) {
-								f32x2 T1 = 0.5f * (q2[k] - q0[k]), T2 = 0.5f * (q3[k] - q1[k]), D = q2[k] - q1[k];
-								f32x2 c3 = (T1 + T2) - 2.0f * D;
-								f32x2 c2 = (D - T1) - c3;
-								float t  = frac[k];
-								f32x2 sv = q1[k] + t * (T1 + t * (c2 + t * c3));
-								acc1[k] += sv.x * cs;
-								acc2[k] += sv.y * cs;
-								if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
-							}
-						}
-					};
-					issue(first_transmit, 0, ws);
-					for (int a = first_transmit; a < A; a++) {
-						const int buf = (a - first_transmit) & 1;
-						const bool more = a + 1 < A;
-						if (more) issue(a + 1, buf ^ 1, ws_next);
-						float t_index = transmit_index(a);
-						asm volatile("" : "+v"(t_index));       /* as in the gather loop: the index is a SUM of two rounded terms, not an fma */
-						const float turns = hw_fract(turns_per_sample * t_index);
-						const f32x2 cs = {hw_cos_turns(turns), hw_sin_turns(turns)};
-						/* the CH loads of transmit a + 1 may stay in flight; everything older has landed */
-						if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory");
-						else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-						if (safe) consume(std::false_type{}, buf, t_index, cs);
-						else      consume(std::true_type{},  buf, t_index, cs);
-						#pragma unroll
-						for (int k = 0; k < CH; k++) ws[k] = ws_next[k];
-					}
-					span_done = true;
-				}
-			}
-
-			for (int a = first_transmit; a < A && !span_done; a++) {
+			auto transmit_loop = [&](auto edge_c) {
+			constexpr bool EDGE = decltype(edge_c)::value;      /* leave out (and note) the terms within the margin of a row end */
+			for (int a = first_transmit; a < A; a++) {
 				float t_index = transmit_index(a);
 				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
 				float tc = 1.f, ts = 0.f;
@@ -474,6 +283,11 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						} else {
 							uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
 							off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+						}
+						if constexpr (EDGE) {
+							const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin) && R[k].index > -1.0e8f;
+							edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
+							off[k] = edge ? p.zero_offset : off[k];
 						}
 					}
 					if constexpr (INTERP == BF_INTERP_LINEAR) {
@@ -515,7 +329,15 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				Tap<INTERP>           tap[CH];
 				TapData<INTERP, CPLX> data[CH];
 				#pragma unroll
-				for (int k = 0; k < CH; k++) tap[k] = tap_setup<INTERP, CPLX>(t_index + R[k].index, Sf, last);
+				for (int k = 0; k < CH; k++) {
+					float index = t_index + R[k].index;
+					if constexpr (EDGE) {
+						const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin) && R[k].index > -1.0e8f;
+						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
+						index = edge ? -8.0f : index;                                 /* outside every mode's range: zero weights */
+					}
+					tap[k] = tap_setup<INTERP, CPLX>(index, Sf, last);
+				}
 				#pragma unroll
 				for (int k = 0; k < CH; k++) {
 					/* rows past the last channel of a ragged chunk are not read: their weights are
@@ -536,6 +358,13 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 					}
 				}
 			}
+			};
+			if constexpr (EDGES) {
+				if (edges) transmit_loop(std::true_type{});
+				else       transmit_loop(std::false_type{});
+			} else {
+				transmit_loop(std::false_type{});
+			}
 
 			#pragma unroll
 			for (int k = 0; k < CH; k++) {
@@ -547,6 +376,28 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 					coherent += R[k].re * part[k];
 				}
 				if constexpr (CW) incoherent += R[k].apod * part_abs[k];
+			}
+		}
+
+		if constexpr (EDGES) {
+			if (edge_lanes != 0ull) {
+				/* ---- row ends: the terms the loops above left out.  The same sum of the same two rounded terms (receive_index,
+				 * transmit_index), so the same terms; each evaluated from the voxel's integer coordinates with the shader's own
+				 * index (das_exact.h) and added to the voxel's sums.  Rare: a wave gets here only if one of its lanes had such a term. */
+				for (int channel = ch_begin; channel < ch_end; channel++) {
+					float dx;
+					const float r_index = receive_index(channel, dx);
+					const bool  pass = __builtin_fabsf(dx * f_over_z) < 0.5f;
+					const bool  reach = pass && !(r_index + t_lo >= bfx::edge_lo<INTERP>() + edge_margin && r_index + t_hi < bfx::edge_hi<INTERP>(S) - edge_margin);
+					if (__builtin_amdgcn_ballot_w64(reach) == 0ull) continue;
+					for (int a = first_transmit; a < A; a++) {
+						float t_index = transmit_index(a);
+						asm volatile("" : "+v"(t_index));
+						const float index = t_index + r_index;
+						if (pass && bfx::edge_near<INTERP>(index, S, edge_margin))
+							bfx::edge_term<FAMILY, INTERP, CPLX, CW>(bfx::kernel_args(), x, y, p.z_first + zl, channel, a, coherent, incoherent);
+					}
+				}
 			}
 		}
 	}
@@ -571,7 +422,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		}
 	}
 
-	if (SPAN ? store : inside) {
+	if (inside) {
 		uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
 		sample_t<CPLX> v = coherent;
 		if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
@@ -586,18 +437,6 @@ hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
 	uint32_t grid    = a->depth_major == 3u ? bf_plane_walk_blocks(a->blocks[0], a->blocks[1], a->band_rows) : ((total + 7u) / 8u) * 8u;
 	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
 	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
-	if constexpr (CPLX && INTERP != BF_INTERP_NEAREST) {
-		if (a->span_stage && !a->split_shift) {
-			/* per wave: the zero block, one floor per transmit, two buffers of CH slots */
-			constexpr uint32_t CH = BF_SPAN_CHUNK(INTERP);
-			const uint32_t per_wave = 64u + 4u * (((uint32_t)a->acquisition_count + 15u) & ~15u) + 2u * CH * kSpanSlotBytes;
-			auto kernel = das_factored_kernel<FAMILY, INTERP, CPLX, CW, true>;
-			hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u * per_wave));
-			if (e != hipSuccess) return e;
-			hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 4u * per_wave, s, *a);
-			return hipGetLastError();
-		}
-	}
 	hipLaunchKernelGGL((das_factored_kernel<FAMILY, INTERP, CPLX, CW>), dim3(grid), dim3(threads), lds, s, *a);
 	return hipGetLastError();
 }

@@ -5,8 +5,7 @@
  *   gather      das_separable.hip  row-column frames whose receive and transmit delays separate over the tile axes (plan_separable)
  *   staged      das_staged*.hip    ... and whose delay spread provably fits an LDS window (plan_staged), from kStagedMinTransmits
  *   hercules    das_hercules.hip   HERCULES family on array-aligned grids, volumes and view planes (plan_hercules)
- *   factored    das_factored.hip   any frame whose index is a receive term plus a transmit term (factored_applies); with wave-span
- *                                  staging on coarse grids
+ *   factored    das_factored.hip   any frame whose index is a receive term plus a transmit term (factored_applies)
  */
 #include "das_select.h"
 #include "host_math.h"
@@ -584,6 +583,14 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	a.first_transmit_weight  = 1.0f / sqrtf((float)A);
 	a.time_offset = plan.das_time_offset;
 	a.f_number    = bp.f_number;
+	/* das_exact.h: how close to an end of an RF row a kernel may still trust its own index.  The index is a sum of terms of magnitude
+	 * up to M = S + |t0 fs| (distance terms and the time offset), each rounded a few times on its way: the kernels' indices and the
+	 * shader's differ by <~ 10 ulp(M) = M 2^-19.7.  The margin is M 2^-18 (2^-9 sample for 512-sample rows, 2^-7 for 2048), never under 2^-10. */
+	{
+		const float magnitude = (float)Sd + std::fabs(plan.das_time_offset * plan.das_sampling_frequency);
+		a.edge_margin = std::fmax(std::ldexp(magnitude, -18), std::ldexp(1.0f, -10));
+		if (!(a.edge_margin < 0.25f)) a.edge_margin = 0.25f;        /* (wild parameters; also a NaN) */
+	}
 	a.size[0] = plan.output_points[0]; a.size[1] = plan.output_points[1]; a.size[2] = plan.output_points[2];
 	a.z_first = zfirst; a.z_count = zcount;
 	a.readi_group_count = bp.readi_group_count; a.readi_group = bp.readi_group;
@@ -753,31 +760,6 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 			                  : (mode & 0x200) ? "das path flag 0x200: no block staging"
 			                  : "coarse grid or steep delays: a 64 x 16-voxel tile's estimated spread exceeds a 64-sample window";
 		}
-		/* wave-span staging (das_factored.hip): per-wave LDS-DMA copies of the RF span a wave touches, built for COARSE grids -- a voxel step
-		 * along x of a sample of delay or more, as the reference harness's 0.23 mm pixels have (tests/throughput.c:20-23).  It measured
-		 * 0.90-0.93 of the gather loop's time there while hipcc interleaved that loop's gathers with their arithmetic; with all gathers of a
-		 * transmit issued before the first is consumed (BF_ALL_GATHERS_ISSUED, pinned since) the gather loop is the faster one on every harness
-		 * frame (15.7-16.8 ms against 17.3-20.1: profiles/r03_harness.json), so span staging runs on request only: das path bit 0x40 wherever
-		 * the kernel supports it (tests: its frames are bit-identical to the gather loop's), 0x80 never. */
-		const bool span_ok = plan.iq_pipeline && a.interpolation >= 1 && !a.split_shift && Sd >= 128 && out.das_input_bytes < (1ull << 32);
-		if (span_ok && !(mode & 0x80) && (mode & 0x40)) {
-			a.span_stage = 1;
-			/* a wave = 64 voxels along the first lateral axis, the block's four waves stacked along depth */
-			uint32_t lat = a.tile_shift[0] >= a.tile_shift[1] ? 0u : 1u;
-			if (a.tile_shift[lat] > 6) {
-				uint32_t spare = a.tile_shift[lat] - 6;
-				a.tile_shift[lat] = 6;
-				for (int k = 0; k < 3 && spare; k++) {
-					if ((uint32_t)k == lat) continue;
-					uint32_t room = ceil_log2(ext[k]) - a.tile_shift[k];
-					uint32_t give = room < spare ? room : spare;
-					a.tile_shift[k] += give; spare -= give;
-				}
-				a.tile_shift[lat] += spare;
-				for (int k = 0; k < 3; k++) a.blocks[k] = (ext[k] + (1u << a.tile_shift[k]) - 1) >> a.tile_shift[k];
-				a.depth_major = tile_walk(out.depth_axis, zcount, a.blocks[1], a.band_rows);
-			}
-		}
 		out.path = DasPath_Factored;
 		why[DasPath_General] = "a specialised kernel applies";
 		out.valid = true;
@@ -785,6 +767,158 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	}
 	out.path = DasPath_General;
 	out.valid = true;
+}
+
+/* ---------------------------------------------------------------- row ends (das_exact.h), host side */
+
+namespace {
+
+struct Range { double lo, hi; };
+
+/* smallest and largest |v| of values v in [lo, hi] */
+Range abs_range(double lo, double hi)
+{
+	if (lo <= 0 && hi >= 0) return {0.0, std::fmax(-lo, hi)};
+	return {std::fmin(std::fabs(lo), std::fabs(hi)), std::fmax(std::fabs(lo), std::fabs(hi))};
+}
+
+double point_segment_distance(double px, double py, double ax, double ay, double bx, double by)
+{
+	const double vx = bx - ax, vy = by - ay, wx = px - ax, wy = py - ay;
+	const double vv = vx * vx + vy * vy;
+	double t = vv > 0 ? (wx * vx + wy * vy) / vv : 0.0;
+	t = t < 0 ? 0 : (t > 1 ? 1 : t);
+	const double dx = ax + t * vx - px, dy = ay + t * vy - py;
+	return std::sqrt(dx * dx + dy * dy);
+}
+
+/* Bounds on the sample index of every IN-APERTURE term of plane z (whole grid coordinates), for the families the staged kernels take
+ * (RCA with one receive orientation; FORCES).  Voxel -> world -> transducer is affine, so coordinates take their extremes at the
+ * plane's corners; distances to points are convex (largest at a corner) and bounded below by the distance to the corners' hull. */
+Range plane_index_bounds(const BfDasArgs &a, const std::vector<BfTransmit> &tx, const float *vox, const float *to_xdc,
+                         const int16_t *sparse_elements, uint32_t z)
+{
+	double world[4][3], xdc[4][3];
+	const double pz = (double)z / (double)(a.size[2] > 1 ? a.size[2] - 1 : 1);
+	for (int k = 0; k < 4; k++) {
+		const double px = (k & 1) && a.size[0] > 1 ? 1.0 : 0.0, py = (k & 2) && a.size[1] > 1 ? 1.0 : 0.0;
+		for (int i = 0; i < 3; i++) {
+			world[k][i] = vox[i] * px + vox[4 + i] * py + vox[8 + i] * pz + vox[12 + i];
+			xdc[k][i]   = to_xdc[i] * px + to_xdc[4 + i] * py + to_xdc[8 + i] * pz + to_xdc[12 + i];
+		}
+	}
+	auto over_corners = [&](auto f) { Range r{1e300, -1e300}; for (int k = 0; k < 4; k++) { double v = f(k); r.lo = std::fmin(r.lo, v); r.hi = std::fmax(r.hi, v); } return r; };
+	const bool forces = a.family == BF_DAS_FORCES;
+	const int  r_axis = forces ? 0 : ((tx[0].flags & BF_RX_ROWS) ? 1 : 0);
+	const double pitch_r = a.pitch[r_axis];
+	const Range zr = over_corners([&](int k) { return xdc[k][2]; });
+	const Range za = abs_range(zr.lo, zr.hi);
+	/* receive: |dx| < |z| / (2 F#) inside the aperture, and never beyond what the array and the plane allow */
+	const Range lat = over_corners([&](int k) { return xdc[k][r_axis]; });
+	const double last = (double)(a.channel_count - 1) * pitch_r;
+	double dx_max = std::fmax(std::fmax(std::fabs(lat.lo), std::fabs(lat.hi)), std::fmax(std::fabs(lat.lo - last), std::fabs(lat.hi - last)));
+	if (a.f_number > 0) dx_max = std::fmin(dx_max, 0.5 * za.hi / (double)a.f_number);
+	const double rx_max = std::sqrt(dx_max * dx_max + za.hi * za.hi), rx_min = za.lo;
+	const double c = a.speed_of_sound, fs = a.sampling_frequency, t0 = a.time_offset;
+	Range index{1e300, -1e300};
+	if (forces) {
+		/* das.glsl:288-321: every decoded transmit element e: sqrt((y - pitch_y C / 2)^2 + z^2 + (x - pitch_x e)^2) */
+		const double half = (double)a.pitch[1] * (double)a.channel_count / 2.0;
+		const Range ty = over_corners([&](int k) { return xdc[k][1] - half; });
+		const Range tya = abs_range(ty.lo, ty.hi);
+		double e_lo = a.sparse ? 1e300 : 0.0, e_hi = a.sparse ? -1e300 : (double)(a.acquisition_count - 1);
+		if (a.sparse) for (int t = 0; t + 1 < a.acquisition_count; t++) { e_lo = std::fmin(e_lo, sparse_elements[t]); e_hi = std::fmax(e_hi, sparse_elements[t]); }
+		const Range xs = over_corners([&](int k) { return xdc[k][0]; });
+		const Range txa = abs_range(xs.lo - (double)a.pitch[0] * (a.pitch[0] >= 0 ? e_hi : e_lo), xs.hi - (double)a.pitch[0] * (a.pitch[0] >= 0 ? e_lo : e_hi));
+		const double tx_max = std::sqrt(tya.hi * tya.hi + za.hi * za.hi + txa.hi * txa.hi);
+		const double tx_min = std::sqrt(tya.lo * tya.lo + za.lo * za.lo + txa.lo * txa.lo);
+		index.lo = (rx_min / c + t0) * fs + tx_min * fs / c;
+		index.hi = (rx_max / c + t0) * fs + tx_max * fs / c;
+		return index;
+	}
+	for (const BfTransmit &t : tx) {
+		Range d{0.0, 0.0};
+		if (!(t.flags & BF_TX_NONE)) {
+			const int w = (t.flags & BF_TX_ROWS) ? 1 : 0;
+			if (t.flags & BF_TX_PLANE) {
+				d = over_corners([&](int k) { return world[k][w] * (double)t.sin_a + world[k][2] * (double)t.cos_a; });
+			} else {
+				d = over_corners([&](int k) { return std::hypot(world[k][w] - (double)t.focus_x, world[k][2] - (double)t.focus_z); });
+				/* smallest distance from the focus to the (px, pz) image of the plane: zero if the focus lies inside it, else the distance
+				 * to its boundary (corner order 0, 1, 3, 2 walks the parallelogram) */
+				const int order[4] = {0, 1, 3, 2};
+				double nearest = 1e300; int sign = 0; bool inside = true;
+				for (int e = 0; e < 4; e++) {
+					const int i = order[e], j = order[(e + 1) & 3];
+					nearest = std::fmin(nearest, point_segment_distance(t.focus_x, t.focus_z, world[i][w], world[i][2], world[j][w], world[j][2]));
+					const double cross = (world[j][w] - world[i][w]) * ((double)t.focus_z - world[i][2]) - (world[j][2] - world[i][2]) * ((double)t.focus_x - world[i][w]);
+					if (cross != 0) { const int sg = cross > 0 ? 1 : -1; if (sign && sg != sign) inside = false; sign = sg; }
+				}
+				d.lo = (inside && sign) ? 0.0 : nearest;
+			}
+		}
+		index.lo = std::fmin(index.lo, ((d.lo + rx_min) / c + t0) * fs);
+		index.hi = std::fmax(index.hi, ((d.hi + rx_max) / c + t0) * fs);
+	}
+	return index;
+}
+
+} // namespace
+
+void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vector<BfTransmit> &tx,
+                      uint32_t zfirst, uint32_t zcount, uint32_t mode, std::vector<DasDecision> &parts)
+{
+	parts.clear();
+	parts.emplace_back();
+	decide_das(pb, plan, tx, zfirst, zcount, mode, parts[0]);
+	const DasDecision &whole = parts[0];
+	if ((whole.path != DasPath_Staged && whole.path != DasPath_Tile) || zcount == 0 || tx.empty()) return;
+	const BfDasArgs &a = whole.a;
+	float to_xdc[16];
+	if (a.family == BF_DAS_FORCES || a.family == BF_DAS_READI) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
+	else m4_mul(pb.parameters.xdc_transform, plan.das_voxel_transform, to_xdc);
+	const bool   cubic = a.interpolation == 2;
+	const double reach = 2.0 * (double)a.edge_margin;        /* the kernels' indices and these bounds differ by far less than the margin */
+	const double lo = (cubic ? 1.0 : 0.0) + reach, hi = (double)(a.sample_count - (cubic ? 2 : 1)) - reach;
+	std::vector<uint8_t> clear(zcount);
+	bool all = true;
+	for (uint32_t k = 0; k < zcount; k++) {
+		const Range r = plane_index_bounds(a, tx, plan.das_voxel_transform, to_xdc, pb.sparse_elements, zfirst + k);
+		clear[k] = r.lo >= lo && r.hi < hi;                  /* (false for a NaN) */
+		all = all && clear[k];
+	}
+	if (all) return;
+	/* the kernel behind the staged one: "automatic, never staged" with block staging off */
+	const uint32_t fallback_mode = (mode & ~0xFu & ~0x100u) | 0x200u | ((mode & 0xFu) == 1u ? 1u : 2u);
+	std::vector<DasDecision> cut;
+	uint32_t runs = 1;
+	for (uint32_t k = 1; k < zcount; k++) runs += clear[k] != clear[k - 1];
+	if (runs > 8) std::fill(clear.begin(), clear.end(), (uint8_t)0);         /* (a geometry that alternates: one launch of the fallback) */
+	for (uint32_t begin = 0, k = 1; k <= zcount; k++) {
+		if (k < zcount && clear[k] == clear[begin]) continue;
+		cut.emplace_back();
+		DasDecision &d = cut.back();
+		decide_das(pb, plan, tx, zfirst + begin, k - begin, clear[begin] ? mode : fallback_mode, d);
+		if (!clear[begin] && (d.path == DasPath_Staged || d.path == DasPath_Tile))
+			decide_das(pb, plan, tx, zfirst + begin, k - begin, (mode & ~0xFu & ~0x100u) | 0x200u | 1u, d);     /* (cannot happen: the general kernel) */
+		d.row_end_fallback = !clear[begin];
+		begin = k;
+	}
+	parts.swap(cut);
+}
+
+uint32_t row_end_planes(const std::vector<DasDecision> &parts)
+{
+	uint32_t n = 0;
+	for (const DasDecision &d : parts) if (d.row_end_fallback) n += d.z_count;
+	return n;
+}
+
+const DasDecision &main_part(const std::vector<DasDecision> &parts)
+{
+	size_t best = 0;
+	for (size_t i = 1; i < parts.size(); i++) if (parts[i].z_count > parts[best].z_count) best = i;
+	return parts[best];
 }
 
 } // namespace bf

@@ -46,6 +46,7 @@ struct DasDecision {
 	bool     valid = false;
 	uint64_t generation = 0, hooks_version = 0;              /* what it was computed for */
 	uint32_t z_first = 0, z_count = 0, mode = 0;
+	uint32_t mode_asked = 0;             /* decide_das_parts: the caller's mode (a fallback part is decided under another) */
 	BfDasArgs a{};                      /* everything but the device pointers */
 	float     tile_spread = 0.f;         /* das_tile.hip: the estimated spread of a tile of 2^tile_estimate_shift voxels (0: not a factored-kernel frame) */
 	uint32_t  tile_estimate_shift[3] = {0, 0, 0};
@@ -60,6 +61,7 @@ struct DasDecision {
 	bool     hercules_prepared = false; /* Hercules: read the {sample, difference} / polynomial copy of the DAS input */
 	uint64_t das_input_bytes = 0;
 	std::string why[DasPath_Count];     /* why each kernel was not taken ("" for the one that runs and for kernels not considered) */
+	bool     row_end_fallback = false;  /* decide_das_parts: these planes went to the kernel BEHIND the staged one because a term can reach an end of its RF row */
 };
 
 /* per-transmit constants of das.glsl:172-202 (host side; the executor uploads them) */
@@ -69,6 +71,20 @@ std::vector<BfTransmit> build_transmit_table(const ParameterBlock &pb);
  * (beamformer_hip_set_das_path).  Pure host arithmetic. */
 void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<BfTransmit> &transmits,
                 uint32_t z_first, uint32_t z_count, uint32_t mode, DasDecision &out);
+
+/* The same, cut along z where the ROW-END rule (das_exact.h) asks for it.  The LDS-staged kernels (das_staged*.hip) and the block-staged
+ * factored kernel (das_tile.hip) decide sample_rf's range test by their own index and carry no exact evaluation of the terms at the ends
+ * of an RF row (their checked loops run at their register limit).  They therefore get only planes on which provably no in-aperture term
+ * comes within reach of an end of its row -- a host bound per plane, in double precision, over the plane's corners; on every real
+ * acquisition whose rows do not end inside the image that is all of them, and `parts` holds ONE decision.  Otherwise the range is cut into
+ * runs of planes: clear runs keep the staged kernel, the others go to the kernel behind it (gather / factored / general, which evaluate
+ * row-end terms exactly).  Parts are contiguous, in z order, and cover [z_first, z_first + z_count). */
+void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vector<BfTransmit> &transmits,
+                      uint32_t z_first, uint32_t z_count, uint32_t mode, std::vector<DasDecision> &parts);
+/* planes of `parts` that took the fallback */
+uint32_t row_end_planes(const std::vector<DasDecision> &parts);
+/* the part with the most planes (what a frame "ran on" in one word) */
+const DasDecision &main_part(const std::vector<DasDecision> &parts);
 
 } // namespace bf
 #endif

@@ -23,7 +23,7 @@
  * segments; blocks are dealt to XCDs in contiguous runs so that neighbouring tiles (which
  * read neighbouring RF windows) share an L2.  Gather-accumulate, VALU/L1-bound: no MFMA.
  */
-#include "das_common.h"
+#include "das_exact.h"
 
 /* (voxel, channel, transmit) terms whose gathers are in flight together per lane */
 #ifndef BF_SEP_BATCH
@@ -87,9 +87,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 	                        fmaxf(1.0f, (float)p.size[2] - 1.0f)};
 	const float pz = (float)z / denom[2];
 	const float phase_k = p.demodulation_frequency * p.inv_sampling_frequency;
-	const BfTransmit t0 = p.transmits[0];
-	const bool  rx_rows = (t0.flags & BF_RX_ROWS) != 0;
-	const float rx_pitch = rx_rows ? p.pitch[1] : p.pitch[0];
+	const bool  rx_rows = (p.transmits[0].flags & BF_RX_ROWS) != 0;
 
 	/* ---- transmit table: A x V entries, built once */
 	for (uint32_t e = threadIdx.x; e < (uint32_t)A * V; e += blockDim.x) {
@@ -137,14 +135,29 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 		range.x = fminf(range.x, wave_range[w].x);
 		range.y = fmaxf(range.y, wave_range[w].y);
 	}
+	/* the same for every lane: kept in scalar registers (through scalar temporaries -- das_staged.hip says why) */
+	{
+		const float lo = range.x, hi = range.y;
+		range.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo)));
+		range.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
+	}
 
 	/* thread -> voxel: lanes run along the output's x axis */
+	/* (the voxel is worked out again where it is needed -- the row-end fix-up, the store at the very end -- rather than held in
+	 * two vector registers across the channel loop: the cubic instances have none to spare) */
+	auto voxel_of = [&](uint32_t thread, uint32_t &vx, uint32_t &vy, uint32_t &lane_u, uint32_t &lane_v) {
+		if (u_axis == 0) { lane_u = thread & (U - 1); lane_v = thread >> q.u_shift; }
+		else             { lane_v = thread & (V - 1); lane_u = thread >> v_shift; }
+		const uint32_t gu = tu * U + lane_u, gv = tv * V + lane_v;
+		vx = u_axis == 0 ? gu : gv; vy = u_axis == 0 ? gv : gu;
+	};
 	uint32_t lu, lv;
-	if (u_axis == 0) { lu = threadIdx.x & (U - 1); lv = threadIdx.x >> q.u_shift; }
-	else             { lv = threadIdx.x & (V - 1); lu = threadIdx.x >> v_shift; }
-	const uint32_t gu = tu * U + lu, gv = tv * V + lv;
-	const uint32_t x = u_axis == 0 ? gu : gv, y = u_axis == 0 ? gv : gu;
-	const bool inside = x < p.size[0] && y < p.size[1];
+	bool inside;
+	{
+		uint32_t x0, y0;
+		voxel_of(threadIdx.x, x0, y0, lu, lv);
+		inside = x0 < p.size[0] && y0 < p.size[1];
+	}
 
 	using VT = sample_t<CPLX>;
 	VT    coherent   = zero_sample<CPLX>();
@@ -155,30 +168,54 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 	const float    fS = (float)S;
 	const uint32_t row_bytes = (uint32_t)S * ES;
 	const f32x4   *Rl = R + lu, *Tl = T + lv;
+	const float    edge_margin = p.edge_margin;
+	/* the terms of one channel that the loops below left out because their index came within the margin of a row end (the same
+	 * sum of the same two table entries, so the same terms): evaluated with the shader's own index, added to the voxel's sums */
+	auto edge_fixup = [&](int channel, const f32x4 &r) {
+		if constexpr (INTERP != BF_INTERP_NEAREST) {
+			uint32_t x, y, unused_u, unused_v, thread = threadIdx.x;
+			asm volatile("" : "+v"(thread));                  /* not the values computed before the loop */
+			voxel_of(thread, x, y, unused_u, unused_v);
+			for (int a = 0; a < A; a++) {
+				const float index = r.x + Tl[(size_t)a * V].z;
+				if (bfx::edge_near<INTERP>(index, S, edge_margin) && r.w != 0.f)
+					bfx::edge_term<BF_DAS_RCA, INTERP, CPLX, CW>(bfx::kernel_args(), x, y, z, channel, a, coherent, incoherent);
+			}
+		}
+	};
 
 	for (int c0 = 0; c0 < C; c0 += chunk) {
 		const int cn = (C - c0) < chunk ? (C - c0) : chunk;
 		__syncthreads();            /* previous chunk's readers are done (and T is complete) */
-		/* ---- receive table for channels [c0, c0 + cn) */
+		/* ---- receive table for channels [c0, c0 + cn).  The ~50 scalars of the launch arguments it is built from (two 4 x 4 transforms,
+		 * pitch, f-number, speed of sound, ...) are read from the kernel-argument segment here, at the top of every chunk, instead of being
+		 * held in SGPRs across the channel loop (das_staged.hip: the same trick; at 8 waves per SIMD a wave has 80 SGPRs) */
+		{
+		const bfx::KernelArgs &ka = bfx::kernel_args();
+		const float k_denom_u = fmaxf(1.0f, (float)ka.size[u_axis] - 1.0f);
+		const float k_pz = (float)z / fmaxf(1.0f, (float)ka.size[2] - 1.0f);
+		const float k_fs = ka.sampling_frequency, k_inv_c = ka.inv_speed_of_sound, k_c = ka.speed_of_sound, k_fnum = ka.f_number;
+		const float k_phase = ka.demodulation_frequency * ka.inv_sampling_frequency;
+		const float k_pitch = rx_rows ? ka.pitch[1] : ka.pitch[0];
 		for (uint32_t e = threadIdx.x; e < (uint32_t)cn * U; e += blockDim.x) {
 			uint32_t c = (uint32_t)c0 + (e >> q.u_shift), iu = e & (U - 1);
-			float coord[3] = {0.f, 0.f, pz};
-			coord[u_axis] = (float)(tu * U + iu) / denom[u_axis];
+			float coord[3] = {0.f, 0.f, k_pz};
+			coord[u_axis] = (float)(tu * U + iu) / k_denom_u;
 			float wx, wy, wz, xx, xy, xz;
-			m4_point(p.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
-			m4_point(p.xdc_transform, wx, wy, wz, xx, xy, xz);
+			m4_point(ka.voxel_transform, coord[0], coord[1], coord[2], wx, wy, wz);
+			m4_point(ka.xdc_transform, wx, wy, wz, xx, xy, xz);
 			float lateral = rx_rows ? xy : xx;
-			float dx      = lateral - (float)c * rx_pitch;
-			float a_arg   = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(xz))));
+			float dx      = lateral - (float)c * k_pitch;
+			float a_arg   = __builtin_fabsf(dx * (k_fnum * hw_rcp(__builtin_fabsf(xz))));
 			f32x4 entry   = {0.f, 0.f, 0.f, 0.f};
 			if (a_arg < 0.5f) {
 				float cs    = hw_cos_turns(0.5f * a_arg);
 				float apod  = cs * cs;
-				float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), p) * p.sampling_frequency;
+				float r_idx = div_speed_of_sound(hw_sqrt(dx * dx + xz * xz), k_inv_c, k_c) * k_fs;
 				entry.x = r_idx;
 				entry.w = apod;
 				if constexpr (CPLX) {
-					float turns = phase_turns(phase_k, r_idx);
+					float turns = phase_turns(k_phase, r_idx);
 					entry.y = apod * hw_cos_turns(turns);
 					entry.z = apod * hw_sin_turns(turns);
 				} else {
@@ -186,6 +223,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				}
 			}
 			R[e] = entry;
+		}
 		}
 		__syncthreads();
 		if (!inside) continue;
@@ -219,9 +257,13 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				};
 				/* When every lane of the wave stays inside the RF row for every transmit of the tile
 				 * (r + min T >= 0 and r + max T < S - 1, the tile-wide extremes of T are in `range`),
-				 * the per-term range test and the zero-block select are dropped. */
-				const bool lane_safe = (r.x + range.x >= 0.f) && (r.x + range.y < (float)(S - 1));
+				 * the per-term range test and the zero-block select are dropped.
+				 * "Stays inside" with p.edge_margin to spare at both ends: a term of the unchecked loop is never one whose keep-or-drop
+				 * this kernel's index could decide differently from the shader's (das_exact.h).  In the checked loop a term within that
+				 * margin of an end reads the zero block -- left out -- and is evaluated exactly, from scratch, after the loop. */
+				const bool lane_safe = (r.x + range.x >= edge_margin) && (r.x + range.y < (float)(S - 1) - edge_margin);
 				const bool wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe) == 0;
+				bool edge_seen = false;
 				auto batches = [&](auto checked) {
 					constexpr bool CHECK = decltype(checked)::value;
 					for (int a = 0; a < A; a += B, row += B * row_bytes) {
@@ -234,7 +276,11 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 							frac[k] = hw_fract(index);
 							uint32_t ki = (uint32_t)cvt_floor_i32(index);
 							off[k] = row + (uint32_t)k * row_bytes + (ki << 3);
-							if constexpr (CHECK) off[k] = ki < ulast ? off[k] : q.zero_offset;
+							if constexpr (CHECK) {
+								const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin) && r.w != 0.f && a + k < A;
+								edge_seen |= edge;
+								off[k] = (ki < ulast && !edge) ? off[k] : q.zero_offset;
+							}
 							if (a + k >= A) off[k] = q.zero_offset;      /* wave-uniform: padding of the last batch */
 						}
 						#pragma unroll
@@ -246,6 +292,7 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 				if (wave_safe) batches(std::false_type{});
 				else           batches(std::true_type{});
 				sum = f32x2{acc1.x - acc2.y, acc1.y + acc2.x};
+				if (!wave_safe && __builtin_amdgcn_ballot_w64(edge_seen) != 0) edge_fixup(c0 + cl, r);
 			} else {
 			/* transmits in batches of B: B broadcast table reads, B index splits, B gathers in
 			 * flight, then B interpolate + rotate-accumulate steps (cubic holds two 16-byte loads
@@ -261,24 +308,46 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 					if constexpr (CW) mag += __builtin_fabsf(sv);
 				}
 			};
-			int a = 0;
-			for (; a + B <= A; a += B, row += B * row_bytes) {
-				f32x4 t[B];
-				Tap<INTERP> tap[B];
-				TapData<INTERP, CPLX> d[B];
-				#pragma unroll
-				for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k) * V];
-				#pragma unroll
-				for (int k = 0; k < B; k++) tap[k] = tap_setup<INTERP, CPLX>(r.x + t[k].z, fS, S - 1);
-				#pragma unroll
-				for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, row + (uint32_t)k * row_bytes + tap[k].off);
-				#pragma unroll
-				for (int k = 0; k < B; k++) term(t[k], tap_finish<INTERP, CPLX>(tap[k], d[k]));
+			/* row ends as above (linear, cubic; nearest interpolation flips at every half-integer, not only there: the parity tests
+			 * budget those): a wave with a lane within reach of an end of its RF row drops the terms inside the margin -- index -8 is
+			 * outside every mode's range, so tap_setup gives them zero weights -- and evaluates them exactly after the loop */
+			bool wave_safe = true, edge_seen = false;
+			if constexpr (INTERP != BF_INTERP_NEAREST) {
+				const bool lane_safe = (r.x + range.x >= bfx::edge_lo<INTERP>() + edge_margin) && (r.x + range.y < bfx::edge_hi<INTERP>(S) - edge_margin);
+				wave_safe = __builtin_amdgcn_ballot_w64(!lane_safe && r.w != 0.f) == 0;
 			}
-			for (; a < A; a++, row += row_bytes) {
-				const f32x4 t = Tl[(size_t)a * V];
-				term(t, interpolate<INTERP, CPLX>(rf, row, r.x + t.z, fS, S - 1));
-			}
+			auto index_of = [&](auto checked, const f32x4 &t) -> float {
+				float index = r.x + t.z;
+				if constexpr (decltype(checked)::value) {
+					const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin) && r.w != 0.f;
+					edge_seen |= edge;
+					index = edge ? -8.0f : index;
+				}
+				return index;
+			};
+			auto batches = [&](auto checked) {
+				int a = 0;
+				for (; a + B <= A; a += B, row += B * row_bytes) {
+					f32x4 t[B];
+					Tap<INTERP> tap[B];
+					TapData<INTERP, CPLX> d[B];
+					#pragma unroll
+					for (int k = 0; k < B; k++) t[k] = Tl[(size_t)(a + k) * V];
+					#pragma unroll
+					for (int k = 0; k < B; k++) tap[k] = tap_setup<INTERP, CPLX>(index_of(checked, t[k]), fS, S - 1);
+					#pragma unroll
+					for (int k = 0; k < B; k++) d[k] = tap_load<INTERP, CPLX>(rf, row + (uint32_t)k * row_bytes + tap[k].off);
+					#pragma unroll
+					for (int k = 0; k < B; k++) term(t[k], tap_finish<INTERP, CPLX>(tap[k], d[k]));
+				}
+				for (; a < A; a++, row += row_bytes) {
+					const f32x4 t = Tl[(size_t)a * V];
+					term(t, interpolate<INTERP, CPLX>(rf, row, index_of(checked, t), fS, S - 1));
+				}
+			};
+			if (wave_safe) batches(std::false_type{});
+			else           batches(std::true_type{});
+			if (!wave_safe && __builtin_amdgcn_ballot_w64(edge_seen) != 0) edge_fixup(c0 + cl, r);
 			}
 			if constexpr (CPLX) {
 				coherent.x += sum.x * r.y - sum.y * r.z;
@@ -291,6 +360,9 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 	}
 	if (!inside) return;
 
+	uint32_t x, y, unused_u, unused_v, thread = threadIdx.x;
+	asm volatile("" : "+v"(thread));
+	voxel_of(thread, x, y, unused_u, unused_v);
 	uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
 	if constexpr (CW) coherent = coherent * (coherent / incoherent);   /* coherency_weighting.glsl:36 */
 	reinterpret_cast<VT *>(p.out)[out_index] = coherent;

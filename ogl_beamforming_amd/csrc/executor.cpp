@@ -290,7 +290,7 @@ static PlanState *commit_block(uint32_t block)
 	if (clears_dirty) pb.dirty = 0;
 	ps.valid = true;
 	ps.generation++;
-	ps.das.valid = false;
+	ps.das_parts.clear();
 	return &ps;
 }
 
@@ -506,25 +506,46 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 			}
 
 			/* which kernel, with which geometry: one table of rules (das_select.cpp), computed once per plan / shard / path mode / hook
-			 * change and reused by every frame after it */
-			DasDecision &dd = ps->das;
-			if (!dd.valid || dd.generation != ps->generation || dd.z_first != zfirst || dd.z_count != zcount || dd.mode != c.das_path_mode ||
-			    dd.hooks_version != hooks().version) {
-				decide_das(pb, plan, ps->transmit_table, zfirst, zcount, c.das_path_mode, dd);
-				dd.generation = ps->generation;
+			 * change and reused by every frame after it.  Usually ONE launch; where a term of the frame can reach an end of its RF row
+			 * the z range is cut and the planes concerned go to the kernel behind the staged one (decide_das_parts, das_exact.h). */
+			std::vector<DasDecision> &parts = ps->das_parts;
+			if (parts.empty() || !parts[0].valid || parts[0].generation != ps->generation || ps->das_z_first != zfirst || ps->das_z_count != zcount ||
+			    parts[0].mode_asked != c.das_path_mode || parts[0].hooks_version != hooks().version) {
+				decide_das_parts(pb, plan, ps->transmit_table, zfirst, zcount, c.das_path_mode, parts);
+				for (DasDecision &dd : parts) { dd.generation = ps->generation; dd.mode_asked = c.das_path_mode; }
+				ps->das_z_first = zfirst; ps->das_z_count = zcount;
 			}
+			const DasDecision &head = main_part(parts);
+			const uint32_t ext[3] = {head.a.size[0], head.a.size[1], zcount};
+			das_path = (uint32_t)(head.path == DasPath_Zero ? DasPath_General : head.path);
+			uint64_t violations_slot = ~0ull;
+			uint32_t *frame_counters = nullptr;        /* [0] staged window violations, [1] / [2] das_tile.hip's staged / gathered chunks */
+			for (const DasDecision &dd : parts)
+				if (dd.path == DasPath_Staged || dd.path == DasPath_Tile) {
+					if (d.staged_violations.ensure(sizeof(uint32_t) * 4 * kTimingSlots)) {
+						frame_counters = (uint32_t *)d.staged_violations.ptr + 4 * (f->id % kTimingSlots);
+						ok &= HIP_OK(hipMemsetAsync(frame_counters, 0, 4 * sizeof(uint32_t), s));
+						violations_slot = f->id % kTimingSlots;
+					} else ok = false;
+					break;
+				}
+			if (c.count_pairs) {
+				ok &= d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 2));
+				if (ok) ok &= HIP_OK(hipMemsetAsync((unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots), 0, sizeof(unsigned long long), s));
+			}
+			const uint64_t plane_bytes = (uint64_t)head.a.size[0] * head.a.size[1] * (plan.iq_pipeline ? 8u : 4u);
+
+			for (const DasDecision &dd : parts) {
 			BfDasArgs a = dd.a;
 			a.rf  = cur;
-			a.out = (char *)d.ring.ptr + f->offset;
+			a.out = (char *)d.ring.ptr + f->offset + (uint64_t)(dd.z_first - zfirst) * plane_bytes;
 			a.transmits       = (const BfTransmit *)ps->transmits.ptr;
 			a.sparse_elements = (const int16_t *)ps->sparse.ptr;
 			a.readi_hadamard  = (const uint16_t *)ps->readi_hadamard.ptr;
-			const uint32_t ext[3] = {a.size[0], a.size[1], zcount};
-			das_path = (uint32_t)(dd.path == DasPath_Zero ? DasPath_General : dd.path);
-			uint64_t violations_slot = ~0ull;
+			uint32_t part_path = (uint32_t)dd.path;
 
 			if (dd.path == DasPath_Zero) {
-				ok &= HIP_OK(hipMemsetAsync(a.out, 0, f->bytes, s));
+				ok &= HIP_OK(hipMemsetAsync(a.out, 0, dd.z_count * plane_bytes, s));
 			} else {
 				/* 64 zero bytes right behind the DAS input (every buffer it can live in is allocated with that much slack): the
 				 * gather target of out-of-range lanes */
@@ -550,18 +571,13 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					}
 					if (staged) {
 						/* window positions outside the staged window are counted (range-checked loop only: STAGED_CHECKED) */
-						ok &= d.staged_violations.ensure(sizeof(uint32_t) * 4 * kTimingSlots);
-						if (ok) {
-							sep.violations = (uint32_t *)d.staged_violations.ptr + 4 * (f->id % kTimingSlots);
-							ok &= HIP_OK(hipMemsetAsync(sep.violations, 0, 4 * sizeof(uint32_t), s));
-							violations_slot = f->id % kTimingSlots;
-						}
+						sep.violations = frame_counters;
 						ok &= HIP_OK(!plan.iq_pipeline ? bf_launch_das_staged_real(&a, &sep, s) :
 						             a.interpolation == 2 ? bf_launch_das_staged_cubic(&a, &sep, s) : bf_launch_das_staged(&a, &sep, s));
-						das_path = DasPath_Staged;
+						part_path = DasPath_Staged;
 					} else {
 						ok &= HIP_OK(bf_launch_das_separable(&a, &sep, s));
-						das_path = DasPath_Gather;
+						part_path = DasPath_Gather;
 					}
 				}break;
 				case DasPath_Hercules:{
@@ -578,7 +594,7 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 						ok &= HIP_OK(bf_launch_das_hercules(&a, &hq, s));
 					} else {
 						ok &= HIP_OK(bf_launch_das(&a, s));                                     /* no memory for the row table: the general kernel */
-						das_path = DasPath_General;
+						part_path = DasPath_General;
 					}
 				}break;
 				case DasPath_Factored:
@@ -586,35 +602,34 @@ static bool run_frame_stages(uint32_t block, const void *rf, int64_t rf_bytes, b
 					break;
 				case DasPath_Tile:
 					/* (block, channel chunk) pairs served from staged windows, and those the kernel sent through its gather loop: words 1, 2 */
-					ok &= d.staged_violations.ensure(sizeof(uint32_t) * 4 * kTimingSlots);
-					if (ok) {
-						uint32_t *slot = (uint32_t *)d.staged_violations.ptr + 4 * (f->id % kTimingSlots);
-						ok &= HIP_OK(hipMemsetAsync(slot, 0, 4 * sizeof(uint32_t), s));
-						a.tile_counters = slot + 1;
-						violations_slot = f->id % kTimingSlots;
-					}
+					a.tile_counters = frame_counters ? frame_counters + 1 : nullptr;
 					ok &= HIP_OK(bf_launch_das_tile(&a, s));
 					break;
 				default:
 					ok &= HIP_OK(bf_launch_das(&a, s));
 					break;
 				}
-				if (c.count_pairs) {
-					/* geometry-only recount of the apodization test; its own segment so that it
-					 * stays out of the DAS time */
-					ok &= d.pair_counter.ensure(sizeof(unsigned long long) * (kTimingSlots + 2));
-					BfDasArgs count = dd.general;              /* the general kernel's own tiles: the specialised kernels reshape them */
-					count.rf = a.rf; count.out = a.out; count.transmits = a.transmits; count.sparse_elements = a.sparse_elements;
-					count.readi_hadamard = a.readi_hadamard;
-					count.pair_counter = (unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots);
-					ok &= HIP_OK(hipMemsetAsync(count.pair_counter, 0, sizeof(unsigned long long), s));
-					segment((uint32_t)st.kind);
-					ok &= HIP_OK(bf_launch_das_count(&count, s));
-					segment(kStagePairCount);
-					t.counted = true;
-					das_segment_done = true;
-				}
 			}
+			if (&dd == &head && dd.path != DasPath_Zero) das_path = part_path;
+			}
+			if (c.count_pairs && head.path != DasPath_Zero) {
+				/* geometry-only recount of the apodization test; its own segment so that it
+				 * stays out of the DAS time */
+				segment((uint32_t)st.kind);
+				for (const DasDecision &dd : parts) {
+					BfDasArgs count = dd.general;              /* the general kernel's own tiles: the specialised kernels reshape them */
+					count.rf = cur; count.out = (char *)d.ring.ptr + f->offset + (uint64_t)(dd.z_first - zfirst) * plane_bytes;
+					count.transmits = (const BfTransmit *)ps->transmits.ptr; count.sparse_elements = (const int16_t *)ps->sparse.ptr;
+					count.readi_hadamard = (const uint16_t *)ps->readi_hadamard.ptr;
+					count.pair_counter = (unsigned long long *)d.pair_counter.ptr + (f->id % kTimingSlots);
+					ok &= HIP_OK(bf_launch_das_count(&count, s));
+				}
+				segment(kStagePairCount);
+				t.counted = true;
+				das_segment_done = true;
+			}
+			const BfDasArgs &a = head.a;
+			t.das_row_end_planes = row_end_planes(parts);
 			t.das_voxels = (uint64_t)ext[0] * ext[1] * ext[2];
 			t.das_taps = a.interpolation == 0 ? 1 : a.interpolation == 1 ? 2 : 4;
 			t.das_sample_bytes = plan.iq_pipeline ? 8 : 4;
@@ -1030,6 +1045,7 @@ static bool timings_of(Device &d, BeamformerHipFrameTimings *out)
 	if (t.count && HIP_OK(hipEventElapsedTime(&total, e.events[0], e.events[t.count]))) out->frame_ms = total;
 	out->das_voxels = t.das_voxels; out->das_taps = t.das_taps;
 	out->das_sample_bytes = t.das_sample_bytes; out->das_path = t.das_path;
+	out->das_row_end_planes = t.das_row_end_planes;
 	if (t.violations_slot != ~0ull && d.staged_violations.ptr) {
 		uint32_t n[4] = {0, 0, 0, 0};
 		(void)hipMemcpy(n, (uint32_t *)d.staged_violations.ptr + 4 * t.violations_slot, sizeof(n), hipMemcpyDeviceToHost);
@@ -1109,6 +1125,7 @@ bool last_frame_timings(BeamformerHipFrameTimings *out)
 		out->das_voxels += peer.das_voxels; out->das_pairs += peer.das_pairs;
 		out->staged_window_violations += peer.staged_window_violations;
 		out->tile_staged_chunks += peer.tile_staged_chunks; out->tile_gather_chunks += peer.tile_gather_chunks;
+		out->das_row_end_planes += peer.das_row_end_planes;
 		if (peer.frame_ms > out->frame_ms) out->frame_ms = peer.frame_ms;
 	}
 	(void)hipSetDevice(c.devices[0].device);

@@ -591,15 +591,18 @@ uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDe
 	if (plan.das_index < 0) { out->path = -1; return 1; }
 	uint32_t zfirst = 0, zcount = plan.output_points[2];
 	if (pb.shard_z_count) { zfirst = pb.shard_z_first; zcount = pb.shard_z_count; }
-	DasDecision d;
-	decide_das(pb, plan, build_transmit_table(pb), zfirst, zcount, c.das_path_mode, d);
+	/* the decision for the planes that keep the first choice; where the row-end rule cuts the range (das_select.h: decide_das_parts) the
+	 * planes handed to the kernel behind it are counted in row_end_planes */
+	std::vector<DasDecision> parts;
+	decide_das_parts(pb, plan, build_transmit_table(pb), zfirst, zcount, c.das_path_mode, parts);
+	const DasDecision &d = main_part(parts);
+	out->row_end_planes = row_end_planes(parts);
 	out->path = d.path == DasPath_Zero ? -2 : d.path;
 	std::snprintf(out->kernel, sizeof(out->kernel), "%s", das_kernel_name(d.path));
 	std::snprintf(out->name, sizeof(out->name), "%s", das_path_name(d.path));
 	for (int k = 0; k < DasPath_Count && k < 8; k++) std::snprintf(out->declined[k], sizeof(out->declined[k]), "%s", d.why[k].c_str());
 	for (int k = 0; k < 3; k++) { out->tile_shift[k] = d.a.tile_shift[k]; out->blocks[k] = d.a.blocks[k]; }
 	out->split_shift = d.a.split_shift; out->tile_walk = d.path == DasPath_Hercules ? d.herc.depth_major : (d.path == DasPath_Gather || d.path == DasPath_Staged) ? d.sep.depth_major : d.a.depth_major;
-	out->span_stage = d.a.span_stage;
 	out->tile_window_samples = d.path == DasPath_Tile ? 1u << d.a.tile_window_shift : 0u;
 	if (d.path == DasPath_Gather || d.path == DasPath_Staged) {
 		out->u_axis = d.sep.u_axis; out->u_shift = d.sep.u_shift; out->v_shift = d.sep.v_shift; out->window_samples = d.path == DasPath_Staged ? d.sep.window_samples : 0;

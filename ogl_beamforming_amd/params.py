@@ -212,7 +212,7 @@ class HipFrameTimings(C.Structure):
         ("stage_ms", C.c_float * HIP_MAX_TIMED_STAGES), ("frame_ms", C.c_float),
         ("das_pairs", C.c_uint64), ("das_voxels", C.c_uint64), ("das_taps", C.c_uint32),
         ("das_sample_bytes", C.c_uint32), ("das_path", C.c_uint32), ("staged_window_violations", C.c_uint32),
-        ("tile_staged_chunks", C.c_uint32), ("tile_gather_chunks", C.c_uint32),
+        ("tile_staged_chunks", C.c_uint32), ("tile_gather_chunks", C.c_uint32), ("das_row_end_planes", C.c_uint32),
     ]
 
 
@@ -225,7 +225,7 @@ class HipDeviceInfo(C.Structure):
 class HipDasDescription(C.Structure):
     _fields_ = [("path", C.c_int32), ("kernel", C.c_char * 48), ("name", C.c_char * 64), ("declined", (C.c_char * 160) * 8),
                 ("tile_shift", C.c_uint32 * 3), ("blocks", C.c_uint32 * 3), ("split_shift", C.c_uint32), ("tile_walk", C.c_uint32),
-                ("span_stage", C.c_uint32), ("tile_window_samples", C.c_uint32), ("u_axis", C.c_uint32), ("u_shift", C.c_uint32), ("v_shift", C.c_uint32), ("window_samples", C.c_uint32),
+                ("row_end_planes", C.c_uint32), ("tile_window_samples", C.c_uint32), ("u_axis", C.c_uint32), ("u_shift", C.c_uint32), ("v_shift", C.c_uint32), ("window_samples", C.c_uint32),
                 ("uniform_tables", C.c_uint32), ("lds_bytes", C.c_uint32), ("threads", C.c_uint32), ("channel_chunk", C.c_uint32),
                 ("hercules_prepared_copy", C.c_uint32), ("tile_spread_estimate", C.c_float), ("tile_estimate_shift", C.c_uint32 * 3)]
 

@@ -69,6 +69,8 @@ def library():
                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
         lib.oracle_set_nearest_ambiguity_buffer.restype = None
         lib.oracle_set_nearest_ambiguity_buffer.argtypes = [C.c_void_p]
+        lib.oracle_set_f64_frame.restype = None
+        lib.oracle_set_f64_frame.argtypes = [C.c_void_p]
         lib.oracle_set_subgrid_stride.restype = None
         lib.oracle_set_subgrid_stride.argtypes = [C.c_uint32, C.c_uint32]
         lib.oracle_set_rows_outermost.restype = None
@@ -136,13 +138,14 @@ def plan(bp, filters=()):
     return out if ok else None
 
 
-def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, stride=(1, 1), flags=None):
+def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, stride=(1, 1), flags=None, truth=None):
     """Whole frame on the CPU, 16-channel chunks as the reference runs it.  z / y = (first,
     count) restrict the computed planes / rows (count 0 = whole axis); stride = (z, y) steps
     between the computed planes / rows.  Returns (frame (Z, Y, X) float32|complex64, pairs);
     timing (a dict) receives das_seconds; flags (a dict) receives, for nearest interpolation, "budget": per
     voxel the sum of |other sample - chosen sample| over the taps whose index sat within 2^-10 of a rounding
-    boundary (what tap flips can move the coherent sum by), and "near_half" = budget > 0."""
+    boundary (what tap flips can move the coherent sum by), and "near_half" = budget > 0; truth (a dict) receives "frame": the
+    same frame with every DAS stage run in double precision on the same float32 DAS input (oracle_set_f64_frame) -- complex128 / float64."""
     pb = parameter_block(bp, filters)
     p = plan(bp, filters)
     if p is None:
@@ -158,6 +161,8 @@ def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, str
     library().oracle_set_subgrid_stride(stride[0], stride[1])
     budget = np.zeros(voxels, np.float32) if flags is not None else None
     library().oracle_set_nearest_ambiguity_buffer(budget.ctypes.data_as(C.c_void_p) if budget is not None else None)
+    exact = np.zeros(voxels * n, np.float64) if truth is not None else None
+    library().oracle_set_f64_frame(exact.ctypes.data_as(C.c_void_p) if exact is not None else None)
     try:
         ok = library().oracle_beamform_subgrid(C.byref(pb), rf.ctypes.data_as(C.c_void_p),
                                                out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(pairs), threads,
@@ -165,6 +170,9 @@ def beamform(bp, rf, filters=(), threads=0, z=(0, 0), y=(0, 0), timing=None, str
     finally:
         library().oracle_set_subgrid_stride(1, 1)
         library().oracle_set_nearest_ambiguity_buffer(None)
+        library().oracle_set_f64_frame(None)
+    if truth is not None:
+        truth["frame"] = (exact.view(np.complex128) if p.iq_pipeline else exact).reshape(nz, ny, pts[0])
     if flags is not None:
         flags["budget"] = budget.reshape(nz, ny, pts[0])
         flags["near_half"] = flags["budget"] > 0

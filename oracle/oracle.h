@@ -236,6 +236,8 @@ int  oracle_beamform(const OracleParameterBlock *pb, const void *raw, float *out
  * implementation that differs by float rounding legitimately picks the other sample, |other - chosen|.
  * A voxel with a zero entry has no such tap.  NULL switches it off. */
 void oracle_set_nearest_ambiguity_buffer(float *budget);
+/* the double-precision twin of every DAS stage of later oracle_beamform* calls into `frame` (voxels x 1 or 2 doubles), or NULL: off */
+void oracle_set_f64_frame(double *frame);
 /* Sampling strides of the sub-grid for later oracle_beamform_subgrid calls (1, 1 = contiguous): plane
  * z_first + k z_stride, row y_first + k y_stride.  bench.py's CPU baseline times evenly spaced planes. */
 void oracle_set_subgrid_stride(uint32_t z_stride, uint32_t y_stride);

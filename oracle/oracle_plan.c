@@ -213,6 +213,7 @@ typedef struct {
 	size_t   slot_bytes;
 	int      input_index;     /* cc->ping_pong_input_index */
 	float   *frame, *incoherent;
+	double  *frame64, *incoherent64;     /* oracle_set_f64_frame: the double twin's sums, or NULL */
 	float   *hadamard, *readi_hadamard;
 	uint64_t pairs;
 	int      threads;
@@ -228,6 +229,13 @@ typedef struct {
 
 static int rows_outermost = 1;
 void oracle_set_rows_outermost(int enable) { rows_outermost = enable != 0; }
+
+/* Tolerance truth (test infrastructure): when set, every DAS stage of the next oracle_beamform* call ALSO runs in double precision
+ * (oracle_das_f64: the same loops on the same float32 DAS input) into this buffer -- voxels x (1 or 2) doubles, cleared by the call --
+ * and coherency weighting is applied to it in double.  What a parity test compares a GPU voxel with when the float oracle and the GPU
+ * disagree by more than the bar: no float evaluation is asked to be closer to the truth than the oracle's own. */
+static double *f64_frame;
+void oracle_set_f64_frame(double *frame) { f64_frame = frame; }
 
 static uint32_t subgrid_z_stride = 1, subgrid_y_stride = 1;   /* oracle_set_subgrid_stride */
 
@@ -346,11 +354,20 @@ static void run_stage(Exec *e, int slot, int channel_offset, const uint8_t *rf_p
 		double t0 = oracle_now();
 		e->pairs += oracle_das(&d, (const float *)pp_das, e->frame, e->incoherent);
 		e->das_seconds += oracle_now() - t0;
+		if (e->frame64) oracle_das_f64(&d, (const float *)pp_das, e->frame64, e->incoherent64);
 	}break;
 	case BeamformerShaderKind_CoherencyWeighting:{
 		uint32_t voxels = (uint32_t)plan->output_points[0] * (e->y_count ? e->y_count : (uint32_t)plan->output_points[1])
 		                  * (e->z_count ? e->z_count : (uint32_t)plan->output_points[2]);
 		oracle_coherency_weighting(e->frame, e->incoherent, voxels, plan->iq_pipeline, 1.0f);  /* :949 */
+		if (e->frame64) {
+			int n = plan->iq_pipeline ? 2 : 1;
+			for (uint32_t i = 0; i < voxels; i++)
+				for (int c = 0; c < n; c++) {
+					double v = e->frame64[n * (uint64_t)i + c];
+					e->frame64[n * (uint64_t)i + c] = v * (v / e->incoherent64[i]);
+				}
+		}
 	}break;
 	default: break;
 	}
@@ -402,6 +419,11 @@ int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, flo
 	e.frame      = out;
 	memset(out, 0, sizeof(float) * elements * voxels);                         /* :1573-1578 */
 	e.incoherent = (float *)calloc(voxels + 16, sizeof(float));                /* :1580-1585 */
+	if (f64_frame) {
+		e.frame64 = f64_frame;
+		memset(e.frame64, 0, sizeof(double) * elements * voxels);
+		e.incoherent64 = (double *)calloc(voxels + 16, sizeof(double));
+	}
 	int A = (int)bp->acquisition_count;
 	e.hadamard = (float *)calloc((size_t)A * A + 1, sizeof(float));
 	if (bp->decode_mode == BeamformerDecodeMode_Hadamard) oracle_hadamard_transpose(A, e.hadamard);
@@ -453,6 +475,7 @@ int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, flo
 				for (int64_t row = t; row < rows; row += T) {
 					d.row_first = row;
 					pairs += oracle_das(&d, input, e.frame, e.incoherent);
+					if (e.frame64) oracle_das_f64(&d, input, e.frame64, e.incoherent64);
 				}
 			}
 		}
@@ -465,6 +488,6 @@ int oracle_beamform_subgrid(const OracleParameterBlock *pb, const void *raw, flo
 
 	if (pairs_out) *pairs_out = e.pairs;
 	if (das_seconds) *das_seconds = e.das_seconds;
-	free(mapped); free(e.ping_pong); free(e.incoherent); free(e.hadamard); free(e.readi_hadamard);
+	free(mapped); free(e.ping_pong); free(e.incoherent); free(e.incoherent64); free(e.hadamard); free(e.readi_hadamard);
 	return 1;
 }

@@ -400,17 +400,16 @@ def test_config5_rows_at_the_edges_of_the_volume(bflib, oracle):
     assert delta / np.abs(ref[ok]).max() <= 4 * cases.tolerance(acq), delta / np.abs(ref[ok]).max()
 
 
-@pytest.mark.parametrize("kind, path, span", [("tpw", 3, 1), ("forces", 3, 1), ("hercules", 5, 0), ("vls", 3, 1)])
-def test_reference_harness_frame_at_full_size(kind, path, span, bflib, oracle):
+@pytest.mark.parametrize("kind, path", [("tpw", 3), ("forces", 3), ("hercules", 5), ("vls", 3)])
+def test_reference_harness_frame_at_full_size(kind, path, bflib, oracle):
     """The frame the reference's own throughput harness beamforms (tests/throughput.c:20-23, :443-491): 256 channels x 128
     transmits x 4096 samples -> the 512 x 1024 XZ view plane, cubic, F# 0.5, {Demodulate, Decode, DAS}.  The automatic path
     (factored kernel, gather loop with all gathers of a transmit issued together; HERCULES: the aligned-grid kernel reading raw taps)
-    against oracle rows at the first, a middle and the last depths, and -- RCA / FORCES -- bit-for-bit against the same kernel with
-    wave-span staging (flag 0x40: automatic until the gather loop's schedule was pinned, on request since)."""
+    against oracle rows at the first, a middle and the last depths."""
     from tests import cases
     acq = cfg.harness(kind)
     p, kernel, _, reasons, d = bflib.describe_das(acq.bp, acq.filters)
-    assert p == path and int(d.span_stage) == 0, (kernel, reasons)
+    assert p == path, (kernel, reasons)
     if kind == "hercules":
         assert int(d.hercules_prepared_copy) == 0
     frame = run(bflib, acq)
@@ -426,11 +425,3 @@ def test_reference_harness_frame_at_full_size(kind, path, span, bflib, oracle):
     delta = np.abs(got[ok] - ref[ok]).max()
     assert delta / peak <= cases.tolerance(acq), delta / peak
     assert delta / np.abs(ref[ok]).max() <= 4 * cases.tolerance(acq), delta / np.abs(ref[ok]).max()
-    if span:
-        bflib.library().beamformer_hip_set_das_path(0x40)
-        try:
-            assert int(bflib.describe_das(acq.bp, acq.filters)[4].span_stage) == 1
-        finally:
-            bflib.library().beamformer_hip_set_das_path(0)
-        staged = run(bflib, acq, path=0x40)
-        assert np.array_equal(staged.view(np.uint32), frame.view(np.uint32)), "wave-span staging and the gather loop differ"

