@@ -34,7 +34,7 @@
  * per-lane term is computed once per element), the other one the inner loop.  Either may be the
  * receive or the transmit axis; only the RF row strides and the first-transmit weight differ.
  */
-#include "das_common.h"
+#include "das_exact.h"
 
 #define BF_HERC_BATCH 4
 /* cos^2(sqrt(w)) on [0, (pi/2)^2]: degree-5 fit at the Chebyshev nodes, |error| < 4.0e-7 (6.7e-7 as an
@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 
 	VT    coherent   = zero_sample<CPLX>();
 	float incoherent = 0.f;
+	const float edge_margin = p.edge_margin;
+	unsigned long long edge_lanes = 0;         /* checked loop: the lanes with a pair left out at an end of its RF row (a scalar) */
 
 	for (int m = 0; m < n_outer; m++) {
 		float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					apod[k] = apod_poly(dn * wsp + wodp);    /* w = ws e2 as one packed fma */
 				}
 				dist[k]  = f32x2{hw_sqrt(dd.x), hw_sqrt(dd.y)};
-				index[k] = dist[k] * kp + T0p;
+				/* (checked loop: explicit fmas -- the row-end pass at the end of the kernel forms the same index again, bit for bit) */
+				if constexpr (CHECK) index[k] = f32x2{__builtin_fmaf(dist[k].x, fs_over_c, T0), __builtin_fmaf(dist[k].y, fs_over_c, T0)};
+				else                 index[k] = dist[k] * kp + T0p;
 				if constexpr (CPLX) { if constexpr (PL) turns[k] = index[k] * tpsp - btp; else turns[k] = index[k] * tpsp; }
 			}
 			/* (floor / fraction of two indices by packed adds -- index + 2^23 - 1/2 leaves floor(index) in the low
@@ -322,12 +326,20 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					const uint32_t first = RAWC ? ki - 1u : ki;              /* raw cubic taps start one sample early */
 					off[k] = CHECK ? row + first * ES : first * ES;
 					if constexpr (CHECK) {
-						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124) */
-						bool ok = ((POLY || RAWC) ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test);
+						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124); a term within the margin of an end of its
+						 * row is left out here and evaluated with the shader's own index at the end of the kernel (das_exact.h) */
+						const bool edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
+						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
+						bool ok = ((POLY || RAWC) ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test) && !edge;
 						off[k] = ok ? off[k] : q.zero_offset;
 						ap[k]  = ok ? ap[k] : 0.f;
 					}
 				} else {
+					if constexpr (CHECK && INTERP != BF_INTERP_NEAREST) {
+						const bool edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
+						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
+						idx = edge ? -8.0f : idx;                     /* outside every mode's range: zero weights */
+					}
 					tap[k] = tap_setup<INTERP, CPLX>(idx, (float)S, S - 1);
 					off[k] = row + tap[k].off;
 					if constexpr (CHECK) ap[k] = (e < apodization_test) ? ap[k] : 0.f;
@@ -429,6 +441,29 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			coherent += outer_weight * accr;
 		}
 		if constexpr (CW) incoherent += outer_weight * mag;
+	}
+	if constexpr (INTERP != BF_INTERP_NEAREST) {
+		if (edge_lanes != 0ull) {
+			/* ---- row ends: the pairs the checked loop left out -- the same index arithmetic, so the same pairs -- each evaluated from
+			 * the voxel's integer coordinates with the shader's own index (das_exact.h), weight and all, into the voxel's sums.  Rare: a
+			 * wave gets here only if one of its lanes had such a pair; its registers are not the loops'. */
+			const int sparse = p.sparse != 0;
+			for (int m = 0; m < n_outer; m++) {
+				const float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
+				const float od  = outer_lateral - outer_element * outer_pitch;
+				const float od2 = od * od * s2;
+				if (__builtin_amdgcn_ballot_w64(od2 + d2_min < apodization_test) == 0) continue;
+				for (int n = 0; n < n_inner; n++) {
+					const float e2  = od2 + row_d2[n];
+					const float idx = __builtin_fmaf(hw_sqrt(z2 + e2), fs_over_c, T0);
+					if (e2 < apodization_test && bfx::edge_near<INTERP>(idx, S, edge_margin)) {
+						const int channel  = q.inner_is_transmit ? m : n;
+						const int transmit = (q.inner_is_transmit ? n : m) + sparse;
+						bfx::edge_term<BF_DAS_HERCULES, INTERP, CPLX, CW>(bfx::kernel_args(), x, y, z, channel, transmit, coherent, incoherent);
+					}
+				}
+			}
+		}
 	}
 	if (!inside) return;
 

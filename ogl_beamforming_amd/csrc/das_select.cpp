@@ -885,6 +885,8 @@ void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vec
 	for (uint32_t k = 0; k < zcount; k++) {
 		const Range r = plane_index_bounds(a, tx, plan.das_voxel_transform, to_xdc, pb.sparse_elements, zfirst + k);
 		clear[k] = r.lo >= lo && r.hi < hi;                  /* (false for a NaN) */
+		if (hooks().debug && (k == 0 || k + 1 == zcount))
+			std::fprintf(stderr, "[beamformer] row ends: plane %u index within [%.3f, %.3f], clear within [%.3f, %.3f): %s\n", zfirst + k, r.lo, r.hi, lo, hi, clear[k] ? "clear" : "fallback");
 		all = all && clear[k];
 	}
 	if (all) return;

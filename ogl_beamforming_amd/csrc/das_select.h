@@ -74,10 +74,10 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 
 /* The same, cut along z where the ROW-END rule (das_exact.h) asks for it.  The LDS-staged kernels (das_staged*.hip) and the block-staged
  * factored kernel (das_tile.hip) decide sample_rf's range test by their own index and carry no exact evaluation of the terms at the ends
- * of an RF row (their checked loops run at their register limit).  They therefore get only planes on which provably no in-aperture term
+ * of an RF row (their checked loops run at their register limit; every other kernel evaluates those terms itself).  They therefore get only planes on which provably no in-aperture term
  * comes within reach of an end of its row -- a host bound per plane, in double precision, over the plane's corners; on every real
  * acquisition whose rows do not end inside the image that is all of them, and `parts` holds ONE decision.  Otherwise the range is cut into
- * runs of planes: clear runs keep the staged kernel, the others go to the kernel behind it (gather / factored / general, which evaluate
+ * runs of planes: clear runs keep their kernel, the others go to the kernel behind it (gather / factored / general, which evaluate
  * row-end terms exactly).  Parts are contiguous, in z order, and cover [z_first, z_first + z_count). */
 void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vector<BfTransmit> &transmits,
                       uint32_t z_first, uint32_t z_count, uint32_t mode, std::vector<DasDecision> &parts);

@@ -220,11 +220,19 @@ def _plane_cases():
     c["harness_hercules_yz_small"] = lambda: cfg.harness("hercules", 0.0625, "yz")
     # wide enough along image x (>= 32 voxels, no channel split: 7 channels) for the aligned-grid HERCULES kernel to be the
     # automatic choice on a view plane; the YZ plane puts world y along the lanes: the loop roles swap
+    # (1024 samples: the deepest pixels' echoes arrive at sample 344 of the 512 that demodulation leaves.  With 512-sample rows -- the
+    # "_short_rows" twins -- rows END inside the image: the kernel's checked loop and its row-end pass (csrc/das_exact.h) run)
     c["hercules_plane_xz"] = lambda: cfg.hercules(
-        "hercules_plane_xz", 7, 16, 512, (64, 48, 1), LO3, HI3, seed=81, cw=True, f_number=0.7, interp=I.Cubic,
+        "hercules_plane_xz", 7, 16, 1024, (64, 48, 1), LO3, HI3, seed=81, cw=True, f_number=0.7, interp=I.Cubic,
         stages=(S.Demodulate, S.Decode, S.DAS), plane="xz", plane_offset=0.4e-3)
     c["hercules_plane_yz"] = lambda: cfg.hercules(
-        "hercules_plane_yz", 7, 16, 512, (64, 40, 1), LO3, HI3, seed=82, cw=True, f_number=0.7,
+        "hercules_plane_yz", 7, 16, 1024, (64, 40, 1), LO3, HI3, seed=82, cw=True, f_number=0.7,
+        stages=(S.Demodulate, S.Decode, S.DAS), plane="yz", plane_offset=-0.3e-3)
+    c["hercules_plane_xz_short_rows"] = lambda: cfg.hercules(
+        "hercules_plane_xz_short_rows", 7, 16, 512, (64, 48, 1), LO3, HI3, seed=81, cw=True, f_number=0.7, interp=I.Cubic,
+        stages=(S.Demodulate, S.Decode, S.DAS), plane="xz", plane_offset=0.4e-3)
+    c["hercules_plane_yz_short_rows"] = lambda: cfg.hercules(
+        "hercules_plane_yz_short_rows", 7, 16, 512, (64, 40, 1), LO3, HI3, seed=82, cw=True, f_number=0.7,
         stages=(S.Demodulate, S.Decode, S.DAS), plane="yz", plane_offset=-0.3e-3)
     c["uhercules_plane_xz_sparse"] = lambda: cfg.hercules(
         "uhercules_plane_xz_sparse", 6, 8, 512, (56, 33, 1), LO3, HI3, seed=83, kind=K.UHERCULES,
@@ -245,4 +253,10 @@ EXPECTED_AUTOMATIC = {
     "rca_staged_real": 2, "rca_staged_cubic": 2, "rca_staged_fine": 2, "rca_sep_ragged_cubic": 3, "rca_sep_real_nearest": 3,
     "hercules_wide_cw": 5, "hercules_wide_real_swapped": 5, "hercules_wide_cubic_cw": 5, "hercules_plane_xz": 5, "hercules_plane_yz": 5,
     "forces": 3, "uforces_sparse": 3, "readi": 0, "harness_tpw_small": 3, "harness_forces_small": 3, "harness_hercules_small": 0,
+    "hercules_plane_xz_short_rows": 5, "hercules_plane_yz_short_rows": 5,
+}
+# ... and how many z-planes of the case the row-end rule hands to the kernel BEHIND that choice (cases not listed: none)
+EXPECTED_ROW_END_PLANES = {
+    "rca_staged_auto": 1, "rca_staged_fine": 1, "rca_staged_ragged": 1,
+    "rca_staged_cubic_short_rows": 1, "rca_staged_real_short_rows": 1, "rca_staged_fine_vls_short_rows": 2, "rca_vls_staged_short_rows": 3,
 }

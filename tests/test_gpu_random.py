@@ -227,21 +227,8 @@ def test_random_acquisition_on_the_block_staged_kernel(seed, bflib, oracle):
         assert int(t.das_path) == path
     finally:
         lib.beamformer_hip_set_das_path(0)
-    try:
-        compare(gpu, ref, acq, flags)
-    except AssertionError:
-        # sample_rf's range test is a step: a term whose index sits within an ulp of the end of a (short) row is in for one arithmetic
-        # and out for the other -- one tap's worth of difference at that voxel, for EVERY kernel of the library alike.  Accept up to
-        # three such voxels, and only if the general kernel lands on the same values there.
-        scale = np.max(np.abs(ref[ok]))
-        bad = ok & (np.abs(gpu - ref) > cases.tolerance(acq) * scale)
-        lib.beamformer_hip_set_das_path(0x11)
-        try:
-            general = bflib.beamform(acq.bp, acq.rf, acq.filters)
-        finally:
-            lib.beamformer_hip_set_das_path(0)
-        assert 0 < int(bad.sum()) <= 3 and np.abs(gpu[ok] - general[ok]).max() <= 2e-4 * scale, (int(bad.sum()), float(np.abs(gpu[ok] - general[ok]).max() / scale))
-    if path == 6:
+    compare(gpu, ref, acq, flags)            # against the oracle, nothing else (round 3 accepted voxels on which another kernel agreed)
+    if int(t.das_path) == 6:
         TILE_DRAWS.append((seed, int(t.tile_staged_chunks), int(t.tile_gather_chunks)))
 
 
@@ -250,3 +237,55 @@ def test_random_draws_reach_the_block_staged_kernel():
     print(f"block-staged draws: {len(TILE_DRAWS)}: {TILE_DRAWS}")
     assert len(TILE_DRAWS) >= 20, TILE_DRAWS
     assert sum(1 for _, s, g in TILE_DRAWS if s > 0) >= 12 and sum(1 for _, s, g in TILE_DRAWS if g > 0) >= 3, TILE_DRAWS
+
+
+# ---- row ends (csrc/das_exact.h).  sample_rf's range test is a step: round 3's fast kernels formed the index as a rounded receive term plus
+# a rounded transmit term and kept or dropped a term within an ulp of the end of an RF row differently from the oracle -- one whole tap of
+# difference at a voxel.  These are the draws of round 3's out-of-sample fuzz (tools/auto_fuzz.py 72 600, tools/tile_fuzz.py) that failed
+# for it, fixed here as cases: every kernel that can take the draw, against the oracle.
+ROW_END_SEPARABLE = [96, 107, 112, 114, 120, 125, 130, 142, 160, 194, 201, 237, 241, 254, 259, 261, 268, 305, 318, 319, 343, 346, 361, 367, 385,
+                     398, 434, 439, 480, 495, 547, 584, 593]
+
+
+@pytest.mark.parametrize("seed", ROW_END_SEPARABLE)
+def test_row_end_draws_of_the_separable_generator(seed, bflib, oracle, hooks):
+    """automatic path, the general kernel, the gather kernel (never staged), the LDS-staged kernel wherever its window holds (every term
+    range-checked) and the factored kernel (block staging on request): the oracle's frame from each"""
+    acq = draw_separable(seed)
+    ref, pairs, flags = reference(oracle, acq)
+    lib = bflib.library()
+    ran = {}
+    for mode in (0, 1, 2, 3, 0x14, 0x114):
+        if mode == 3:
+            hooks.set("STAGED_CHECKED")
+        lib.beamformer_hip_set_das_path(mode)
+        try:
+            gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+            t = last_timings(bflib)
+            ran[mode] = (int(t.das_path), int(t.das_row_end_planes))
+            assert int(t.staged_window_violations) == 0
+        finally:
+            lib.beamformer_hip_set_das_path(0)
+            if mode == 3:
+                hooks.clear("STAGED_CHECKED")
+        compare(gpu, ref, acq, flags)
+    assert ran[1][0] == 0, ran
+
+
+@pytest.mark.parametrize("seed", [540, 11, 63, 131, 207])
+def test_row_end_draws_of_the_tile_generator(seed, bflib, oracle):
+    """540: the draw on which das_tile.hip's window-relative position arithmetic flipped ALONE in round 3; block staging asked for, the
+    factored kernel and the general kernel: the oracle's frame from each"""
+    acq = draw_tile(seed)
+    ref, pairs, flags = reference(oracle, acq)
+    ok = ~np.isnan(ref)
+    if not ok.any() or np.max(np.abs(ref[ok])) == 0:
+        pytest.skip("empty image")
+    lib = bflib.library()
+    for mode in (0x110, 0x210, 0x11):
+        lib.beamformer_hip_set_das_path(mode)
+        try:
+            gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        finally:
+            lib.beamformer_hip_set_das_path(0)
+        compare(gpu, ref, acq, flags)
