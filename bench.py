@@ -365,6 +365,33 @@ def main():
         rf_checksum_ok = len({d["rf_checksum"] for d in devices_info}) == 1 and all(d["rf_bytes"] > 0 for d in devices_info)
         assert rf_checksum_ok, f"the devices beamformed different RF: {devices_info}"
 
+    # The same frames with the RF coming from HOST memory through beamformer_push_data_with_compute -- what the reference's own harness times
+    # (tests/throughput.c:535-557: push -> frame, raw-RF GB/s) and what a C / MATLAB client of the unchanged API gets: the caller's bytes
+    # are copied into one of three pinned slots, cross PCIe on the copy stream while the previous frame computes, and the frame follows.
+    # Reported beside `value` (config.upload_inclusive), never as it.
+    upload = None
+    if not distributed and n_gpus == 1 and not args.planes:
+        host_rf = np.ascontiguousarray(acq.rf)
+        host_ptr, host_bytes = host_rf.ctypes.data_as(C.c_void_p), host_rf.nbytes
+
+        def host_step():
+            assert L.beamformer_push_data_with_compute(host_ptr, host_bytes, 0, 0), lib.last_error()
+            if args.config == 5:
+                assert L.beamformer_hip_frame_min_max(min_max), lib.last_error()
+
+        for _ in range(max(1, args.warmup)):
+            host_step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        fence()
+        per_frame = (time.perf_counter() - t1) / args.steps
+        upload = {"ms_per_frame": per_frame * 1e3, "voxels_per_s": voxels_total / per_frame, "rf_GBps": host_bytes / per_frame / 1e9,
+                  "rf_bytes_per_frame": host_bytes,
+                  "what": "host RF -> beamformer_push_data_with_compute (pinned three-slot upload, H2D on the copy stream overlapping the previous frame) "
+                          "-> frame, as tests/throughput.c:535-557 measures; `value` above starts from RF resident in HBM"}
+
     if distributed:
         agg = torch.tensor([elapsed, das_s, float(pairs_local)], dtype=torch.float64, device="cpu" if rehearse else device)
         mx = agg.clone()
@@ -431,6 +458,7 @@ def main():
                           "profiles/r02_other_configs.json, DESIGN.md section 8)"),
                 "scale": args.scale, "interpolation": P.InterpolationMode(bp.interpolation_mode).name,
                 "f_number": bp.f_number, "sharding": how,
+                "upload_inclusive": upload,
                 "das_path": PATH_NAMES[das_path], "das_plan": das_plan, "slab_verified": verified, "rf_checksum_equal_on_all_ranks": rf_checksum_ok,
                 "stage_ms": stage_ms, **({"device_das_ms": device_das_ms, "devices": devices_info} if device_das_ms else {}),
             },
@@ -497,6 +525,15 @@ def measured_traffic(config, kernel):
                                           f"`{entry.get('command', 'bench.py')}`, kernel sources {entry.get('kernel_source_sha16')}")
 
 
+def newest_profile(suffix):
+    """the newest round's profiles/rNN_<suffix> (the round's profile pass writes them: tools/profile_round.sh)"""
+    import glob
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not names:
+        raise OSError(suffix)
+    return names[-1]
+
+
 def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, terms, das_plan=None):
     """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
@@ -507,7 +544,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     achieved is measured live in this run; the VALU / LDS busy fractions next to it come from the committed PMC pass."""
     out = {}
     try:
-        micro_name = next(n for n in ("r03_microbench.json", "r02_microbench.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        micro_name = newest_profile("microbench.json")
         with open(os.path.join(ROOT, "profiles", micro_name)) as f:
             micro = json.load(f)
         cus = int(micro["compute_units"])
@@ -530,12 +567,14 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 out["stream_note"] = ("the probe's cubic stream evaluates the PREPARED segment polynomial (three packed fmas per pair); this frame is on a coarse grid, gathers the "
                                       "four raw taps with two gather instructions per pair and builds the Catmull-Rom cubic per pair (nine more packed operations), and a share "
                                       "of the executed pairs fails the f-number test: `frac` is measured against a lighter stream than the one that ran and counts passing pairs only")
-        elif kernel == "das_tile_kernel":
-            # VALU issue, priced against the kernel's own instruction stream as the committed PMC pass counted it (SQ_ACTIVE_INST_VALU: the
-            # cycles a SIMD spent issuing the kernel's VALU instructions, per executed wave64 term), and next to it the LDS read path: two
-            # ds_read_b128 per term and lane = 2 KiB per wave64 term at 128 B/clk/CU
+        elif kernel == "das_tile_kernel" and config == 2:
+            # VALU issue.  NOT an independent ceiling: the denominator is the VALU-busy time per executed wave64 term that the committed PMC pass
+            # counted for THIS kernel on THIS frame (SQ_ACTIVE_INST_VALU), so `frac` restates the kernel's VALU utilisation (passing terms
+            # over executed ones included) -- labelled so (`frac_is`); other frames that take das_tile.hip are left unpriced.  Next to it the LDS
+            # read path: two ds_read_b128 per term and lane = 2 KiB per wave64 term at 128 B/clk/CU
             clock = max(g["clock_ghz"] for g in micro["gather"])
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_tile_cfg2.json")) as f:
+            tile_name = newest_profile("pmc_tile_cfg2.json")
+            with open(os.path.join(ROOT, "profiles", tile_name)) as f:
                 pmc = json.load(f)
             per_term = pmc["valu_busy_cycles_per_wave_term_per_simd"]
             peak = cus * 4 * 64 * clock * 1e9 / per_term
@@ -548,11 +587,15 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "achieved": terms / das_s / 1e12, "unit": "T terms/s (terms that pass the f-number test)", "peak": peak / 1e12,
                 "peak_model": f"{cus} CUs x 4 SIMDs x 64 lanes x {clock:.3f} GHz / {per_term:.1f} clk (every SIMD issuing nothing but this kernel's VALU stream)",
                 "frac": terms / das_s / peak, "probe_clock_ghz": clock, "peak_cycles_per_term_per_simd": per_term,
-                "source": "profiles/r03_pmc_tile_cfg2.json (tools/pmc_das.py, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU over config 2's launch); achieved measured in this run",
+                "frac_is": "VALU utilisation of this kernel on this frame restated (its own PMC-counted VALU-busy time per term is the denominator), not a fraction of an independent ceiling",
+                "source": f"profiles/{tile_name} (tools/pmc_das.py, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU over config 2's launch); achieved measured in this run",
                 "lds_read_path": {"cycles_per_term_per_cu": lds_clk, "peak": lds_peak / 1e12, "frac": terms / das_s / lds_peak,
                                   "model": "two ds_read_b128 per term and lane = 2 KiB per wave64 term at 128 B/clk/CU: the floor under the gathers' 32.6 clk "
                                            "(two wave64 gather instructions through L1), which is what das_factored.hip waits for on the same frame"},
             }
+        elif kernel == "das_tile_kernel":
+            out = {"resource": "VALU issue (das_tile.hip); unpriced on this frame: the kernel has no independent stream probe, and its PMC-derived utilisation "
+                               "figure is committed for BASELINE config 2 only"}
         elif kernel == "das_rca_staged_kernel":
             best = min((v for v in micro["valu_stream"] if v["waves_per_simd"] == 8 and v["stream"].startswith("das_staged term, shipping form")),
                        key=lambda v: v["cycles_per_term_per_simd_wall"])
@@ -603,7 +646,7 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
     except (OSError, KeyError, ValueError, StopIteration):
         out = {"resource": "unpriced: profiles/r0x_microbench.json missing or without the probe this kernel needs"}
     try:
-        bound_name = next(n for n in ("r03_das_bound.json", "r02_das_bound.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        bound_name = newest_profile("das_bound.json")
         with open(os.path.join(ROOT, "profiles", bound_name)) as f:
             bound = json.load(f)
         entry = bound[f"config{config}" if isinstance(config, int) else config][kernel]

@@ -305,6 +305,8 @@ typedef struct {
 	float    tile_spread_estimate;  /* factored-kernel frames: the host's upper bound of a 1024-voxel tile's delay spread in samples (what decides
 	                                   for or against path 6; the kernel measures the real spread per block and chunk); 0 where not computed */
 	uint32_t tile_estimate_shift[3];/* ... and the tile it was computed for */
+	uint32_t row_ends;              /* 1: some in-aperture term of the launch may come within reach of an end of its RF row (a host bound, per plane, in
+	                                   double precision): the kernel's instantiation WITH the exact row-end evaluation runs (csrc/das_exact.h); 0: the one without */
 } BeamformerHipDasDescription;
 BEAMFORMER_LIB_EXPORT uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDescription *out);
 

@@ -65,7 +65,10 @@ typedef struct {
 	                                     behind the DAS input, the gather target of out-of-range lanes */
 	uint32_t tile_window_shift;       /* das_tile.hip: log2 of the staged window length (5 or 6) */
 	float    edge_margin;             /* samples: a term whose index comes this close to an end of sample_rf's valid range is decided by the
-	                                     shader's own expression, evaluated exactly (das_exact.h); 2^-18 of the largest index magnitude */
+	                                     shader's own expression, evaluated exactly (das_exact.h); 2^-19 of the largest index magnitude */
+	uint32_t row_ends;                /* 1: some in-aperture term of this launch may come within reach of an end of its RF row (a host bound over the
+	                                     launch's planes, das_select.cpp; 1 also where no bound is implemented).  The factored and HERCULES kernels
+	                                     have an instantiation without any row-end code for launches where it is 0 */
 } BfDasArgs;
 
 /* tile geometry of the separable-delay fast path (das_separable.hip) */

@@ -27,17 +27,19 @@
 
 namespace bfx {
 
-#define BF_EXACT_STAGE() ((void)0)
-
 /* valid range of sample_rf as floats: lo <= index < hi */
 template <int INTERP> __device__ __forceinline__ float edge_lo()        { return INTERP == BF_INTERP_CUBIC ? 1.0f : 0.0f; }
 template <int INTERP> __device__ __forceinline__ float edge_hi(int S)   { return (float)(S - (INTERP == BF_INTERP_CUBIC ? 2 : 1)); }
 
-/* within `margin` of an end of the valid range (false for a NaN) */
+/* within `margin` of an end of the valid range (false for a NaN).  One expression for both ends -- the distance from the middle of the
+ * range, less half its length, is within the margin of zero: two subtractions and a compare (the loops that carry this test per term are
+ * VALU bound).  The subtraction from the middle is rounded at an ulp of S, far inside the margin; every loop and its fix-up use this one
+ * function, so they agree on which terms are "near". */
 template <int INTERP>
 __device__ __forceinline__ bool edge_near(float index, int S, float margin)
 {
-	return __builtin_fabsf(index - edge_hi<INTERP>(S)) < margin || __builtin_fabsf(index - edge_lo<INTERP>()) < margin;
+	const float half = 0.5f * (edge_hi<INTERP>(S) - edge_lo<INTERP>()), mid = edge_lo<INTERP>() + half;        /* (scalars: exact halves of integers) */
+	return __builtin_fabsf(__builtin_fabsf(index - mid) - half) < margin;
 }
 /* strictly inside the valid range, a margin away from both ends: what a fast kernel may decide by its own index */
 template <int INTERP>
@@ -63,21 +65,16 @@ __device__ __forceinline__ Voxel exact_voxel(const P &p, uint32_t x, uint32_t y,
 	const float px = (float)x / (float)(p.size[0] > 2u ? p.size[0] - 1u : 1u);
 	const float py = (float)y / (float)(p.size[1] > 2u ? p.size[1] - 1u : 1u);
 	const float pz = (float)z / (float)(p.size[2] > 2u ? p.size[2] - 1u : 1u);
-	/* (one matrix at a time: the compiler fences keep the scalar loads of the second matrix -- and of whatever the caller reads next --
-	 * behind the arithmetic that consumes the first, so that this path never holds both in scalar registers beside a fast kernel's own) */
-	BF_EXACT_STAGE();
 	const auto &m = p.voxel_transform;
 	v.wx = m[0] * px + m[4] * py + m[8]  * pz + m[12];
 	v.wy = m[1] * px + m[5] * py + m[9]  * pz + m[13];
 	v.wz = m[2] * px + m[6] * py + m[10] * pz + m[14];
-	BF_EXACT_STAGE();
 	if constexpr (FAMILY == BF_DAS_RCA || FAMILY == BF_DAS_HERCULES) {
 		const auto &t = p.xdc_transform;
 		v.xx = t[0] * v.wx + t[4] * v.wy + t[8]  * v.wz + t[12];
 		v.xy = t[1] * v.wx + t[5] * v.wy + t[9]  * v.wz + t[13];
 		v.xz = t[2] * v.wx + t[6] * v.wy + t[10] * v.wz + t[14];
-		BF_EXACT_STAGE();
-	} else {
+		} else {
 		v.xx = v.wx; v.xy = v.wy; v.xz = v.wz;
 	}
 	return v;

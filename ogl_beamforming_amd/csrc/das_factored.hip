@@ -64,7 +64,9 @@ __device__ __forceinline__ float transmit_distance(const BfTransmit &t, float wx
 	return result;
 }
 
-template <int FAMILY, int INTERP, bool CPLX, bool CW>
+/* ROW_ENDS: the instantiation for launches in which a term can come within reach of an end of its RF row (BfDasArgs::row_ends, a host
+ * bound: das_select.cpp); the other one carries none of that code -- its loops and its register allocation are round 3's. */
+template <int FAMILY, int INTERP, bool CPLX, bool CW, bool ROW_ENDS>
 __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 {
 	constexpr int      CH = BF_FACTORED_CHUNK(INTERP);
@@ -105,6 +107,13 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 	uint32_t ly  = (tid >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u);
 	uint32_t lz  = (tid >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u);
 	uint32_t split = tid >> (p.tile_shift[0] + p.tile_shift[1] + p.tile_shift[2]);
+	/* (the voxel is worked out again where it is needed after the channel loop -- the row-end pass, the store -- rather than held in
+	 * registers across it: the linear IQ instances run at their 128-register limit) */
+	auto voxel_of = [&](uint32_t thread, uint32_t &vx, uint32_t &vy, uint32_t &vz) {
+		vx = (bx << p.tile_shift[0]) + (thread & ((1u << p.tile_shift[0]) - 1u));
+		vy = (by << p.tile_shift[1]) + ((thread >> p.tile_shift[0]) & ((1u << p.tile_shift[1]) - 1u));
+		vz = (bz << p.tile_shift[2]) + ((thread >> (p.tile_shift[0] + p.tile_shift[1])) & ((1u << p.tile_shift[2]) - 1u));
+	};
 	uint32_t x = (bx << p.tile_shift[0]) + lx;
 	uint32_t y = (by << p.tile_shift[1]) + ly;
 	uint32_t zl = (bz << p.tile_shift[2]) + lz;
@@ -196,10 +205,11 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		 * every chunk of nearly every frame) runs the loops below as they are; otherwise the EDGE forms of the same loops leave the terms
 		 * inside the margin out, and a pass at the END of the kernel (its registers are not the loops') evaluates those with the shader's
 		 * own index. */
-		constexpr bool EDGES = INTERP != BF_INTERP_NEAREST;      /* (nearest flips at every half-integer: budgeted per voxel by the tests) */
-		const float edge_margin = p.edge_margin;
-		float t_lo = 0.f, t_hi = 0.f;
-		unsigned long long edge_lanes = 0;                       /* lanes of this wave with a term left out (a scalar) */
+		constexpr bool EDGES = ROW_ENDS && INTERP != BF_INTERP_NEAREST;      /* (nearest flips at every half-integer: budgeted per voxel by the tests) */
+		[[maybe_unused]] const float edge_margin = p.edge_margin;
+		[[maybe_unused]] float t_lo = 0.f, t_hi = 0.f;
+		[[maybe_unused]] unsigned long long edge_lanes = 0;                       /* lanes of this wave with a term left out in the current chunk (a scalar) */
+		[[maybe_unused]] unsigned long long edge_chunks = 0;                      /* the chunks (bit = chunk number within this wave's channel range) in which that happened */
 		if constexpr (EDGES) {
 			t_lo = __builtin_inff(); t_hi = -__builtin_inff();
 			for (int a = first_transmit; a < A; a++) {
@@ -240,6 +250,16 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 					                                                   R[k].index + t_hi <  bfx::edge_hi<INTERP>(S) - edge_margin));
 				edges = __builtin_amdgcn_ballot_w64(!lane_safe) != 0ull;
 			}
+			/* ... and then, per transmit, whether any lane's receive terms of this chunk [r_lo, r_hi] plus THAT transmit term reach an end:
+			 * only those transmits run the EDGE form of the body (two adds and two compares per transmit instead of a test per term) */
+			[[maybe_unused]] float r_lo = __builtin_inff(), r_hi = -__builtin_inff();
+			if constexpr (EDGES) {
+				if (edges) {
+					#pragma unroll
+					for (int k = 0; k < CH; k++)
+						if (R[k].index > -1.0e8f) { r_lo = fminf(r_lo, R[k].index); r_hi = fmaxf(r_hi, R[k].index); }
+				}
+			}
 
 			sample_t<CPLX> part[CH];
 			float          part_abs[CH];
@@ -253,11 +273,8 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			#pragma unroll
 			for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; }
 
-			auto transmit_loop = [&](auto edge_c) {
-			constexpr bool EDGE = decltype(edge_c)::value;      /* leave out (and note) the terms within the margin of a row end */
-			for (int a = first_transmit; a < A; a++) {
-				float t_index = transmit_index(a);
-				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
+			auto transmit_body = [&](auto edge_c, int a, float t_index) {
+				constexpr bool EDGE = decltype(edge_c)::value;      /* leave out (and note) the terms within the margin of a row end */
 				float tc = 1.f, ts = 0.f;
 				if constexpr (CPLX) {
 					float turns = hw_fract(turns_per_sample * t_index);
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 							off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
 						}
 						if constexpr (EDGE) {
-							const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin) && R[k].index > -1.0e8f;
+							const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin);      /* (a channel outside the aperture: index -1e9, never near) */
 							edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
 							off[k] = edge ? p.zero_offset : off[k];
 						}
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 							if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
 						}
 					}
-					continue;
+					return;
 				}
 				Tap<INTERP>           tap[CH];
 				TapData<INTERP, CPLX> data[CH];
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				for (int k = 0; k < CH; k++) {
 					float index = t_index + R[k].index;
 					if constexpr (EDGE) {
-						const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin) && R[k].index > -1.0e8f;
+						const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin);      /* (a channel outside the aperture: index -1e9, never near) */
 						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
 						index = edge ? -8.0f : index;                                 /* outside every mode's range: zero weights */
 					}
@@ -357,14 +374,18 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						if constexpr (CW) part_abs[k] += __builtin_fabsf(s);
 					}
 				}
-			}
 			};
-			if constexpr (EDGES) {
-				if (edges) transmit_loop(std::true_type{});
-				else       transmit_loop(std::false_type{});
-			} else {
-				transmit_loop(std::false_type{});
+			if constexpr (EDGES) edge_lanes = 0;
+			for (int a = first_transmit; a < A; a++) {
+				float t_index = transmit_index(a);
+				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
+				if constexpr (EDGES) {
+					const bool reach = edges && !(r_lo + t_index >= bfx::edge_lo<INTERP>() + edge_margin && r_hi + t_index < bfx::edge_hi<INTERP>(S) - edge_margin);
+					if (__builtin_amdgcn_ballot_w64(reach) != 0ull) { transmit_body(std::true_type{}, a, t_index); continue; }
+				}
+				transmit_body(std::false_type{}, a, t_index);
 			}
+			if constexpr (EDGES) { if (edge_lanes != 0ull) edge_chunks |= 1ull << (uint32_t)((c0 - ch_begin) / CH); }
 
 			#pragma unroll
 			for (int k = 0; k < CH; k++) {
@@ -380,11 +401,19 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		}
 
 		if constexpr (EDGES) {
-			if (edge_lanes != 0ull) {
-				/* ---- row ends: the terms the loops above left out.  The same sum of the same two rounded terms (receive_index,
-				 * transmit_index), so the same terms; each evaluated from the voxel's integer coordinates with the shader's own
-				 * index (das_exact.h) and added to the voxel's sums.  Rare: a wave gets here only if one of its lanes had such a term. */
-				for (int channel = ch_begin; channel < ch_end; channel++) {
+			/* ---- row ends: the terms the loops above left out, chunk by chunk of those that left any out (at most 64 chunks: 256 channels in
+			 * chunks of four).  The same sum of the same two rounded terms (receive_index, transmit_index), so the same terms; each evaluated
+			 * from the voxel's integer coordinates with the shader's own index (das_exact.h) and added to the voxel's sums. */
+			uint32_t ex, ey, ezl, thread = threadIdx.x;
+			asm volatile("" : "+v"(thread));                     /* not the values computed before the loop */
+			voxel_of(thread, ex, ey, ezl);
+			while (edge_chunks != 0ull) {
+				const int chunk = __builtin_ctzll(edge_chunks);
+				edge_chunks &= edge_chunks - 1ull;
+				#pragma unroll 1
+				for (int k = 0; k < CH; k++) {
+					const int channel = ch_begin + chunk * CH + k;
+					if (channel >= ch_end) break;
 					float dx;
 					const float r_index = receive_index(channel, dx);
 					const bool  pass = __builtin_fabsf(dx * f_over_z) < 0.5f;
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						asm volatile("" : "+v"(t_index));
 						const float index = t_index + r_index;
 						if (pass && bfx::edge_near<INTERP>(index, S, edge_margin))
-							bfx::edge_term<FAMILY, INTERP, CPLX, CW>(bfx::kernel_args(), x, y, p.z_first + zl, channel, a, coherent, incoherent);
+							bfx::edge_term<FAMILY, INTERP, CPLX, CW>(bfx::kernel_args(), ex, ey, p.z_first + ezl, channel, a, coherent, incoherent);
 					}
 				}
 			}
@@ -423,7 +452,10 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 	}
 
 	if (inside) {
-		uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * zl + (uint64_t)p.size[0] * y + x;
+		uint32_t sx, sy, szl, thread = threadIdx.x;
+		asm volatile("" : "+v"(thread));
+		voxel_of(thread, sx, sy, szl);
+		uint64_t out_index = (uint64_t)p.size[0] * p.size[1] * szl + (uint64_t)p.size[0] * sy + sx;
 		sample_t<CPLX> v = coherent;
 		if constexpr (CW) v = v * (v / incoherent);                      /* coherency_weighting.glsl:36 */
 		reinterpret_cast<sample_t<CPLX> *>(p.out)[out_index] = v;
@@ -437,7 +469,8 @@ hipError_t launch_one(const BfDasArgs *a, hipStream_t s)
 	uint32_t grid    = a->depth_major == 3u ? bf_plane_walk_blocks(a->blocks[0], a->blocks[1], a->band_rows) : ((total + 7u) / 8u) * 8u;
 	uint32_t threads = a->split_shift ? 64u << a->split_shift : 256u;
 	uint32_t lds     = a->split_shift ? ((1u << a->split_shift) - 1u) * 192u * (uint32_t)sizeof(float) : 0u;
-	hipLaunchKernelGGL((das_factored_kernel<FAMILY, INTERP, CPLX, CW>), dim3(grid), dim3(threads), lds, s, *a);
+	if (a->row_ends && INTERP != BF_INTERP_NEAREST) hipLaunchKernelGGL((das_factored_kernel<FAMILY, INTERP, CPLX, CW, true>), dim3(grid), dim3(threads), lds, s, *a);
+	else                                            hipLaunchKernelGGL((das_factored_kernel<FAMILY, INTERP, CPLX, CW, false>), dim3(grid), dim3(threads), lds, s, *a);
 	return hipGetLastError();
 }
 

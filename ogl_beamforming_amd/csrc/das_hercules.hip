@@ -173,9 +173,12 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
  * complex coefficients of the Catmull-Rom segment [k, k + 1] as a polynomial in the fraction (das.glsl:67-97: a0 = P1,
  * a1 = T1, a2 = 3 (P2 - P1) - 2 T1 - T2, a3 = 2 (P1 - P2) + T1 + T2) -- 32 bytes, two aligned gathers -- and the Hermite
  * weights, the tangents and the four-term sum of every pair become a three-step Horner chain of packed fmas. */
-template <int INTERP, bool CPLX, bool CW, bool PL, bool PD>
+/* ROW_ENDS: the instantiation for launches in which a pair can come within reach of an end of its RF row (BfDasArgs::row_ends, a host
+ * bound: das_select.cpp); the other one carries none of that code -- its loops and its register allocation are round 3's. */
+template <int INTERP, bool CPLX, bool CW, bool PL, bool PD, bool ROW_ENDS>
 __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
 {
+	constexpr bool EDGES = ROW_ENDS && INTERP != BF_INTERP_NEAREST;     /* (nearest flips at every half-integer: budgeted per voxel by the tests) */
 	static_assert(!PD || (CPLX && INTERP != BF_INTERP_NEAREST), "prepared data: linear or cubic interpolation of complex samples");
 	constexpr bool POLY = PD && INTERP == BF_INTERP_CUBIC;       /* q.pairs holds the cubic segment polynomials (hercules_cubic_kernel) */
 	constexpr uint32_t ES = POLY ? 32 : PD ? 16 : CPLX ? 8 : 4;
@@ -251,8 +254,8 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 
 	VT    coherent   = zero_sample<CPLX>();
 	float incoherent = 0.f;
-	const float edge_margin = p.edge_margin;
-	unsigned long long edge_lanes = 0;         /* checked loop: the lanes with a pair left out at an end of its RF row (a scalar) */
+	[[maybe_unused]] const float edge_margin = p.edge_margin;
+	[[maybe_unused]] unsigned long long edge_lanes = 0;         /* checked loop: the lanes with a pair left out at an end of its RF row (a scalar) */
 
 	for (int m = 0; m < n_outer; m++) {
 		float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				}
 				dist[k]  = f32x2{hw_sqrt(dd.x), hw_sqrt(dd.y)};
 				/* (checked loop: explicit fmas -- the row-end pass at the end of the kernel forms the same index again, bit for bit) */
-				if constexpr (CHECK) index[k] = f32x2{__builtin_fmaf(dist[k].x, fs_over_c, T0), __builtin_fmaf(dist[k].y, fs_over_c, T0)};
+				if constexpr (CHECK && EDGES) index[k] = f32x2{__builtin_fmaf(dist[k].x, fs_over_c, T0), __builtin_fmaf(dist[k].y, fs_over_c, T0)};
 				else                 index[k] = dist[k] * kp + T0p;
 				if constexpr (CPLX) { if constexpr (PL) turns[k] = index[k] * tpsp - btp; else turns[k] = index[k] * tpsp; }
 			}
@@ -328,14 +331,17 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					if constexpr (CHECK) {
 						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124); a term within the margin of an end of its
 						 * row is left out here and evaluated with the shader's own index at the end of the kernel (das_exact.h) */
-						const bool edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
-						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
+						bool edge = false;
+						if constexpr (EDGES) {
+							edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
+							edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
+						}
 						bool ok = ((POLY || RAWC) ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test) && !edge;
 						off[k] = ok ? off[k] : q.zero_offset;
 						ap[k]  = ok ? ap[k] : 0.f;
 					}
 				} else {
-					if constexpr (CHECK && INTERP != BF_INTERP_NEAREST) {
+					if constexpr (CHECK && EDGES) {
 						const bool edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
 						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
 						idx = edge ? -8.0f : idx;                     /* outside every mode's range: zero weights */
@@ -442,24 +448,29 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		}
 		if constexpr (CW) incoherent += outer_weight * mag;
 	}
-	if constexpr (INTERP != BF_INTERP_NEAREST) {
+	if constexpr (EDGES) {
 		if (edge_lanes != 0ull) {
 			/* ---- row ends: the pairs the checked loop left out -- the same index arithmetic, so the same pairs -- each evaluated from
 			 * the voxel's integer coordinates with the shader's own index (das_exact.h), weight and all, into the voxel's sums.  Rare: a
 			 * wave gets here only if one of its lanes had such a pair; its registers are not the loops'. */
 			const int sparse = p.sparse != 0;
+			uint32_t ex = x;
+			asm volatile("" : "+v"(ex));                       /* (or hipcc evaluates the exact voxel transform at the top of the kernel and keeps it across the loops) */
 			for (int m = 0; m < n_outer; m++) {
 				const float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
 				const float od  = outer_lateral - outer_element * outer_pitch;
 				const float od2 = od * od * s2;
 				if (__builtin_amdgcn_ballot_w64(od2 + d2_min < apodization_test) == 0) continue;
+				/* (only outer elements for which some lane's index range reaches an end of its row: the loop's own test) */
+				const float i_lo = T0 + hw_sqrt(z2 + (od2 + d2_min)) * fs_over_c, i_hi = T0 + hw_sqrt(z2 + (od2 + d2_max)) * fs_over_c;
+				if (__builtin_amdgcn_ballot_w64(!(i_lo >= bfx::edge_lo<INTERP>() + 0.5f && i_hi < bfx::edge_hi<INTERP>(S) - 0.5f)) == 0) continue;
 				for (int n = 0; n < n_inner; n++) {
 					const float e2  = od2 + row_d2[n];
 					const float idx = __builtin_fmaf(hw_sqrt(z2 + e2), fs_over_c, T0);
 					if (e2 < apodization_test && bfx::edge_near<INTERP>(idx, S, edge_margin)) {
 						const int channel  = q.inner_is_transmit ? m : n;
 						const int transmit = (q.inner_is_transmit ? n : m) + sparse;
-						bfx::edge_term<BF_DAS_HERCULES, INTERP, CPLX, CW>(bfx::kernel_args(), x, y, z, channel, transmit, coherent, incoherent);
+						bfx::edge_term<BF_DAS_HERCULES, INTERP, CPLX, CW>(bfx::kernel_args(), ex, y, z, channel, transmit, coherent, incoherent);
 					}
 				}
 			}
@@ -487,7 +498,8 @@ static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipSt
 	}
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = q->depth_major == 3u ? bf_plane_walk_blocks(q->tiles[0], q->tiles[1], q->band_rows) : ((total + 7u) / 8u) * 8u;
-	hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD>), dim3(grid), dim3(256), 0, s, *a, *q);
+	if (a->row_ends && INTERP != BF_INTERP_NEAREST) hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD, true>), dim3(grid), dim3(256), 0, s, *a, *q);
+	else                                            hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD, false>), dim3(grid), dim3(256), 0, s, *a, *q);
 	return hipGetLastError();
 }
 

@@ -585,10 +585,11 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	a.f_number    = bp.f_number;
 	/* das_exact.h: how close to an end of an RF row a kernel may still trust its own index.  The index is a sum of terms of magnitude
 	 * up to M = S + |t0 fs| (distance terms and the time offset), each rounded a few times on its way: the kernels' indices and the
-	 * shader's differ by <~ 10 ulp(M) = M 2^-19.7.  The margin is M 2^-18 (2^-9 sample for 512-sample rows, 2^-7 for 2048), never under 2^-10. */
+	 * shader's differ by a few ulp(M) = M 2^-23 (measured bound: the out-of-sample fuzz, profiles/r04_fuzz.json, runs with this margin).  The
+	 * margin is M 2^-19 -- 16 ulp(M): 2^-10 sample for 512-sample rows, 2^-8 for 2048 --, never under 2^-11. */
 	{
 		const float magnitude = (float)Sd + std::fabs(plan.das_time_offset * plan.das_sampling_frequency);
-		a.edge_margin = std::fmax(std::ldexp(magnitude, -18), std::ldexp(1.0f, -10));
+		a.edge_margin = std::fmax(std::ldexp(magnitude, -19), std::ldexp(1.0f, -11));
 		if (!(a.edge_margin < 0.25f)) a.edge_margin = 0.25f;        /* (wild parameters; also a NaN) */
 	}
 	a.size[0] = plan.output_points[0]; a.size[1] = plan.output_points[1]; a.size[2] = plan.output_points[2];
@@ -810,17 +811,60 @@ Range plane_index_bounds(const BfDasArgs &a, const std::vector<BfTransmit> &tx, 
 	auto over_corners = [&](auto f) { Range r{1e300, -1e300}; for (int k = 0; k < 4; k++) { double v = f(k); r.lo = std::fmin(r.lo, v); r.hi = std::fmax(r.hi, v); } return r; };
 	const bool forces = a.family == BF_DAS_FORCES;
 	const int  r_axis = forces ? 0 : ((tx[0].flags & BF_RX_ROWS) ? 1 : 0);
-	const double pitch_r = a.pitch[r_axis];
 	const Range zr = over_corners([&](int k) { return xdc[k][2]; });
 	const Range za = abs_range(zr.lo, zr.hi);
 	/* receive: |dx| < |z| / (2 F#) inside the aperture, and never beyond what the array and the plane allow */
-	const Range lat = over_corners([&](int k) { return xdc[k][r_axis]; });
-	const double last = (double)(a.channel_count - 1) * pitch_r;
-	double dx_max = std::fmax(std::fmax(std::fabs(lat.lo), std::fabs(lat.hi)), std::fmax(std::fabs(lat.lo - last), std::fabs(lat.hi - last)));
+	auto reach_along = [&](int axis) {
+		const Range lat = over_corners([&](int k) { return xdc[k][axis]; });
+		const double last = (double)(a.channel_count - 1) * (double)a.pitch[axis];
+		return std::fmax(std::fmax(std::fabs(lat.lo), std::fabs(lat.hi)), std::fmax(std::fabs(lat.lo - last), std::fabs(lat.hi - last)));
+	};
+	double dx_max = reach_along(r_axis);
+	if (!forces && a.family == BF_DAS_RCA)
+		for (const BfTransmit &t : tx)                          /* per-transmit receive orientations (general kernel): the larger reach */
+			if (((t.flags & BF_RX_ROWS) ? 1 : 0) != r_axis) { dx_max = std::fmax(dx_max, reach_along(1 - r_axis)); break; }
 	if (a.f_number > 0) dx_max = std::fmin(dx_max, 0.5 * za.hi / (double)a.f_number);
 	const double rx_max = std::sqrt(dx_max * dx_max + za.hi * za.hi), rx_min = za.lo;
 	const double c = a.speed_of_sound, fs = a.sampling_frequency, t0 = a.time_offset;
 	Range index{1e300, -1e300};
+	/* das.glsl:187-202 over the plane: a plane wave's "distance" is affine (extremes at the corners); a focused or diverging wave's is
+	 * the distance to the focus: largest at a corner, smallest zero if the focus lies inside the (px, pz) image of the plane, else the
+	 * distance to its boundary (corner order 0, 1, 3, 2 walks the parallelogram) */
+	auto transmit_range = [&](const BfTransmit &t) {
+		Range d{0.0, 0.0};
+		if (t.flags & BF_TX_NONE) return d;
+		const int w = (t.flags & BF_TX_ROWS) ? 1 : 0;
+		if (t.flags & BF_TX_PLANE) return over_corners([&](int k) { return world[k][w] * (double)t.sin_a + world[k][2] * (double)t.cos_a; });
+		d = over_corners([&](int k) { return std::hypot(world[k][w] - (double)t.focus_x, world[k][2] - (double)t.focus_z); });
+		const int order[4] = {0, 1, 3, 2};
+		double nearest = 1e300; int sign = 0; bool inside = true;
+		for (int e = 0; e < 4; e++) {
+			const int i = order[e], j = order[(e + 1) & 3];
+			nearest = std::fmin(nearest, point_segment_distance(t.focus_x, t.focus_z, world[i][w], world[i][2], world[j][w], world[j][2]));
+			const double cross = (world[j][w] - world[i][w]) * ((double)t.focus_z - world[i][2]) - (world[j][2] - world[i][2]) * ((double)t.focus_x - world[i][w]);
+			if (cross != 0) { const int sg = cross > 0 ? 1 : -1; if (sign && sg != sign) inside = false; sign = sg; }
+		}
+		d.lo = (inside && sign) ? 0.0 : nearest;
+		return d;
+	};
+	if (a.family == BF_DAS_HERCULES) {
+		/* das.glsl:233-286: index = T0(voxel) + sqrt(z^2 + e^2) fs / c over element pairs with e^2 < z^2 / (4 F#^2); without an f-number
+		 * every pair passes: e^2 then is bounded by the array (both lateral axes) */
+		double e_max;
+		if (a.f_number > 0) e_max = 0.5 * za.hi / (double)a.f_number;
+		else {
+			const Range lx = over_corners([&](int k) { return xdc[k][0]; }), ly = over_corners([&](int k) { return xdc[k][1]; });
+			const double n = (double)(a.channel_count > a.acquisition_count ? a.channel_count : a.acquisition_count) + 1.0;
+			double far_x = std::fabs(n * a.pitch[0]), far_y = std::fabs(n * a.pitch[1]);
+			if (a.sparse) for (int t = 0; t + 1 < a.acquisition_count; t++) { far_x = std::fmax(far_x, std::fabs((double)sparse_elements[t] * a.pitch[0])); far_y = std::fmax(far_y, std::fabs((double)sparse_elements[t] * a.pitch[1])); }
+			const double ex = std::fmax(std::fabs(lx.lo), std::fabs(lx.hi)) + far_x, ey = std::fmax(std::fabs(ly.lo), std::fabs(ly.hi)) + far_y;
+			e_max = std::sqrt(ex * ex + ey * ey);
+		}
+		const Range d = transmit_range(tx[0]);
+		index.lo = (d.lo / c + t0) * fs + za.lo * fs / c;
+		index.hi = (d.hi / c + t0) * fs + std::sqrt(za.hi * za.hi + e_max * e_max) * fs / c;
+		return index;
+	}
 	if (forces) {
 		/* das.glsl:288-321: every decoded transmit element e: sqrt((y - pitch_y C / 2)^2 + z^2 + (x - pitch_x e)^2) */
 		const double half = (double)a.pitch[1] * (double)a.channel_count / 2.0;
@@ -837,26 +881,7 @@ Range plane_index_bounds(const BfDasArgs &a, const std::vector<BfTransmit> &tx, 
 		return index;
 	}
 	for (const BfTransmit &t : tx) {
-		Range d{0.0, 0.0};
-		if (!(t.flags & BF_TX_NONE)) {
-			const int w = (t.flags & BF_TX_ROWS) ? 1 : 0;
-			if (t.flags & BF_TX_PLANE) {
-				d = over_corners([&](int k) { return world[k][w] * (double)t.sin_a + world[k][2] * (double)t.cos_a; });
-			} else {
-				d = over_corners([&](int k) { return std::hypot(world[k][w] - (double)t.focus_x, world[k][2] - (double)t.focus_z); });
-				/* smallest distance from the focus to the (px, pz) image of the plane: zero if the focus lies inside it, else the distance
-				 * to its boundary (corner order 0, 1, 3, 2 walks the parallelogram) */
-				const int order[4] = {0, 1, 3, 2};
-				double nearest = 1e300; int sign = 0; bool inside = true;
-				for (int e = 0; e < 4; e++) {
-					const int i = order[e], j = order[(e + 1) & 3];
-					nearest = std::fmin(nearest, point_segment_distance(t.focus_x, t.focus_z, world[i][w], world[i][2], world[j][w], world[j][2]));
-					const double cross = (world[j][w] - world[i][w]) * ((double)t.focus_z - world[i][2]) - (world[j][2] - world[i][2]) * ((double)t.focus_x - world[i][w]);
-					if (cross != 0) { const int sg = cross > 0 ? 1 : -1; if (sign && sg != sign) inside = false; sign = sg; }
-				}
-				d.lo = (inside && sign) ? 0.0 : nearest;
-			}
-		}
+		const Range d = transmit_range(t);
 		index.lo = std::fmin(index.lo, ((d.lo + rx_min) / c + t0) * fs);
 		index.hi = std::fmax(index.hi, ((d.hi + rx_max) / c + t0) * fs);
 	}
@@ -871,11 +896,15 @@ void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vec
 	parts.clear();
 	parts.emplace_back();
 	decide_das(pb, plan, tx, zfirst, zcount, mode, parts[0]);
-	const DasDecision &whole = parts[0];
-	if ((whole.path != DasPath_Staged && whole.path != DasPath_Tile) || zcount == 0 || tx.empty()) return;
+	DasDecision &whole = parts[0];
+	whole.a.row_ends = whole.general.row_ends = 1;           /* until shown otherwise */
+	if (whole.path == DasPath_Zero || zcount == 0 || tx.empty()) return;
 	const BfDasArgs &a = whole.a;
+	/* a bound exists for the families whose index is a sum of distances over an aperture the f-number limits (plane_index_bounds);
+	 * READI keeps row_ends = 1, and so does nearest interpolation (which has no row-end evaluation: its flips are everywhere) */
+	if (a.family == BF_DAS_READI || a.family < 0 || a.interpolation == 0) return;
 	float to_xdc[16];
-	if (a.family == BF_DAS_FORCES || a.family == BF_DAS_READI) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
+	if (a.family == BF_DAS_FORCES) std::memcpy(to_xdc, plan.das_voxel_transform, sizeof(to_xdc));
 	else m4_mul(pb.parameters.xdc_transform, plan.das_voxel_transform, to_xdc);
 	const bool   cubic = a.interpolation == 2;
 	const double reach = 2.0 * (double)a.edge_margin;        /* the kernels' indices and these bounds differ by far less than the margin */
@@ -889,7 +918,8 @@ void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vec
 			std::fprintf(stderr, "[beamformer] row ends: plane %u index within [%.3f, %.3f], clear within [%.3f, %.3f): %s\n", zfirst + k, r.lo, r.hi, lo, hi, clear[k] ? "clear" : "fallback");
 		all = all && clear[k];
 	}
-	if (all) return;
+	if (all) { whole.a.row_ends = whole.general.row_ends = 0; return; }      /* no term of this launch comes near a row end */
+	if (whole.path != DasPath_Staged && whole.path != DasPath_Tile) return;    /* every other kernel evaluates such terms itself */
 	/* the kernel behind the staged one: "automatic, never staged" with block staging off */
 	const uint32_t fallback_mode = (mode & ~0xFu & ~0x100u) | 0x200u | ((mode & 0xFu) == 1u ? 1u : 2u);
 	std::vector<DasDecision> cut;
@@ -904,6 +934,7 @@ void decide_das_parts(const ParameterBlock &pb, const Plan &plan, const std::vec
 		if (!clear[begin] && (d.path == DasPath_Staged || d.path == DasPath_Tile))
 			decide_das(pb, plan, tx, zfirst + begin, k - begin, (mode & ~0xFu & ~0x100u) | 0x200u | 1u, d);     /* (cannot happen: the general kernel) */
 		d.row_end_fallback = !clear[begin];
+		d.a.row_ends = d.general.row_ends = clear[begin] ? 0u : 1u;
 		begin = k;
 	}
 	parts.swap(cut);

@@ -611,6 +611,7 @@ uint32_t beamformer_hip_describe_das(uint32_t parameter_slot, BeamformerHipDasDe
 	out->hercules_prepared_copy = d.hercules_prepared;
 	out->tile_spread_estimate = d.tile_spread;
 	for (int k = 0; k < 3; k++) out->tile_estimate_shift[k] = d.tile_estimate_shift[k];
+	out->row_ends = d.a.row_ends;
 	return 1;
 }
 

@@ -227,7 +227,7 @@ class HipDasDescription(C.Structure):
                 ("tile_shift", C.c_uint32 * 3), ("blocks", C.c_uint32 * 3), ("split_shift", C.c_uint32), ("tile_walk", C.c_uint32),
                 ("row_end_planes", C.c_uint32), ("tile_window_samples", C.c_uint32), ("u_axis", C.c_uint32), ("u_shift", C.c_uint32), ("v_shift", C.c_uint32), ("window_samples", C.c_uint32),
                 ("uniform_tables", C.c_uint32), ("lds_bytes", C.c_uint32), ("threads", C.c_uint32), ("channel_chunk", C.c_uint32),
-                ("hercules_prepared_copy", C.c_uint32), ("tile_spread_estimate", C.c_float), ("tile_estimate_shift", C.c_uint32 * 3)]
+                ("hercules_prepared_copy", C.c_uint32), ("tile_spread_estimate", C.c_float), ("tile_estimate_shift", C.c_uint32 * 3), ("row_ends", C.c_uint32)]
 
 
 class HipPlanStage(C.Structure):

@@ -260,3 +260,5 @@ EXPECTED_ROW_END_PLANES = {
     "rca_staged_auto": 1, "rca_staged_fine": 1, "rca_staged_ragged": 1,
     "rca_staged_cubic_short_rows": 1, "rca_staged_real_short_rows": 1, "rca_staged_fine_vls_short_rows": 2, "rca_vls_staged_short_rows": 3,
 }
+# ... and the cases of which NO plane keeps the staged kernel (their das path is the fallback's)
+ROW_END_EVERY_PLANE = {"rca_staged_fine_vls_short_rows", "rca_vls_staged_short_rows"}

@@ -196,3 +196,18 @@ def test_staged_window_holds_every_tile_brute_force(seed):
     # linear: p = R' + T'' < W - 1.5 with T'' = T - floor(min T) - 1/2  <=>  spread < W - 1;  cubic (window one sample early): spread < W - 3
     budget = W - 3 if cubic else W - 1
     assert worst < budget - 0.01, f"tile spread {worst:.2f} samples does not fit the {W}-sample window (U = {1 << d.u_shift}, V = {1 << d.v_shift})"
+
+
+def test_full_size_configurations_stay_clear_of_row_ends_and_the_harness_planes_do_not():
+    """the host bound per plane (das_select.cpp plane_index_bounds): BASELINE configs 2-5 at full size have no in-aperture term within
+    reach of an end of its RF row -- their kernels run the instantiation without any row-end code, as in round 3 --, while on the
+    reference harness's own F# 0.5 view plane the outermost channels of the deepest pixels echo from beyond the row's 2048 samples"""
+    lib.library().beamformer_hip_set_das_path(0)
+    for n in (2, 3, 4, 5):
+        acq = cfg.config(n)
+        d = lib.describe_das(acq.bp, acq.filters)[4]
+        assert int(d.row_ends) == 0 and int(d.row_end_planes) == 0, n
+    for kind in ("tpw", "forces", "hercules"):
+        acq = cfg.harness(kind)
+        d = lib.describe_das(acq.bp, acq.filters)[4]
+        assert int(d.row_ends) == 1 and int(d.row_end_planes) == 0, kind

@@ -37,6 +37,23 @@ def test_single_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "voxels/s" and cpu["sample"]
+    # the same frames with the RF pushed from host memory (what tests/throughput.c:535-557 times), beside `value`, never as it
+    up = d["config"]["upload_inclusive"]
+    assert up["ms_per_frame"] > 0 and up["rf_bytes_per_frame"] > 0 and "beamformer_push_data_with_compute" in up["what"]
+    assert up["voxels_per_s"] == pytest.approx(64 ** 3 / (up["ms_per_frame"] * 1e-3), rel=1e-6)
+    assert up["rf_GBps"] == pytest.approx(up["rf_bytes_per_frame"] / (up["ms_per_frame"] * 1e-3) / 1e9, rel=1e-6)
+    assert up["voxels_per_s"] <= d["value"] * 1.5          # (an upload cannot make frames much faster; small frames jitter)
+
+
+def test_gpus_argument_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts one rank per GPU itself (a child torch.distributed.run) and relays
+    the line; here both ranks rehearse on the one GPU over gloo.  n_gpus in the line is what was asked for."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.125", "--steps", "3", "--warmup", "1",
+                        "--rehearse-on-one-gpu", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["slab_verified"] is True
 
 
 def test_config2_line_names_the_block_staged_kernel():

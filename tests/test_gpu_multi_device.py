@@ -77,8 +77,12 @@ def test_block_staged_kernel_slabs(name, count, bflib, devices):
         devices([0] * count)
         many = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert same_bits(one, many)
+        # (a slab whose planes reach the end of an RF row is handed to the factored kernel by the row-end rule, das_select.h)
+        paths = []
         for i in range(count):
-            assert lib.beamformer_hip_get_device_frame_timings(i, C.byref(t)) and int(t.das_path) == 6 and int(t.das_voxels) > 0
+            assert lib.beamformer_hip_get_device_frame_timings(i, C.byref(t)) and int(t.das_voxels) > 0
+            paths.append(int(t.das_path))
+        assert set(paths) <= {6, 3} and 6 in paths, paths
     finally:
         lib.beamformer_hip_set_das_path(0)
 

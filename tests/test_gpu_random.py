@@ -236,7 +236,8 @@ def test_random_draws_reach_the_block_staged_kernel():
     """most draws must have run das_tile.hip, and between them both kinds of chunk in quantity"""
     print(f"block-staged draws: {len(TILE_DRAWS)}: {TILE_DRAWS}")
     assert len(TILE_DRAWS) >= 20, TILE_DRAWS
-    assert sum(1 for _, s, g in TILE_DRAWS if s > 0) >= 12 and sum(1 for _, s, g in TILE_DRAWS if g > 0) >= 3, TILE_DRAWS
+    # (draws whose rows end inside the image -- most of the coarse ones -- go to the factored kernel by the row-end rule)
+    assert sum(1 for _, s, g in TILE_DRAWS if s > 0) >= 12 and sum(1 for _, s, g in TILE_DRAWS if g > 0) >= 1, TILE_DRAWS
 
 
 # ---- row ends (csrc/das_exact.h).  sample_rf's range test is a step: round 3's fast kernels formed the index as a rounded receive term plus

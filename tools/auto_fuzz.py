@@ -1,6 +1,13 @@
-"""One-off fuzz beyond the fixed seeds of tests/test_gpu_random.py: seeds FIRST..LAST of its two generators (general draws on the automatic path;
-separable draws on the automatic path and with every staged term range-checked), same comparison as the tests.
-PYTHONPATH=. python tools/auto_fuzz.py 72 400"""
+"""Out-of-sample fuzz beyond the fixed seeds of tests/test_gpu_random.py: seeds FIRST..LAST of its three generators, every draw
+against the oracle with the SUITE'S comparison (tests/test_gpu_parity.py compare(): the tolerance of the pipeline's arithmetic, and
+for a voxel over it the double-precision truth -- never another kernel of the library):
+  general    draws on the automatic path
+  separable  draws on the automatic path, and where the LDS-staged kernel ran, again with every staged term range-checked
+  tile       draws with the block-staged factored kernel asked for (flags 0x10 | 0x100)
+Writes a JSON summary (draws, failures, kernels taken, planes the row-end rule re-routed).
+PYTHONPATH=. python tools/auto_fuzz.py 72 1200 [--json gpurun_out/r04/fuzz.json] [--generators general,separable,tile]"""
+import argparse
+import json
 import sys
 import traceback
 
@@ -11,44 +18,66 @@ from oracle import binding as oracle
 from tests import test_gpu_random as R
 from tests.test_gpu_parity import compare, last_timings, reference
 
-first, last = int(sys.argv[1]), int(sys.argv[2])
+ap = argparse.ArgumentParser()
+ap.add_argument("first", type=int)
+ap.add_argument("last", type=int)
+ap.add_argument("--json", default="")
+ap.add_argument("--generators", default="general,separable,tile")
+args = ap.parse_args()
 L = bflib.library()
-ran = failed = 0
-paths = {}
-for gen, name in ((R.draw, "general"), (R.draw_separable, "separable")):
-    for seed in range(first, last):
+GENERATORS = {"general": (R.draw, 0), "separable": (R.draw_separable, 0), "tile": (R.draw_tile, 0x110)}
+summary = {"seeds": [args.first, args.last], "comparison": "tests/test_gpu_parity.py compare(): tolerance of the pipeline, second bar against the oracle's double twin",
+           "generators": {}, "failures": []}
+total = failed_total = 0
+for name in args.generators.split(","):
+    gen, mode = GENERATORS[name]
+    ran = failed = row_end_draws = second_bar = 0
+    paths = {}
+    for seed in range(args.first, args.last):
         try:
             acq = gen(seed)
-        except Exception as e:                      # a draw the generator itself cannot build
-            continue
-        try:
             ref, pairs, flags = reference(oracle, acq)
-        except Exception:
+        except Exception:                               # a draw the generator or the oracle's planner cannot build
             continue
         ok = ~np.isnan(ref)
         if not ok.any() or np.max(np.abs(ref[ok])) == 0:
             continue
-        L.beamformer_hip_set_das_path(0)
+        path = -1
         try:
+            L.beamformer_hip_set_das_path(mode)
             gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-            path = int(last_timings(bflib).das_path)
+            t = last_timings(bflib)
+            path = int(t.das_path)
             paths[path] = paths.get(path, 0) + 1
+            row_end_draws += int(t.das_row_end_planes) > 0
             ran += 1
             compare(gpu, ref, acq, flags)
             if path == 2:
                 bflib.set_hook("STAGED_CHECKED", "1")
                 try:
                     checked = bflib.beamform(acq.bp, acq.rf, acq.filters)
-                    t = last_timings(bflib)
-                    assert int(t.staged_window_violations) == 0, "window violation"
+                    assert int(last_timings(bflib).staged_window_violations) == 0, "window violation"
                     compare(checked, ref, acq, flags)
                 finally:
                     bflib.set_hook("STAGED_CHECKED", None)
         except AssertionError as e:
             failed += 1
-            print(name, "seed", seed, "path", path, "FAIL:", str(e)[:160])
+            summary["failures"].append({"generator": name, "seed": seed, "path": path, "what": str(e)[:200]})
+            print(name, "seed", seed, "path", path, "FAIL:", str(e)[:200], flush=True)
         except Exception:
             failed += 1
-            print(name, "seed", seed, "ERROR"); traceback.print_exc(limit=1)
-print(f"{ran} draws, {failed} failures, DAS paths taken: {dict(sorted(paths.items()))}")
-sys.exit(1 if failed else 0)
+            summary["failures"].append({"generator": name, "seed": seed, "path": path, "what": "exception"})
+            print(name, "seed", seed, "ERROR", flush=True); traceback.print_exc(limit=1)
+        finally:
+            L.beamformer_hip_set_das_path(0)
+        if ran and ran % 100 == 0:
+            print(f"{name}: {ran} draws, {failed} failures so far", flush=True)
+    summary["generators"][name] = {"draws": ran, "failures": failed, "das_paths_taken": {str(k): v for k, v in sorted(paths.items())},
+                                   "draws_with_planes_rerouted_by_the_row_end_rule": row_end_draws}
+    total += ran; failed_total += failed
+    print(f"{name}: {ran} draws, {failed} failures, DAS paths taken: {dict(sorted(paths.items()))}, row-end re-routed draws: {row_end_draws}", flush=True)
+summary["draws"] = total; summary["failed"] = failed_total
+if args.json:
+    json.dump(summary, open(args.json, "w"), indent=1)
+print(f"{total} draws, {failed_total} failures")
+sys.exit(1 if failed_total else 0)

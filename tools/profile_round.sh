@@ -1,12 +1,12 @@
-# The GPU-box commands behind profiles/r03_*: microbenchmarks, PMC passes (one counter group per rocprofv3 pass, tools/pmc_das.py),
+# The GPU-box commands behind profiles/<round>_* (round = $R, default r04): microbenchmarks, PMC passes (one counter group per rocprofv3 pass, tools/pmc_das.py),
 # the default bench, the other configurations and the reference harness's frames, rocprofv3 kernel stats, the GPU test log.
 # Two calls (each fits a gpurun limit), from the repository root:
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh pmc'
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh bench'
-# They write under gpurun_out/r03/ and ALSO refresh the tracked summaries in the box's copy; copy those back from gpurun_out/r03/profiles/.
-set -e
+# They write under gpurun_out/$R/ and ALSO refresh the tracked summaries in the box's copy; copy those back from gpurun_out/$R/profiles/.
+# A leg that fails leaves its stderr under gpurun_out/$R/ and the script goes on (no `set -e`: one failing leg must not hide the others).
 ROOT=$PWD
-R=r03
+R=${R:-r04}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT $OUT/profiles
 part=${1:-pmc}
@@ -28,7 +28,7 @@ python3 tools/tile_pmc_summary.py $OUT/pmc_cfg2/summary.json profiles/${R}_pmc_t
 cp profiles/das_traffic.json profiles/${R}_das_bound.json profiles/${R}_pmc_tile_cfg2.json $OUT/profiles/
 exit 0
 fi
-# ---- part "bench" (expects profiles/r03_microbench.json, das_traffic.json, r03_das_bound.json and r03_pmc_tile_cfg2.json of part "pmc" in the tree)
+# ---- part "bench" (expects profiles/${R}_microbench.json, das_traffic.json, ${R}_das_bound.json and ${R}_pmc_tile_cfg2.json of part "pmc" in the tree)
 timeout -k 10 400 python bench.py > $OUT/profiles/${R}_bench.json 2> $OUT/bench.err
 cut -c1-400 $OUT/profiles/${R}_bench.json
 for c in 1 2 3 5; do
@@ -38,15 +38,13 @@ timeout -k 10 300 python bench.py --config 5 --interpolation cubic --steps 3 --w
 timeout -k 10 300 python bench.py --das-path 2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg4_gather.json 2> $OUT/bench_cfg4_gather.err
 for k in tpw tpw_swapped vls hercules forces; do
   timeout -k 10 200 python bench.py --config harness:$k --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_harness_$k.json 2> $OUT/bench_harness_$k.err
-  timeout -k 10 200 python bench.py --config harness:$k --das-path 1 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_harness_${k}_general.json 2> /dev/null
-done
-for k in tpw forces; do
-  timeout -k 10 200 python bench.py --config harness:$k --das-path 64 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_harness_${k}_span_staging.json 2> /dev/null
+  timeout -k 10 200 python bench.py --config harness:$k --das-path 1 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_harness_${k}_general.json 2> $OUT/last_leg.err
 done
 PYTHONPATH=. timeout -k 10 300 python tools/tile_threshold.py --json $OUT/profiles/${R}_tile_threshold.json > $OUT/tile_threshold.log 2>&1
 timeout -k 10 300 python bench.py --in-process --devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_inprocess_0_0.json 2> $OUT/bench_inprocess.err
-python3 - <<'PY'
-import json
+python3 - $R <<'PY'
+import json, sys
+R = sys.argv[1]
 def line(p):
     return json.loads(open(p).read().strip().splitlines()[-1])
 def brief(d):
@@ -55,22 +53,20 @@ def brief(d):
             "roofline": {k: d["roofline"].get(k) for k in ("bound", "achieved", "frac", "kernel", "kernel_ms", "pairs_per_launch", "binding")}}
 out = {}
 for c in (1, 2, 3, 5):
-    out[f"config{c}"] = brief(line(f"gpurun_out/r03/bench_cfg{c}.json"))
-out["config5_cubic_interpolation_the_harness_setting"] = brief(line("gpurun_out/r03/bench_cfg5_cubic.json"))
-out["config4_gather_kernel_das_path_2"] = brief(line("gpurun_out/r03/bench_cfg4_gather.json"))
-d = line("gpurun_out/r03/bench_inprocess_0_0.json")
+    out[f"config{c}"] = brief(line(f"gpurun_out/{R}/bench_cfg{c}.json"))
+out["config5_cubic_interpolation_the_harness_setting"] = brief(line("gpurun_out/" + R + "/bench_cfg5_cubic.json"))
+out["config4_gather_kernel_das_path_2"] = brief(line("gpurun_out/" + R + "/bench_cfg4_gather.json"))
+d = line("gpurun_out/" + R + "/bench_inprocess_0_0.json")
 out["config4_in_process_two_contexts_on_one_gpu"] = {"ms_per_step": d["ms_per_step"], "sharding": d["config"]["sharding"], "devices": d["config"].get("devices"),
                                                       "rf_checksum_equal": d["config"]["rf_checksum_equal_on_all_ranks"], "note": "orchestration check only: both device contexts share one GPU"}
-json.dump(out, open("gpurun_out/r03/profiles/r03_other_configs.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/" + R + "/profiles/" + R + "_other_configs.json", "w"), indent=1)
 h = {}
 for k in ("tpw", "tpw_swapped", "vls", "hercules", "forces"):
-    e = {"automatic": brief(line(f"gpurun_out/r03/bench_harness_{k}.json"))}
-    try: e["general_kernel_das_path_1"] = brief(line(f"gpurun_out/r03/bench_harness_{k}_general.json"))
+    e = {"automatic": brief(line(f"gpurun_out/{R}/bench_harness_{k}.json"))}
+    try: e["general_kernel_das_path_1"] = brief(line(f"gpurun_out/{R}/bench_harness_{k}_general.json"))
     except Exception as x: e["general_kernel_das_path_1"] = str(x)[:100]
-    if k in ("tpw", "forces"):
-        e["factored_kernel_wave_span_staging_das_path_0x40"] = brief(line(f"gpurun_out/r03/bench_harness_{k}_span_staging.json"))
     h[f"harness:{k}"] = e
-json.dump(h, open("gpurun_out/r03/profiles/r03_harness.json", "w"), indent=1)
+json.dump(h, open("gpurun_out/" + R + "/profiles/" + R + "_harness.json", "w"), indent=1)
 PY
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o fast -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/profiles/${R}_bench_under_rocprof.json 2> $OUT/rocprof.err
