@@ -39,14 +39,13 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 PATH_NAMES = ["general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
-              "(retired: LDS row-cache experiment)", "HERCULES aligned-grid kernel", "per-voxel factored kernel with block-wide LDS staging"]
-KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
-                "das_hercules_kernel", "das_tile_kernel"]
+              "HERCULES aligned-grid kernel", "per-voxel factored kernel with block-wide LDS staging"]
+KERNEL_NAMES = ["das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_hercules_kernel", "das_tile_kernel"]
 # the sources whose hash ties a committed PMC figure to the code that produced it (tools/summarize_profiles.py): the
 # kernel's own file plus the headers every DAS kernel includes
 KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
                 "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_hercules_kernel": "das_hercules.hip", "das_tile_kernel": "das_tile.hip"}
-COMMON_SOURCES = ["das_common.h", "bf_kernels.h", "das_select.cpp"]       # (the selection rules decide tile shapes, windows and walks: they change a kernel's traffic)
+COMMON_SOURCES = ["das_common.h", "das_exact.h", "bf_kernels.h", "das_select.cpp"]       # (the selection rules decide tile shapes, windows and walks: they change a kernel's traffic)
 
 def parse():
     ap = argparse.ArgumentParser()

@@ -100,10 +100,10 @@ typedef struct {
 	uint32_t das_taps;         /* 1 nearest, 2 linear, 4 cubic */
 	uint32_t das_sample_bytes; /* 4 real / 8 complex float32 */
 	uint32_t das_path;         /* 0 general kernel, 1 separable-delay gather kernel, 2 LDS-staged kernel, 3 per-voxel factored kernel,
-	                              4 (retired), 5 HERCULES aligned-grid kernel, 6 factored kernel with block-wide LDS staging (das_tile.hip) */
+	                              4 HERCULES aligned-grid kernel, 5 factored kernel with block-wide LDS staging (das_tile.hip) */
 	uint32_t staged_window_violations;   /* LDS-staged kernels with the STAGED_CHECKED hook: (wave, channel) pairs in which a term's position
 	                                        fell outside the staged window -- the host's window bound was wrong.  Must be 0. */
-	uint32_t tile_staged_chunks;         /* das path 6 (das_tile.hip): (block, chunk of four channels) pairs whose terms were read from the windows the
+	uint32_t tile_staged_chunks;         /* das path 5 (das_tile.hip): (block, chunk of four channels) pairs whose terms were read from the windows the
 	                                        block staged in LDS ... */
 	uint32_t tile_gather_chunks;         /* ... and those whose spread did not fit the window: the block ran das_factored.hip's gather loop for them */
 	uint32_t das_row_end_planes;         /* z-planes of the frame the ROW-END rule handed to the kernel behind the staged one (LDS-staged -> gather /
@@ -298,12 +298,12 @@ typedef struct {
 	uint32_t tile_shift[3], blocks[3], split_shift;      /* per-voxel kernels (general, factored): block shape and count */
 	uint32_t tile_walk;             /* 0 x,y,z; 1 z fastest; 2 y fastest; 3 view plane in XCD-balanced bands; staged kernels: + their flag bits */
 	uint32_t row_end_planes;        /* planes of the shard the row-end rule hands to the kernel behind the staged one (BeamformerHipFrameTimings::das_row_end_planes) */
-	uint32_t tile_window_samples;   /* block-staged factored kernel (path 6): staged window length */
+	uint32_t tile_window_samples;   /* block-staged factored kernel (path 5): staged window length */
 	uint32_t u_axis, u_shift, v_shift, window_samples, uniform_tables, lds_bytes, threads, channel_chunk;   /* separable-delay kernels: the tile is 2^u_shift voxels
 	                                   along the receive axis (voxel axis u_axis) by 2^v_shift along the transmit axis, one plane thick */
 	uint32_t hercules_prepared_copy;/* HERCULES kernel: reads the {sample, difference} / polynomial copy of the DAS input */
 	float    tile_spread_estimate;  /* factored-kernel frames: the host's upper bound of a 1024-voxel tile's delay spread in samples (what decides
-	                                   for or against path 6; the kernel measures the real spread per block and chunk); 0 where not computed */
+	                                   for or against path 5; the kernel measures the real spread per block and chunk); 0 where not computed */
 	uint32_t tile_estimate_shift[3];/* ... and the tile it was computed for */
 	uint32_t row_ends;              /* 1: some in-aperture term of the launch may come within reach of an end of its RF row (a host bound, per plane, in
 	                                   double precision): the kernel's instantiation WITH the exact row-end evaluation runs (csrc/das_exact.h); 0: the one without */

@@ -215,5 +215,58 @@ __device__ __forceinline__ void edge_term(const P &p, uint32_t x, uint32_t y, ui
 	}
 }
 
+/* The same for a kernel whose loops did NOT leave the term out but decided it with their own index `fast_index` (the factored and
+ * HERCULES kernels: their loops stay exactly as they are; a pass at the end of the kernel walks the few chunks that can hold such terms):
+ * the voxel's sums are corrected by  weight x (sample_rf(exact index) - sample_rf(fast_index)).  sample_rf applies the very range test the
+ * loops applied to the very same index bits, so the subtracted term is what the loops added (or nothing, if they dropped it) up to the
+ * rounding of one term's arithmetic -- 1e-7 of a single tap; where both indices lie on the same side of the row's end the correction is
+ * that small too, where they straddle it, it is the whole tap: the oracle's decision. */
+template <int FAMILY, int INTERP, bool CPLX, bool CW, typename P>
+__device__ __forceinline__ void edge_correct(const P &p, uint32_t x, uint32_t y, uint32_t z, int channel, int transmit, float fast_index,
+                                             sample_t<CPLX> &coherent, float &incoherent)
+{
+	static_assert(FAMILY != BF_DAS_READI, "READI runs on the general kernel only");
+	const Voxel v = exact_voxel<FAMILY>(p, x, y, z);
+	const int   S = p.sample_count, A = p.acquisition_count;
+	float weight;
+	if constexpr (FAMILY == BF_DAS_RCA) {
+		const Tx t = load_transmit(p, transmit);
+		const bool  rx_rows = (t.flags & BF_RX_ROWS) != 0;
+		const float dx = pick(rx_rows, v.xy, v.xx) - (float)channel * pick(rx_rows, p.pitch[1], p.pitch[0]);
+		const float a_arg = __builtin_fabsf(dx * (p.f_number * hw_rcp(__builtin_fabsf(v.xz))));
+		if (!(a_arg < 0.5f)) return;
+		weight = apodize(a_arg);
+	} else if constexpr (FAMILY == BF_DAS_HERCULES) {
+		const bool  rx_cols = (load_transmit(p, 0).flags & BF_RX_COLUMNS) != 0;
+		const float tx_channel = p.sparse ? (float)p.sparse_elements[transmit - 1] : (float)transmit;
+		const float rd = rx_cols ? v.xx - (float)channel * p.pitch[0] : v.xy - (float)channel * p.pitch[1];
+		const float td = rx_cols ? v.xy - tx_channel * p.pitch[1]     : v.xx - tx_channel * p.pitch[0];
+		const float eds = td * td + rd * rd;
+		const float f_over_z = __builtin_fabsf(p.f_number * hw_rcp(v.xz));
+		if (!(eds < 0.25f / (f_over_z * f_over_z))) return;
+		weight = (transmit == 0 ? p.first_transmit_weight : 1.0f) * apodize(f_over_z * hw_sqrt(eds));
+	} else {
+		const float dx = v.xx - (float)channel * p.pitch[0];
+		const float a_arg = __builtin_fabsf(dx * (p.f_number * hw_rcp(v.xz)));
+		if (!(a_arg < 0.5f)) return;
+		weight = apodize(a_arg);
+	}
+	const float index = exact_index<FAMILY>(p, v, channel, transmit);
+	const int   row = (channel * A + transmit) * S;
+	/* (one evaluation after the other, as a loop the compiler may not unroll: interleaved, the two cubic interpolations of IQ samples hold
+	 * twice the registers, and the kernel's occupancy is set by its most expensive point -- this rare one) */
+	#pragma unroll 1
+	for (int which = 0; which < 2; which++) {
+		const float at = which ? fast_index : index, sign = which ? -weight : weight;
+		const sample_t<CPLX> s = sign * sample_rf<INTERP, CPLX>((const char *)p.rf, row, at, p);
+		coherent += s;
+		if constexpr (CW) {
+			float magnitude;
+			if constexpr (CPLX) magnitude = hw_sqrt(s.x * s.x + s.y * s.y); else magnitude = __builtin_fabsf(s);
+			incoherent += which ? -magnitude : magnitude;
+		}
+	}
+}
+
 } /* namespace bfx */
 #endif

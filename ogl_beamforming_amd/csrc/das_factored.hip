@@ -202,14 +202,19 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 		/* Row ends (das_exact.h).  This kernel's index is a rounded receive term plus a rounded transmit term: within p.edge_margin of an
 		 * end of sample_rf's valid range it is not trusted to decide keep-or-drop.  One pass over the transmits gives the lane the
 		 * extremes of its transmit term; a chunk in which no lane of the wave can come that close to an end for any transmit (nearly
-		 * every chunk of nearly every frame) runs the loops below as they are; otherwise the EDGE forms of the same loops leave the terms
-		 * inside the margin out, and a pass at the END of the kernel (its registers are not the loops') evaluates those with the shader's
-		 * own index. */
+		 * every chunk of nearly every frame) needs nothing; in the others every transmit gets one wave-level test before its terms, and
+		 * the rare term inside the margin is corrected with the shader's own index on the spot.  The gathers, the interpolation and the
+		 * accumulation are round 3's, untouched. */
 		constexpr bool EDGES = ROW_ENDS && INTERP != BF_INTERP_NEAREST;      /* (nearest flips at every half-integer: budgeted per voxel by the tests) */
 		[[maybe_unused]] const float edge_margin = p.edge_margin;
+		/* does the index interval [lo_index, hi_index] contain a point within the margin of an end of the row?  (Terms wholly inside the
+		 * row need no test; terms wholly BEYOND it -- the outermost channels of the deepest pixels -- are dropped by the ordinary range
+		 * test and need none either: only intervals that straddle an end do.) */
+		[[maybe_unused]] auto straddles = [&](float lo_index, float hi_index) -> bool {
+			const float e_hi = bfx::edge_hi<INTERP>(S), e_lo = bfx::edge_lo<INTERP>();
+			return (lo_index < e_hi + edge_margin && hi_index > e_hi - edge_margin) || (lo_index < e_lo + edge_margin && hi_index > e_lo - edge_margin);
+		};
 		[[maybe_unused]] float t_lo = 0.f, t_hi = 0.f;
-		[[maybe_unused]] unsigned long long edge_lanes = 0;                       /* lanes of this wave with a term left out in the current chunk (a scalar) */
-		[[maybe_unused]] unsigned long long edge_chunks = 0;                      /* the chunks (bit = chunk number within this wave's channel range) in which that happened */
 		if constexpr (EDGES) {
 			t_lo = __builtin_inff(); t_hi = -__builtin_inff();
 			for (int a = first_transmit; a < A; a++) {
@@ -241,17 +246,16 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				any |= pass;
 			}
 			if (!__builtin_amdgcn_ballot_w64(any)) continue;          /* wave-uniform */
-			bool edges = false;                                       /* wave-uniform: some lane of the wave can come within the margin of a row end in this chunk */
+			[[maybe_unused]] bool edges = false;                      /* wave-uniform: some lane's index range over the transmits contains an end of its row in this chunk */
 			if constexpr (EDGES) {
 				bool lane_safe = true;
 				#pragma unroll
 				for (int k = 0; k < CH; k++)
-					lane_safe = lane_safe && (R[k].index < -1.0e8f || (R[k].index + t_lo >= bfx::edge_lo<INTERP>() + edge_margin &&
-					                                                   R[k].index + t_hi <  bfx::edge_hi<INTERP>(S) - edge_margin));
+					lane_safe = lane_safe && (R[k].index < -1.0e8f || !straddles(R[k].index + t_lo, R[k].index + t_hi));
 				edges = __builtin_amdgcn_ballot_w64(!lane_safe) != 0ull;
 			}
-			/* ... and then, per transmit, whether any lane's receive terms of this chunk [r_lo, r_hi] plus THAT transmit term reach an end:
-			 * only those transmits run the EDGE form of the body (two adds and two compares per transmit instead of a test per term) */
+			/* ... and, for such a chunk, the extremes of the lane's receive terms over its channels: per transmit ONE wave-level test of
+			 * [r_lo, r_hi] + T against the row's ends decides whether any term of that transmit needs the per-term test at all */
 			[[maybe_unused]] float r_lo = __builtin_inff(), r_hi = -__builtin_inff();
 			if constexpr (EDGES) {
 				if (edges) {
@@ -260,7 +264,6 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						if (R[k].index > -1.0e8f) { r_lo = fminf(r_lo, R[k].index); r_hi = fmaxf(r_hi, R[k].index); }
 				}
 			}
-
 			sample_t<CPLX> part[CH];
 			float          part_abs[CH];
 			#pragma unroll
@@ -273,8 +276,34 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			#pragma unroll
 			for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; }
 
-			auto transmit_body = [&](auto edge_c, int a, float t_index) {
-				constexpr bool EDGE = decltype(edge_c)::value;      /* leave out (and note) the terms within the margin of a row end */
+			for (int a = first_transmit; a < A; a++) {
+				float t_index = transmit_index(a);
+				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
+				if constexpr (EDGES) {
+					if (edges && __builtin_amdgcn_ballot_w64(straddles(r_lo + t_index, r_hi + t_index)) != 0ull) {
+						/* ---- row ends (rare): a term of this transmit within the margin of an end of its row is evaluated from the voxel's
+						 * integer coordinates with the shader's own index, and the voxel's sums are CORRECTED by the difference to what the
+						 * loop below decides and adds for it with its own index (das_exact.h: edge_correct) */
+						bool some = false;
+						#pragma unroll
+						for (int k = 0; k < CH; k++) some = some || bfx::edge_near<INTERP>(t_index + R[k].index, S, edge_margin);
+						if (__builtin_amdgcn_ballot_w64(some) != 0ull) {           /* (else: the intervals contain an end, but no term comes near it) */
+						uint32_t ex, ey, ezl, thread = threadIdx.x;
+						asm volatile("" : "+v"(thread));             /* (worked out here, not held across the loop) */
+						voxel_of(thread, ex, ey, ezl);
+						#pragma unroll 1
+						for (int k = 0; k < CH; k++) {
+							/* (R[k] by a chain of selects on the scalar k: a run-time index would put the register array on the stack) */
+							float r_k = R[0].index;
+							#pragma unroll
+							for (int j = 1; j < CH; j++) r_k = k == j ? R[j].index : r_k;
+							const float index = t_index + r_k;             /* (a channel outside the aperture: -1e9, never near) */
+							if (bfx::edge_near<INTERP>(index, S, edge_margin))
+								bfx::edge_correct<FAMILY, INTERP, CPLX, CW>(bfx::kernel_args(), ex, ey, p.z_first + ezl, c0 + k, a, index, coherent, incoherent);
+						}
+						}
+					}
+				}
 				float tc = 1.f, ts = 0.f;
 				if constexpr (CPLX) {
 					float turns = hw_fract(turns_per_sample * t_index);
@@ -300,11 +329,6 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						} else {
 							uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
 							off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
-						}
-						if constexpr (EDGE) {
-							const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin);      /* (a channel outside the aperture: index -1e9, never near) */
-							edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
-							off[k] = edge ? p.zero_offset : off[k];
 						}
 					}
 					if constexpr (INTERP == BF_INTERP_LINEAR) {
@@ -341,20 +365,12 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 							if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }
 						}
 					}
-					return;
+					continue;
 				}
 				Tap<INTERP>           tap[CH];
 				TapData<INTERP, CPLX> data[CH];
 				#pragma unroll
-				for (int k = 0; k < CH; k++) {
-					float index = t_index + R[k].index;
-					if constexpr (EDGE) {
-						const bool edge = bfx::edge_near<INTERP>(index, S, edge_margin);      /* (a channel outside the aperture: index -1e9, never near) */
-						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
-						index = edge ? -8.0f : index;                                 /* outside every mode's range: zero weights */
-					}
-					tap[k] = tap_setup<INTERP, CPLX>(index, Sf, last);
-				}
+				for (int k = 0; k < CH; k++) tap[k] = tap_setup<INTERP, CPLX>(t_index + R[k].index, Sf, last);
 				#pragma unroll
 				for (int k = 0; k < CH; k++) {
 					/* rows past the last channel of a ragged chunk are not read: their weights are
@@ -374,18 +390,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						if constexpr (CW) part_abs[k] += __builtin_fabsf(s);
 					}
 				}
-			};
-			if constexpr (EDGES) edge_lanes = 0;
-			for (int a = first_transmit; a < A; a++) {
-				float t_index = transmit_index(a);
-				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
-				if constexpr (EDGES) {
-					const bool reach = edges && !(r_lo + t_index >= bfx::edge_lo<INTERP>() + edge_margin && r_hi + t_index < bfx::edge_hi<INTERP>(S) - edge_margin);
-					if (__builtin_amdgcn_ballot_w64(reach) != 0ull) { transmit_body(std::true_type{}, a, t_index); continue; }
-				}
-				transmit_body(std::false_type{}, a, t_index);
 			}
-			if constexpr (EDGES) { if (edge_lanes != 0ull) edge_chunks |= 1ull << (uint32_t)((c0 - ch_begin) / CH); }
 
 			#pragma unroll
 			for (int k = 0; k < CH; k++) {
@@ -400,35 +405,6 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			}
 		}
 
-		if constexpr (EDGES) {
-			/* ---- row ends: the terms the loops above left out, chunk by chunk of those that left any out (at most 64 chunks: 256 channels in
-			 * chunks of four).  The same sum of the same two rounded terms (receive_index, transmit_index), so the same terms; each evaluated
-			 * from the voxel's integer coordinates with the shader's own index (das_exact.h) and added to the voxel's sums. */
-			uint32_t ex, ey, ezl, thread = threadIdx.x;
-			asm volatile("" : "+v"(thread));                     /* not the values computed before the loop */
-			voxel_of(thread, ex, ey, ezl);
-			while (edge_chunks != 0ull) {
-				const int chunk = __builtin_ctzll(edge_chunks);
-				edge_chunks &= edge_chunks - 1ull;
-				#pragma unroll 1
-				for (int k = 0; k < CH; k++) {
-					const int channel = ch_begin + chunk * CH + k;
-					if (channel >= ch_end) break;
-					float dx;
-					const float r_index = receive_index(channel, dx);
-					const bool  pass = __builtin_fabsf(dx * f_over_z) < 0.5f;
-					const bool  reach = pass && !(r_index + t_lo >= bfx::edge_lo<INTERP>() + edge_margin && r_index + t_hi < bfx::edge_hi<INTERP>(S) - edge_margin);
-					if (__builtin_amdgcn_ballot_w64(reach) == 0ull) continue;
-					for (int a = first_transmit; a < A; a++) {
-						float t_index = transmit_index(a);
-						asm volatile("" : "+v"(t_index));
-						const float index = t_index + r_index;
-						if (pass && bfx::edge_near<INTERP>(index, S, edge_margin))
-							bfx::edge_term<FAMILY, INTERP, CPLX, CW>(bfx::kernel_args(), ex, ey, p.z_first + ezl, channel, a, coherent, incoherent);
-					}
-				}
-			}
-		}
 	}
 
 	if (p.split_shift) {

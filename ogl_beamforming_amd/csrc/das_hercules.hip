@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	VT    coherent   = zero_sample<CPLX>();
 	float incoherent = 0.f;
 	[[maybe_unused]] const float edge_margin = p.edge_margin;
-	[[maybe_unused]] unsigned long long edge_lanes = 0;         /* checked loop: the lanes with a pair left out at an end of its RF row (a scalar) */
+	[[maybe_unused]] unsigned long long edge_outer[4] = {0, 0, 0, 0};       /* the outer elements (bit m; at most 256) whose checked loop met such a pair: scalars */
 
 	for (int m = 0; m < n_outer; m++) {
 		float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		/* partial sums of this outer element; acc1/acc2 hold re*(cos,sin) and im*(cos,sin) */
 		f32x2 acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
 		float accr = 0.f, mag = 0.f;
+		[[maybe_unused]] unsigned long long edge_here = 0;      /* checked loop, row-end instantiation: lanes with a pair within the margin of a row end (a scalar) */
 		const f32x2 od2p = splat(od2), z2p = splat(z2), T0p = splat(T0), kp = splat(fs_over_c),
 		            wsp = splat(w_scale), tpsp = splat(turns_per_sample),
 		            oz2p = splat(od2 + z2), wodp = splat(w_scale * od2);
@@ -329,26 +330,17 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					const uint32_t first = RAWC ? ki - 1u : ki;              /* raw cubic taps start one sample early */
 					off[k] = CHECK ? row + first * ES : first * ES;
 					if constexpr (CHECK) {
-						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124); a term within the margin of an end of its
-						 * row is left out here and evaluated with the shader's own index at the end of the kernel (das_exact.h) */
-						bool edge = false;
-						if constexpr (EDGES) {
-							edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
-							edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
-						}
-						bool ok = ((POLY || RAWC) ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test) && !edge;
+						/* linear: 0 <= index < S - 1; cubic: 1 <= index < S - 2 (das.glsl:99-124) */
+						bool ok = ((POLY || RAWC) ? (ki - 1u) < (uint32_t)(S - 3) : ki < ulast) && (e < apodization_test);
+						if constexpr (EDGES) edge_here |= __builtin_amdgcn_ballot_w64(bfx::edge_near<INTERP>(idx, S, edge_margin) && e < apodization_test);
 						off[k] = ok ? off[k] : q.zero_offset;
 						ap[k]  = ok ? ap[k] : 0.f;
 					}
 				} else {
-					if constexpr (CHECK && EDGES) {
-						const bool edge = bfx::edge_near<INTERP>(idx, S, edge_margin) && (e < apodization_test);
-						edge_lanes |= __builtin_amdgcn_ballot_w64(edge);
-						idx = edge ? -8.0f : idx;                     /* outside every mode's range: zero weights */
-					}
 					tap[k] = tap_setup<INTERP, CPLX>(idx, (float)S, S - 1);
 					off[k] = row + tap[k].off;
 					if constexpr (CHECK) ap[k] = (e < apodization_test) ? ap[k] : 0.f;
+					if constexpr (CHECK && EDGES) edge_here |= __builtin_amdgcn_ballot_w64(bfx::edge_near<INTERP>(idx, S, edge_margin) && e < apodization_test);
 				}
 			}
 			TapData<INTERP, CPLX> d[B];
@@ -410,6 +402,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		};
 
 		auto inner = [&](auto checked_c) {
+			constexpr int NB = BF_HERC_BATCH;
 			int n = 0;
 			/* the reference's weight of transmit 0 (das.glsl:272-273); UHERCULES never visits it */
 			if (q.inner_is_transmit && !p.sparse) {
@@ -419,16 +412,16 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 			}
 			/* table entries of the next batch are fetched (scalar loads) while this one computes; the
 			 * row is padded so that reading one batch past the end stays inside it */
-			float cur[BF_HERC_BATCH];
+			float cur[NB];
 			#pragma unroll
-			for (int k = 0; k < BF_HERC_BATCH; k++) cur[k] = row_d2[n + k];
-			for (; n + BF_HERC_BATCH <= n_inner; n += BF_HERC_BATCH) {
-				float nxt[BF_HERC_BATCH];
+			for (int k = 0; k < NB; k++) cur[k] = row_d2[n + k];
+			for (; n + NB <= n_inner; n += NB) {
+				float nxt[NB];
 				#pragma unroll
-				for (int k = 0; k < BF_HERC_BATCH; k++) nxt[k] = row_d2[n + BF_HERC_BATCH + k];
-				group(checked_c, std::integral_constant<int, BF_HERC_BATCH>{}, n, cur, 1.0f);
+				for (int k = 0; k < NB; k++) nxt[k] = row_d2[n + NB + k];
+				group(checked_c, std::integral_constant<int, NB>{}, n, cur, 1.0f);
 				#pragma unroll
-				for (int k = 0; k < BF_HERC_BATCH; k++) cur[k] = nxt[k];
+				for (int k = 0; k < NB; k++) cur[k] = nxt[k];
 			}
 			for (; n < n_inner; n++) {
 				float d2 = row_d2[n];
@@ -437,6 +430,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		};
 		if (wave_fast) inner(std::false_type{});
 		else           inner(std::true_type{});
+		if constexpr (EDGES) { if (edge_here != 0ull) edge_outer[(m >> 6) & 3] |= 1ull << (m & 63); }
 
 		/* fold this outer element (its weight when the outer loop is the transmit loop) */
 		const float outer_weight = (!q.inner_is_transmit && !p.sparse && m == 0) ? p.first_transmit_weight : 1.0f;
@@ -449,28 +443,27 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 		if constexpr (CW) incoherent += outer_weight * mag;
 	}
 	if constexpr (EDGES) {
-		if (edge_lanes != 0ull) {
-			/* ---- row ends: the pairs the checked loop left out -- the same index arithmetic, so the same pairs -- each evaluated from
-			 * the voxel's integer coordinates with the shader's own index (das_exact.h), weight and all, into the voxel's sums.  Rare: a
-			 * wave gets here only if one of its lanes had such a pair; its registers are not the loops'. */
+		{
+			/* ---- row ends (das_exact.h).  The loops above are round 3's, untouched: they decide sample_rf's range test with their own index.
+			 * Here the outer elements whose checked loop met a pair within the margin of an end (noted there: one compare per pair) are
+			 * walked again -- the same index arithmetic as the checked loop's (explicit fmas there and here) --; such a pair is evaluated from the
+			 * voxel's integer coordinates with the shader's own index, and the voxel's sums are corrected by the difference to what the
+			 * loops decided and added for it.  Its registers are not the loops'. */
 			const int sparse = p.sparse != 0;
 			uint32_t ex = x;
 			asm volatile("" : "+v"(ex));                       /* (or hipcc evaluates the exact voxel transform at the top of the kernel and keeps it across the loops) */
 			for (int m = 0; m < n_outer; m++) {
+				if (!((edge_outer[(m >> 6) & 3] >> (m & 63)) & 1ull)) continue;
 				const float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
 				const float od  = outer_lateral - outer_element * outer_pitch;
 				const float od2 = od * od * s2;
-				if (__builtin_amdgcn_ballot_w64(od2 + d2_min < apodization_test) == 0) continue;
-				/* (only outer elements for which some lane's index range reaches an end of its row: the loop's own test) */
-				const float i_lo = T0 + hw_sqrt(z2 + (od2 + d2_min)) * fs_over_c, i_hi = T0 + hw_sqrt(z2 + (od2 + d2_max)) * fs_over_c;
-				if (__builtin_amdgcn_ballot_w64(!(i_lo >= bfx::edge_lo<INTERP>() + 0.5f && i_hi < bfx::edge_hi<INTERP>(S) - 0.5f)) == 0) continue;
 				for (int n = 0; n < n_inner; n++) {
 					const float e2  = od2 + row_d2[n];
 					const float idx = __builtin_fmaf(hw_sqrt(z2 + e2), fs_over_c, T0);
 					if (e2 < apodization_test && bfx::edge_near<INTERP>(idx, S, edge_margin)) {
 						const int channel  = q.inner_is_transmit ? m : n;
 						const int transmit = (q.inner_is_transmit ? n : m) + sparse;
-						bfx::edge_term<BF_DAS_HERCULES, INTERP, CPLX, CW>(bfx::kernel_args(), ex, y, z, channel, transmit, coherent, incoherent);
+						bfx::edge_correct<BF_DAS_HERCULES, INTERP, CPLX, CW>(bfx::kernel_args(), ex, y, z, channel, transmit, idx, coherent, incoherent);
 					}
 				}
 			}

@@ -20,16 +20,16 @@ namespace bf {
 const char *das_path_name(int path)
 {
 	static const char *names[] = {"general kernel", "separable-delay gather kernel", "separable-delay LDS-staged kernel", "per-voxel factored kernel",
-	                              "(retired: LDS row-cache experiment)", "HERCULES aligned-grid kernel", "per-voxel factored kernel with block-wide LDS staging",
+	                              "HERCULES aligned-grid kernel", "per-voxel factored kernel with block-wide LDS staging",
 	                              "?", "none: the frame is cleared"};
-	return path >= 0 && path <= 8 ? names[path] : "?";
+	return path >= 0 && path <= 7 ? names[path] : "?";
 }
 
 const char *das_kernel_name(int path)
 {
-	static const char *names[] = {"das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel", "das_rowcache_kernel (retired)",
+	static const char *names[] = {"das_kernel", "das_rca_separable_kernel", "das_rca_staged_kernel", "das_factored_kernel",
 	                              "das_hercules_kernel", "das_tile_kernel", "?", "(none)"};
-	return path >= 0 && path <= 8 ? names[path] : "?";
+	return path >= 0 && path <= 7 ? names[path] : "?";
 }
 
 /* ---------------------------------------------------------------- hooks */
@@ -624,7 +624,6 @@ void decide_das(const ParameterBlock &pb, const Plan &plan, const std::vector<Bf
 	const bool factored = factored_applies(a, tx, das_mode);
 	auto &why = out.why;
 	why[DasPath_Tile] = "only where the factored kernel would run (its block-staged form)";
-	why[DasPath_Retired] = "retired";
 	if (das_mode == 1) {
 		why[DasPath_Gather] = why[DasPath_Staged] = why[DasPath_Hercules] = why[DasPath_Factored] = "das path 1: the general kernel was asked for";
 	}

@@ -13,10 +13,10 @@ namespace bf {
 
 /* BeamformerHipFrameTimings::das_path */
 enum DasPath {
-	DasPath_General = 0, DasPath_Gather = 1, DasPath_Staged = 2, DasPath_Factored = 3, DasPath_Retired = 4, DasPath_Hercules = 5,
-	DasPath_Tile = 6,             /* das_tile.hip: the factored kernel with block-wide LDS staging */
-	DasPath_Count = 7,
-	DasPath_Zero = 8,             /* a family / interpolation the shader leaves at zero: the frame is cleared, no kernel */
+	DasPath_General = 0, DasPath_Gather = 1, DasPath_Staged = 2, DasPath_Factored = 3, DasPath_Hercules = 4,
+	DasPath_Tile = 5,             /* das_tile.hip: the factored kernel with block-wide LDS staging */
+	DasPath_Count = 6,
+	DasPath_Zero = 7,             /* a family / interpolation the shader leaves at zero: the frame is cleared, no kernel */
 };
 const char *das_path_name(int path);      /* "LDS-staged kernel", ... */
 const char *das_kernel_name(int path);    /* "das_rca_staged_kernel", ... */

@@ -564,8 +564,10 @@ hipError_t launch_tile(const BfDasArgs *a, hipStream_t s)
 	const uint32_t grid  = a->depth_major == 3u ? bf_plane_walk_blocks(a->blocks[0], a->blocks[1], a->band_rows) : ((total + 7u) / 8u) * 8u;
 	const uint32_t A_pad = ((uint32_t)a->acquisition_count + 15u) & ~15u;
 	uint32_t lds = 64u + 2u * kTileElems * 32u + 32u + 4u * A_pad + 4u * 2u * kTileCH * 16u + 64u;
-	const uint32_t scratch = 64u + 2u * 4u * 16u * A_pad;             /* the transmit pass borrows the staging area */
-	if (scratch > lds) lds = scratch;
+	/* the transmit pass borrows the staging area for its [transmit][wave] minima and maxima: they must end before the zero element and the
+	 * floors behind it (true for every count the planner admits -- BeamformerMaxEmissionsCount = 256 -- and checked rather than assumed) */
+	const uint32_t scratch = 64u + 2u * 4u * 16u * A_pad;
+	if (scratch > 64u + 2u * kTileElems * 32u) return hipErrorInvalidValue;
 	auto kernel = das_tile_kernel<FAMILY, CW, WS>;
 	hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (e != hipSuccess) return e;

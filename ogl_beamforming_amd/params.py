@@ -216,6 +216,16 @@ class HipFrameTimings(C.Structure):
     ]
 
 
+class DasPath(enum.IntEnum):
+    """BeamformerHipFrameTimings::das_path / BeamformerHipDasDescription::path (csrc/das_select.h)"""
+    General = 0
+    Gather = 1
+    Staged = 2
+    Factored = 3
+    Hercules = 4
+    Tile = 5
+
+
 class HipDeviceInfo(C.Structure):
     _fields_ = [("ordinal", C.c_int32), ("peer_access", C.c_int32), ("slab_first", C.c_uint32), ("slab_count", C.c_uint32),
                 ("peer_copy_ms", C.c_float), ("das_ms", C.c_float), ("frame_ms", C.c_float),

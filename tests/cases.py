@@ -246,14 +246,14 @@ CASES.update(_plane_cases())
 # What the automatic selection is EXPECTED to pick for the named cases -- written down, not derived: the rules live in ONE place
 # (csrc/das_select.cpp; beamformer_hip_describe_das reports its decision and the reason every other kernel declined), and the
 # test below checks (1) that the kernel that ran is the one described and (2) these expectations.
-# 0 general, 1 separable-delay gather, 2 LDS-staged, 3 per-voxel factored, 5 HERCULES aligned-grid
+# 0 general, 1 separable-delay gather, 2 LDS-staged, 3 per-voxel factored, 4 HERCULES aligned-grid (5: block-staged factored)
 EXPECTED_AUTOMATIC = {
     "config1_small": 0, "config2_small": 3, "config3_small": 0, "config4_small": 1, "config5_small": 0,
     "rca_staged_auto": 2, "rca_staged_w64": 1, "rca_staged_too_wide": 1, "rca_staged_ragged": 2, "rca_vls_staged": 2,
     "rca_staged_real": 2, "rca_staged_cubic": 2, "rca_staged_fine": 2, "rca_sep_ragged_cubic": 3, "rca_sep_real_nearest": 3,
-    "hercules_wide_cw": 5, "hercules_wide_real_swapped": 5, "hercules_wide_cubic_cw": 5, "hercules_plane_xz": 5, "hercules_plane_yz": 5,
+    "hercules_wide_cw": 4, "hercules_wide_real_swapped": 4, "hercules_wide_cubic_cw": 4, "hercules_plane_xz": 4, "hercules_plane_yz": 4,
     "forces": 3, "uforces_sparse": 3, "readi": 0, "harness_tpw_small": 3, "harness_forces_small": 3, "harness_hercules_small": 0,
-    "hercules_plane_xz_short_rows": 5, "hercules_plane_yz_short_rows": 5,
+    "hercules_plane_xz_short_rows": 4, "hercules_plane_yz_short_rows": 4,
 }
 # ... and how many z-planes of the case the row-end rule hands to the kernel BEHIND that choice (cases not listed: none)
 EXPECTED_ROW_END_PLANES = {

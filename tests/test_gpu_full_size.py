@@ -147,7 +147,7 @@ def test_other_baseline_configs_at_full_size(n, path_name, bflib, oracle):
     frame = run(bflib, acq, shard=shard)
     t = P.HipFrameTimings()
     assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t))
-    assert int(t.das_path) == {"general": 0, "factored": 3, "hercules": 5, "tile": 6}[path_name]
+    assert int(t.das_path) == {"general": 0, "factored": 3, "hercules": 4, "tile": 5}[path_name]
     if path_name == "tile":
         # 1024 blocks x 32 chunks of four channels: (almost) all of them read from the staged windows
         assert int(t.tile_staged_chunks) + int(t.tile_gather_chunks) <= 1024 * 32
@@ -300,7 +300,7 @@ def test_config2_block_staged_frames_repeat_bit_for_bit(bflib):
     acq = cfg.config(2)
     first = run(bflib, acq).copy()
     t = P.HipFrameTimings()
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 6 and int(t.tile_gather_chunks) == 0
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 5 and int(t.tile_gather_chunks) == 0
     for k in range(11):
         again = run(bflib, acq)
         assert np.array_equal(first.view(np.uint32), again.view(np.uint32)), f"frame {k + 2} differs from the first"
@@ -317,7 +317,7 @@ def test_config2_f32_complex_first_and_last_rows(bflib, oracle):
                     angles=np.linspace(-15.0, 15.0, 31), scatterer=scatterer)
     frame = run(bflib, acq)
     t = P.HipFrameTimings()
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 6
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 5
     mag = np.abs(frame)
     _, py, px = np.unravel_index(np.argmax(mag), mag.shape)
     assert abs(px - (scatterer[0] + 12.8e-3) / 25.6e-3 * 1023) <= 2 and abs(py - 0.4 * 1023) <= 2, (px, py)
@@ -347,7 +347,7 @@ def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits,
     if interp == P.InterpolationMode.Cubic and transmits == 128:
         # 128 transmits x 32-byte window elements do not fit the LDS: the staged cubic kernel declines, the factored kernel runs -- in its
         # block-staged form (das_tile.hip): the slab's grid is fine enough for 64-sample windows
-        assert int(t.das_path) == 6
+        assert int(t.das_path) == 5
         return
     assert int(t.das_path) == 2
     bflib.set_hook("STAGED_CHECKED", "1")
@@ -358,7 +358,7 @@ def test_staged_kernel_against_the_gather_kernel_over_transmit_counts(transmits,
         bflib.set_hook("STAGED_CHECKED", None)
     assert np.array_equal(checked.view(np.uint32), staged.view(np.uint32))
     gathered = run(bflib, acq, shard=(120, 4), path=2)          # cubic: the factored kernel (block-staged form)
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == (6 if interp == P.InterpolationMode.Cubic else 1)
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == (5 if interp == P.InterpolationMode.Cubic else 1)
     assert np.array_equal(np.isnan(staged), np.isnan(gathered))
     ok = ~np.isnan(gathered)
     assert ok.any() and np.abs(staged[ok] - gathered[ok]).max() / np.abs(gathered[ok]).max() < 1e-4
@@ -385,7 +385,7 @@ def test_config5_rows_at_the_edges_of_the_volume(bflib, oracle):
     acq = cfg.config(5)
     frame = run(bflib, acq)
     t = P.HipFrameTimings()
-    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 5
+    assert bflib.library().beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 4
     ref, _ = oracle.beamform(acq.bp, acq.rf, acq.filters, threads=16, z=(0, 3), y=(0, 3), stride=(255, 255))
     got = frame[0:511:255, 0:511:255]
     assert got.shape == ref.shape == (3, 3, 512)
@@ -400,7 +400,7 @@ def test_config5_rows_at_the_edges_of_the_volume(bflib, oracle):
     assert delta / np.abs(ref[ok]).max() <= 4 * cases.tolerance(acq), delta / np.abs(ref[ok]).max()
 
 
-@pytest.mark.parametrize("kind, path", [("tpw", 3), ("forces", 3), ("hercules", 5), ("vls", 3)])
+@pytest.mark.parametrize("kind, path", [("tpw", 3), ("forces", 3), ("hercules", 4), ("vls", 3)])
 def test_reference_harness_frame_at_full_size(kind, path, bflib, oracle):
     """The frame the reference's own throughput harness beamforms (tests/throughput.c:20-23, :443-491): 256 channels x 128
     transmits x 4096 samples -> the 512 x 1024 XZ view plane, cubic, F# 0.5, {Demodulate, Decode, DAS}.  The automatic path

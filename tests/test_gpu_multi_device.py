@@ -64,7 +64,7 @@ def test_slabs_stitch_to_the_one_device_frame(name, count, bflib, devices):
 
 @pytest.mark.parametrize("name, count", [("rca_sep_ragged_cubic", 3), ("rca_staged_cubic", 2)])
 def test_block_staged_kernel_slabs(name, count, bflib, devices):
-    """das_tile.hip (das path 6, asked for with flag 0x100) on z-slabs of a volume: every device context runs it on its planes
+    """das_tile.hip (das path 5, asked for with flag 0x100) on z-slabs of a volume: every device context runs it on its planes
     (z_first, z_count in the kernel's tiling) and the stitched frame is bit-identical to the one-device frame."""
     acq = cases.make(name)
     lib = bflib.library()
@@ -73,7 +73,7 @@ def test_block_staged_kernel_slabs(name, count, bflib, devices):
         devices([0])
         one = bflib.beamform(acq.bp, acq.rf, acq.filters).copy()
         t = P.HipFrameTimings()
-        assert lib.beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 6
+        assert lib.beamformer_hip_get_last_frame_timings(C.byref(t)) and int(t.das_path) == 5
         devices([0] * count)
         many = bflib.beamform(acq.bp, acq.rf, acq.filters)
         assert same_bits(one, many)
@@ -82,7 +82,7 @@ def test_block_staged_kernel_slabs(name, count, bflib, devices):
         for i in range(count):
             assert lib.beamformer_hip_get_device_frame_timings(i, C.byref(t)) and int(t.das_voxels) > 0
             paths.append(int(t.das_path))
-        assert set(paths) <= {6, 3} and 6 in paths, paths
+        assert set(paths) <= {5, 3} and 5 in paths, paths
     finally:
         lib.beamformer_hip_set_das_path(0)
 

@@ -127,7 +127,7 @@ def test_frame_parity(name, bflib, oracle):
     assert last_das_path(bflib) == path, (kernel, reasons)
     if name in EXPECTED_AUTOMATIC:
         assert path == EXPECTED_AUTOMATIC[name], (name, kernel, reasons)
-    assert all(reasons[k] for k in (1, 2, 3, 5) if k != path), reasons          # every kernel not taken says why
+    assert all(reasons[k] for k in (1, 2, 3, 4) if k != path), reasons          # every kernel not taken says why
     compare(gpu, ref, acq, flags)
 
 
@@ -290,7 +290,7 @@ def test_hercules_aligned_kernel(name, bflib, oracle):
     lib.beamformer_hip_set_das_path(6)
     try:
         gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-        assert last_das_path(bflib) == 5
+        assert last_das_path(bflib) == 4
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)
@@ -327,7 +327,7 @@ def test_hercules_coherent_peak_at_long_delays(bflib, oracle):
     peak = np.abs(ref).max()
     assert peak > 0.5 * 4.0 * C_ * A * 0.5                      # coherent: most of the 4096 taps add up
     lib = bflib.library()
-    for mode, want_path in ((6, 5), (0x11, 0)):
+    for mode, want_path in ((6, 4), (0x11, 0)):
         lib.beamformer_hip_set_das_path(mode)
         try:
             gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
@@ -410,7 +410,7 @@ def tile_candidates():
     try:
         for n in sorted(cases.CASES):
             acq = cases.make(n)
-            if bflib_mod.describe_das(acq.bp, acq.filters)[0] == 6:
+            if bflib_mod.describe_das(acq.bp, acq.filters)[0] == 5:
                 out.append(n)
     finally:
         lib.beamformer_hip_set_das_path(0)
@@ -467,7 +467,7 @@ def test_factored_kernel_block_staging(name, bflib, oracle):
         lib.beamformer_hip_enable_pair_counting(1)         # (the count runs with the general kernel's tiles, not the block's)
         tile = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
         t = last_timings(bflib)
-        assert int(t.das_path) == 6
+        assert int(t.das_path) == 5
         assert abs(int(t.das_pairs) - pairs) <= max(4, 2e-4 * pairs), (int(t.das_pairs), pairs)
         staged, gathered = int(t.tile_staged_chunks), int(t.tile_gather_chunks)
         assert staged + gathered > 0
@@ -478,7 +478,7 @@ def test_factored_kernel_block_staging(name, bflib, oracle):
         lib.beamformer_hip_enable_pair_counting(0)
         lib.beamformer_hip_set_das_path(0x14 | 0x200)
         np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters))
-        assert last_das_path(bflib) != 6
+        assert last_das_path(bflib) != 5
     finally:
         lib.beamformer_hip_enable_pair_counting(0)
         lib.beamformer_hip_set_das_path(0)
@@ -495,7 +495,7 @@ def test_block_staged_kernel_is_deterministic(name, bflib):
     try:
         lib.beamformer_hip_set_das_path(0x14 | 0x100)
         first = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters)).copy()
-        assert last_das_path(bflib) == 6
+        assert last_das_path(bflib) == 5
         for k in range(39):
             again = np.asarray(bflib.beamform(acq.bp, acq.rf, acq.filters))
             assert np.array_equal(first.view(np.uint32), again.view(np.uint32)), f"frame {k + 2} differs from the first"

@@ -112,7 +112,7 @@ def test_random_acquisition(seed, bflib, oracle, hooks):
         bflib.library().beamformer_hip_set_das_path(6)
         try:
             gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
-            assert last_das_path(bflib) == 5
+            assert last_das_path(bflib) == 4
         finally:
             bflib.library().beamformer_hip_set_das_path(0)
         compare(gpu, ref, acq, flags)
@@ -228,7 +228,7 @@ def test_random_acquisition_on_the_block_staged_kernel(seed, bflib, oracle):
     finally:
         lib.beamformer_hip_set_das_path(0)
     compare(gpu, ref, acq, flags)            # against the oracle, nothing else (round 3 accepted voxels on which another kernel agreed)
-    if int(t.das_path) == 6:
+    if int(t.das_path) == 5:
         TILE_DRAWS.append((seed, int(t.tile_staged_chunks), int(t.tile_gather_chunks)))
 
 

@@ -1,8 +1,8 @@
-"""Where the block-staged factored kernel (das_tile.hip, das path 6) beats the per-voxel factored kernel (das_factored.hip): BASELINE
+"""Where the block-staged factored kernel (das_tile.hip, das path 5) beats the per-voxel factored kernel (das_factored.hip): BASELINE
 config 2's acquisition (128 channels x 31 plane waves, cubic, IQ) beamformed onto N x N grids of the same extent -- the finer the
 grid, the smaller the spread of a 64 x 16-voxel tile.  For each N: what the library picks on its own, then the block-staged kernel
 forced (flags 0x100 | 0x10: no channel split either) and forbidden (flag 0x200), with the share of (block, chunk) pairs the block-staged kernel had to run through
-its gather loop.  das_select.cpp's rule for path 6 (estimated spread <= 58 samples) comes from this table.
+its gather loop.  das_select.cpp's rule for path 5 (estimated spread <= 58 samples) comes from this table.
 Run from the repository root on a GPU box:  PYTHONPATH=. python tools/tile_threshold.py [--json out.json]"""
 import argparse
 import ctypes as C
@@ -43,7 +43,7 @@ for N in (int(v) for v in args.points.split(",")):
             best = min(best, float(t.stage_ms[kinds.index(int(P.ShaderKind.DAS))]))
         row[name + "_ms"] = round(best, 4)
         row[name + "_path"] = int(t.das_path)
-        if int(t.das_path) == 6:
+        if int(t.das_path) == 5:
             total = int(t.tile_staged_chunks) + int(t.tile_gather_chunks)
             row[name + "_gather_share"] = round(int(t.tile_gather_chunks) / max(1, total), 4)
             row[name + "_window"] = int(lib.describe_das(bp, base.filters)[4].tile_window_samples)
