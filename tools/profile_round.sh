@@ -14,12 +14,12 @@ if [ $part = pmc ]; then
 timeout -k 10 300 tools/bin/microbench > $OUT/profiles/${R}_microbench.json 2> $OUT/microbench.err
 cp $OUT/profiles/${R}_microbench.json profiles/${R}_microbench.json
 echo "microbench done"
-timeout -k 10 480 python3 tools/pmc_das.py --config 4 --groups 0,1,2,7,8,9 --timeout 120 --out $OUT/pmc_cfg4 > $OUT/pmc_cfg4.log 2>&1
+timeout -k 10 600 python3 tools/pmc_das.py --config 4 --groups 0,1,2,7,8,9,10 --timeout 120 --out $OUT/pmc_cfg4 > $OUT/pmc_cfg4.log 2>&1
 timeout -k 10 200 python3 tools/pmc_das.py --config 4 --planes 16 --groups 3,5 --timeout 90 --out $OUT/pmc_cfg4_ta > $OUT/pmc_cfg4_ta.log 2>&1
 timeout -k 10 300 python3 tools/pmc_das.py --config 2 --groups 0,1,3,5,7,8,9 --timeout 60 --out $OUT/pmc_cfg2 > $OUT/pmc_cfg2.log 2>&1
 timeout -k 10 420 python3 tools/pmc_das.py --config 5 --planes 32 --groups 0,1,3,5,9 --timeout 90 --out $OUT/pmc_cfg5 > $OUT/pmc_cfg5.log 2>&1
 for k in tpw hercules forces; do
-  timeout -k 10 300 python3 tools/pmc_das.py --config harness:$k --groups 0,1,2,3,5,7,8,9 --timeout 60 --out $OUT/pmc_harness_$k > $OUT/pmc_harness_$k.log 2>&1
+  timeout -k 10 400 python3 tools/pmc_das.py --config harness:$k --groups 0,1,2,3,5,7,8,9,10,11 --timeout 60 --out $OUT/pmc_harness_$k > $OUT/pmc_harness_$k.log 2>&1
 done
 echo "pmc done"
 python3 tools/summarize_profiles.py --round $R $OUT/pmc_cfg4/summary.json $OUT/pmc_cfg4_ta/summary.json $OUT/pmc_cfg2/summary.json $OUT/pmc_cfg5/summary.json \

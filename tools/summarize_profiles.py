@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # as bench.py: the kernel's own file plus the headers every DAS kernel includes, comments and whitespace removed
 KERNEL_FILES = {"das_kernel": "das.hip", "das_rca_separable_kernel": "das_separable.hip", "das_rca_staged_kernel": "das_staged.hip",
                 "das_rca_staged_real_kernel": "das_staged_real.hip", "das_rca_staged_cubic_kernel": "das_staged_cubic.hip", "das_factored_kernel": "das_factored.hip", "das_tile_kernel": "das_tile.hip", "das_hercules_kernel": "das_hercules.hip"}
-COMMON_SOURCES = ["das_common.h", "bf_kernels.h", "das_select.cpp"]
+COMMON_SOURCES = ["das_common.h", "das_exact.h", "bf_kernels.h", "das_select.cpp"]
 
 
 def kernel_source_hash(kernel):
@@ -92,6 +92,16 @@ def main():
                     "elapsed_cycles_per_simd": cycles * SIMDS / g}
             if "SQ_WAVE_CYCLES" in c:
                 e["mean_resident_waves_per_cu"] = c["SQ_WAVE_CYCLES"] * 4.0 / (cycles * 256)
+            if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+                # what a resident wave does with its cycles (disjoint, MI355X_MICROARCH.md "rocprofv3 PMC slots"): parked on s_waitcnt or a
+                # barrier, issue-stalled (a dependency or a busy pipe), or issuing
+                w = c["SQ_WAVE_CYCLES"]
+                e["wave_cycles"] = {"parked_on_waitcnt_or_barrier": c["SQ_WAIT_ANY"] / w, "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / w,
+                                    "issuing": c.get("SQ_ACTIVE_INST_ANY", 0.0) / w}
+            if c.get("TCP_TCC_READ_REQ_LATENCY_sum") and c.get("TCP_TCC_READ_REQ_sum"):
+                e["l1_miss_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
+            if c.get("TCP_PENDING_STALL_CYCLES_sum") is not None and "GRBM_GUI_ACTIVE" in c:
+                e["tcp_pending_stall_frac"] = c["TCP_PENDING_STALL_CYCLES_sum"] / (cycles * 256)
             if "TCC_HIT_sum" in c:
                 e["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
             if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
@@ -107,7 +117,7 @@ def main():
                 # a second run of the same kernel (e.g. the TA/TCP groups taken on a slab): derived fractions the first
                 # run lacks are added, raw counters are kept apart under the run's own label
                 for k in ("valu_busy_frac", "ta_busy_frac", "l1_hit_rate", "l2_hit_rate", "per_gather_instruction", "mean_resident_waves_per_cu",
-                          "lds_idx_active_frac", "lds_bank_conflict_frac"):
+                          "lds_idx_active_frac", "lds_bank_conflict_frac", "wave_cycles", "l1_miss_latency_cycles", "tcp_pending_stall_frac"):
                     if k in e and k not in have:
                         have[k] = e[k]
                         have.setdefault("also_from", {})[k] = s["command"]
