@@ -80,13 +80,14 @@ typedef struct {
 	uint32_t lds_bytes;       /* 16 * (channel_chunk << u_shift) + 16 * (transmits << v_shift) */
 	uint32_t tiles[3];        /* tiles along u, along v, z planes of the shard */
 	uint32_t depth_major;     /* tile walk: 1 = z fastest (consecutive tiles share a lateral column), 0 = x, y, z */
+	uint32_t walk_columns;    /* depth_major: columns adjacent along u that are walked together (bf_column_walk): 4, 2 or 1, a divisor of tiles[0] */
 	uint32_t window_shift;    /* staged kernel: log2 of the RF window (samples) copied to LDS per transmit */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes the host keeps behind
 	                             the DAS input: where out-of-range lanes gather from */
 	/* staged kernel (complex, linear), 64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are
 	 * uniform and come from a global table (bf_launch_das_staged_tables writes it per frame) through scalar loads */
 	uint32_t uniform;         /* 1: use `tables` */
-	uint32_t window_samples;  /* 32, 64 (= 1 << window_shift), or 48: the uniform variant's in-between window */
+	uint32_t window_samples;  /* 32 or 64 (= 1 << window_shift) */
 	uint32_t table_stride;    /* bytes per (lateral tile row, plane) slice: 4 A4 + 16 + 16 (A4 / 4) 48, A4 = transmits rounded up to 4 */
 	void    *tables;          /* tiles[1] * tiles[2] slices */
 	uint32_t *violations;     /* staged kernels, range-checked loop: incremented once per wave and channel in which some term's window
@@ -157,6 +158,25 @@ typedef struct {
 	uint32_t channels, transmits;
 	int32_t  in_kind, out_kind;
 } BfFilterArgs;
+
+/* Depth-major tile walk of VOLUMES (separable gather and LDS-staged kernels).  An XCD has ~64 consecutive tiles of its run in flight (two
+ * 1024-thread blocks on each of 32 CUs) and its 4 MiB L2 serves what they read.  With one column walked z fastest those are 64 consecutive
+ * depths: the RF window of a (channel, transmit) drifts ~1.5 samples per plane at config 4, 96 samples over the set -- three 32-sample
+ * windows apart, so most lines are pulled for one tile.  With g columns ADJACENT ALONG u walked together they are 64 / g depths (g = 4: a
+ * 24-sample drift, inside one window) of columns whose transmit windows are the same and whose receive windows neighbour.  Measured on
+ * config 4's staged kernel, HBM-side bytes per launch (profiles/r04_traffic.json; kernel time equal within 0.3 %): one column 288 GB,
+ * g = 2 123 GB, g = 4 52 GB, g = 8 94 GB, a whole row of 16 columns 181 GB, 4 columns along v 56 GB, 2 x 2 65 GB, plane-major 96 GB.
+ * The gather kernel (smaller blocks, more of them in flight, no staging loads) keeps g = 1: 280 GB against 520 with g = 4. */
+static inline uint32_t bf_walk_columns(uint32_t tiles_u) { return tiles_u % 4u == 0 ? 4u : (tiles_u % 2u == 0 ? 2u : 1u); }
+#ifdef __HIPCC__
+static __device__ __forceinline__ void bf_column_walk(uint32_t tile, uint32_t tiles_u, uint32_t tiles_z, uint32_t g, uint32_t &tu, uint32_t &tv, uint32_t &zl)
+{
+	const uint32_t r = tile / g, col = r / tiles_z, per_row = tiles_u / g;
+	zl = r % tiles_z;
+	tu = (col % per_row) * g + tile % g;
+	tv = col / per_row;
+}
+#endif
 
 /* Tile walk of VIEW PLANES (depth_major == 3; depth lies along voxel y, one voxel along z -- math.c:844-885).  The work of a
  * tile grows with its depth (the f-number test culls shallow voxels), so neither a run of depth rows per XCD (idle XCDs: the

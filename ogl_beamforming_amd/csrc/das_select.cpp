@@ -309,6 +309,7 @@ static bool plan_separable(const BfDasArgs &a, const std::vector<BfTransmit> &tx
 	q.tiles[0] = (nu + (1u << best_u) - 1) >> best_u;
 	q.tiles[1] = (nv + (1u << best_v) - 1) >> best_v;
 	q.tiles[2] = zcount;
+	q.walk_columns = 1u;          /* the gather kernel: one column (four together doubled its HBM-side bytes at config 4, 280 -> 520 GB, time equal) */
 	return true;
 }
 
@@ -412,6 +413,7 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 	q.tiles[0] = (nu + (1u << q.u_shift) - 1) >> q.u_shift;
 	q.tiles[1] = (nv + (1u << q.v_shift) - 1) >> q.v_shift;
 	q.tiles[2] = zcount;
+	q.walk_columns = bf_walk_columns(q.tiles[0]);
 	return true;
 }
 

@@ -67,14 +67,12 @@ __global__ __launch_bounds__(1024, 8) void das_rca_separable_kernel(const BfDasA
 	const uint32_t tile  = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 	if (tile >= total) return;                               /* whole block: no barrier is skipped */
 	/* walk order of the tile list.  Depth-major (default): consecutive tiles -- the ones an XCD has in
-	 * flight together -- are the same (u, v) column at consecutive depths, whose RF windows overlap
-	 * by ~94 % (the window moves ~1.5 samples per plane and ~14 per tile laterally at config 4), so
-	 * the lines one tile pulls into the XCD's L2 serve its neighbours.  Plane-major: x, then y, then z. */
-	uint32_t tu, tv, zl;
+	 * flight together -- are a few columns adjacent along u at consecutive depths, whose RF windows overlap
+	 * (the window moves ~1.5 samples per plane and ~14 per tile laterally at config 4), so the lines one tile
+	 * pulls into the XCD's L2 serve its neighbours (bf_column_walk, bf_kernels.h).  Plane-major: x, then y, then z. */
+	uint32_t tu, tv, zl;                                         /* along the receive axis, along the transmit axis, plane inside the shard */
 	if (q.depth_major) {
-		zl = tile % q.tiles[2];                                  /* plane inside the shard */
-		tu = (tile / q.tiles[2]) % q.tiles[0];                   /* along the receive axis */
-		tv = tile / (q.tiles[2] * q.tiles[0]);                   /* along the transmit axis */
+		bf_column_walk(tile, q.tiles[0], q.tiles[2], q.walk_columns, tu, tv, zl);
 	} else {
 		tu = tile % q.tiles[0];
 		tv = (tile / q.tiles[0]) % q.tiles[1];

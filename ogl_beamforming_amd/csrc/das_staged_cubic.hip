@@ -63,9 +63,7 @@ __global__ __launch_bounds__(1024, 4) void das_rca_staged_cubic_kernel(const BfD
 	if (tile >= total) return;                               /* whole block */
 	uint32_t tu, tv, zl;                                     /* walk order: das_separable.hip */
 	if (q.depth_major & 1u) {
-		zl = tile % q.tiles[2];
-		tu = (tile / q.tiles[2]) % q.tiles[0];
-		tv = tile / (q.tiles[2] * q.tiles[0]);
+		bf_column_walk(tile, q.tiles[0], q.tiles[2], q.walk_columns, tu, tv, zl);
 	} else {
 		tu = tile % q.tiles[0];
 		tv = (tile / q.tiles[0]) % q.tiles[1];

@@ -42,7 +42,16 @@ def compare(gpu, ref, acq, flags=None):
         if clean.any():
             bad = float(np.mean(err[clean] > max(tol, 1e-3) * scale))
             assert bad < 1e-3, f"nearest: mismatch fraction {bad:.2e} on the {int(clean.sum())} voxels without boundary taps"
-        assert np.median(err[ok]) / scale < (1e-5 if tol <= 1e-4 else tol)
+        # no systematic offset hiding under the budget: the median voxel agrees ten times better than the bar -- or, where float rounding
+        # of the phase alone is that large (round 4's fuzz draw general/1001: 12 terms at 96 turns, the float oracle itself 1.1e-5 from
+        # its double twin at the median voxel), the GPU's median distance to that truth is the oracle's own plus the same allowance
+        median_bar = 1e-5 if tol <= 1e-4 else tol
+        if not np.median(err[ok]) / scale < median_bar:
+            exact = truth_frame(acq, ref.shape)
+            assert exact is not None, f"nearest: median error {np.median(err[ok]) / scale:.3e} >= {median_bar:.0e}"
+            gpu_off, oracle_off = np.median(np.abs(gpu[ok] - exact[ok])) / scale, np.median(np.abs(ref[ok] - exact[ok])) / scale
+            assert gpu_off <= oracle_off + median_bar, (f"nearest: median error {np.median(err[ok]) / scale:.3e} >= {median_bar:.0e} and the GPU's median distance to the "
+                                                        f"double-precision truth {gpu_off:.3e} exceeds the float oracle's {oracle_off:.3e} by more than that")
         return float(np.median(err[ok]) / scale)
     err = np.abs(gpu[ok] - ref[ok]) / scale
     if err.max() > tol:

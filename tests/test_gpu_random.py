@@ -71,7 +71,9 @@ def draw(seed):
 STAGED_DRAWS = []          # seeds whose forced-staged pass ran the LDS-staged kernel (reported by the last test of this module)
 
 
-@pytest.mark.parametrize("seed", range(72))
+# 1001: round 4's out-of-sample fuzz draw whose median error on the gather kernel (1.4e-5: the phase of 96 turns rounded once more than the
+# shader rounds it) is the size of the float oracle's own distance from its double twin -- the draw behind compare()'s median rule
+@pytest.mark.parametrize("seed", list(range(72)) + [1001])
 def test_random_acquisition(seed, bflib, oracle, hooks):
     acq = draw(seed)
     ref, pairs, flags = reference(oracle, acq)

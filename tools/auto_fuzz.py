@@ -62,8 +62,9 @@ for name in args.generators.split(","):
                     bflib.set_hook("STAGED_CHECKED", None)
         except AssertionError as e:
             failed += 1
-            summary["failures"].append({"generator": name, "seed": seed, "path": path, "what": str(e)[:200]})
-            print(name, "seed", seed, "path", path, "FAIL:", str(e)[:200], flush=True)
+            what = str(e)[:200] or traceback.format_exc(limit=-1).strip().splitlines()[-2].strip()[:200]
+            summary["failures"].append({"generator": name, "seed": seed, "path": path, "what": what})
+            print(name, "seed", seed, "path", path, "FAIL:", what, flush=True)
         except Exception:
             failed += 1
             summary["failures"].append({"generator": name, "seed": seed, "path": path, "what": "exception"})

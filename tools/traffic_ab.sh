@@ -5,10 +5,12 @@
 #   part "build" (no GPU; run here):  bash tools/traffic_ab.sh build
 #   part "run"   (GPU box):           gpurun --timeout 1200 -- 'bash tools/traffic_ab.sh run'
 # Variants:
-#   base      the product as it ships: depth-major walk, two 1024-thread blocks per CU (64 tiles in flight per XCD = 64 consecutive depths of one column)
+#   base      the product as it shipped until round 4 (since then: quad_u): depth-major walk, two 1024-thread blocks per CU (64 tiles in flight per XCD = 64 consecutive depths of one column)
 #   one_block 84 KB of LDS asked for: ONE block per CU (32 tiles in flight per XCD: half the depth span, half the phase spread)
 #   pair_u    the 64 tiles in flight = 32 consecutive depths of TWO columns adjacent along u
-#   quad_u    16 consecutive depths of FOUR columns adjacent along u
+#   quad_u    16 consecutive depths of FOUR columns adjacent along u;  oct_u: 8 x 8;  hex_u: 4 depths of a whole row of 16 columns
+#   quad_v    16 consecutive depths of four columns adjacent along v;  quad_uv: 16 depths of 2 x 2 columns
+# VARIANTS="a b c" limits either part to those names (profiles/r04_traffic.json was put together from two such runs: gpurun_out/ does not travel to the box).
 #   plane     plane-major walk (x, y, z): the 64 tiles in flight lie in one plane
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -18,7 +20,7 @@ part=${1:-build}
 if [ $part = build ]; then
   mkdir -p $V
   make -s -C $SRC
-  for name in one_block pair_u quad_u plane; do
+  for name in ${VARIANTS:-one_block pair_u quad_u oct_u hex_u quad_v quad_uv plane}; do
     d=$V/$name; rm -rf $d; mkdir -p $d
     cp $SRC/*.h $d/; cp $SRC/das_staged.hip $d/
     python3 - $name $d/das_staged.hip <<'PY'
@@ -33,10 +35,10 @@ else:
     if name == "plane":
         new = "		tu = tile % q.tiles[0];\n		tv = (tile / q.tiles[0]) % q.tiles[1];\n		zl = tile / (q.tiles[0] * q.tiles[1]);"
     else:
-        g = 2 if name == "pair_u" else 4
-        new = (f"		const uint32_t g_ = {g}u, sub_ = tile % g_, r_ = tile / g_;      /* (tiles[0] divisible by g: config 4 has 16) */\n"
-               "		zl = r_ % q.tiles[2];\n		const uint32_t col_ = r_ / q.tiles[2], per_row_ = q.tiles[0] / g_;\n"
-               "		tu = (col_ % per_row_) * g_ + sub_;\n		tv = col_ / per_row_;")
+        gu, gv = {"pair_u": (2, 1), "quad_u": (4, 1), "oct_u": (8, 1), "hex_u": (16, 1), "quad_v": (1, 4), "quad_uv": (2, 2)}[name]
+        new = (f"		const uint32_t gu_ = {gu}u, gv_ = {gv}u, sub_ = tile % (gu_ * gv_), r_ = tile / (gu_ * gv_);      /* (tiles[0], tiles[1] divisible: config 4 has 16 x 16) */\n"
+               "		zl = r_ % q.tiles[2];\n		const uint32_t col_ = r_ / q.tiles[2], per_row_ = q.tiles[0] / gu_;\n"
+               "		tu = (col_ % per_row_) * gu_ + sub_ % gu_;\n		tv = (col_ / per_row_) * gv_ + sub_ / gu_;")
 assert old in s, name
 open(path, "w").write(s.replace(old, new))
 PY
@@ -51,16 +53,17 @@ fi
 OUT=$ROOT/gpurun_out/r04/traffic
 mkdir -p $OUT
 cd $ROOT
-for name in base one_block pair_u quad_u plane; do
+NAMES=${VARIANTS:-base one_block pair_u quad_u oct_u hex_u quad_v quad_uv plane}
+for name in $NAMES; do
   if [ $name = base ]; then unset OGL_BEAMFORMER_LIB; else export OGL_BEAMFORMER_LIB=$V/libogl_$name.so; fi
   timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_$name.json 2> $OUT/bench_$name.err
   timeout -k 10 400 python3 tools/pmc_das.py --config 4 --groups 7,9 --timeout 150 --out $OUT/pmc_$name > $OUT/pmc_$name.log 2>&1
   echo "$name done"
 done
-python3 - <<'PY'
-import json
-out = {"what": "BASELINE config 4, das_rca_staged_kernel<true,5,5,3,false>: kernel time and HBM-side traffic per launch under five ways of dealing the tiles to the XCDs (tools/traffic_ab.sh)", "variants": {}}
-for name in ("base", "one_block", "pair_u", "quad_u", "plane"):
+python3 - $NAMES <<'PY'
+import json, os, sys
+out = {"what": "BASELINE config 4, das_rca_staged_kernel<true,5,5,3,false>: kernel time and HBM-side traffic per launch under several ways of dealing the tiles to the XCDs (tools/traffic_ab.sh)", "variants": {}}
+for name in sys.argv[1:]:
     try:
         b = json.loads(open(f"gpurun_out/r04/traffic/bench_{name}.json").read().strip().splitlines()[-1])
         summary = json.load(open(f"gpurun_out/r04/traffic/pmc_{name}/summary.json"))
