@@ -478,7 +478,7 @@ def main():
                 "pairs_per_launch": pairs_local, "pairs_total": pairs_total,
                 "model": "G*taps*sizeof(sample) + V*(sizeof(voxel)+4 with CW); logical gather bytes, "
                          "compulsory HBM traffic is ~1e4x smaller (BASELINE.md section 4)",
-                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s, pairs_local, das_plan),
+                "binding": binding_resource(args.config, KERNEL_NAMES[das_path], gather_bytes, taps * sample_bytes, das_s, pairs_local, das_plan, cw=bool(bp.coherency_weighting)),
             },
         }
         if not args.no_cpu_baseline and n_gpus == 1:
@@ -533,7 +533,7 @@ def newest_profile(suffix):
     return names[-1]
 
 
-def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, terms, das_plan=None):
+def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, terms, das_plan=None, cw=True):
     """The physical resource that limits the DAS launch, priced against measured ceilings (tools/microbench.hip):
       * gather kernels -- the per-CU vector-memory (texture-address) path: a wave64 per-lane gather instruction of up
         to 16 bytes per lane takes 16 clocks per CU whatever its width (pattern "das_like", window resident in L1);
@@ -552,6 +552,12 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
             # hercules_probe: the expressions of das_hercules.hip's unchecked IQ loop, 4 pairs per iteration)
             cubic = bytes_per_gather >= 32
             rows = [v for v in micro["hercules_stream"] if ("cubic" in v["stream"]) == cubic]
+            # the stream that ran: prepared copy or raw taps (coarse grids), with or without the |s| sum of coherency weighting -- where the
+            # microbenchmark file has those rows (round 4 on); else the lighter prepared stream, and `stream_note` below says so
+            raw = bool(cubic and das_plan is not None and not das_plan.get("hercules_prepared_copy"))
+            exact = [v for v in rows if v.get("taps") == ("raw" if raw else "prepared") and v.get("coherency_weighting") == bool(cw)]
+            matched = bool(exact)
+            rows = exact or [v for v in rows if v.get("coherency_weighting", True)] or rows
             best = min(rows, key=lambda v: v["cycles_per_pair_per_simd_wall"])
             per_pair = best["cycles_per_pair_per_simd_wall"]
             peak = cus * 4 * 64 * best["clock_ghz"] * 1e9 / per_pair
@@ -562,7 +568,10 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 "frac": terms / das_s / peak, "probe_clock_ghz": best["clock_ghz"], "peak_cycles_per_pair_per_simd": per_pair,
                 "source": f"profiles/{micro_name} hercules_stream (tools/microbench.hip hercules_probe); achieved measured in this run",
             }
-            if cubic and das_plan is not None and not das_plan.get("hercules_prepared_copy"):
+            out["stream"] = best["stream"]
+            if matched:
+                out["stream_note"] = "the probe's stream is this frame's (same interpolation form and coherency-weighting setting); pairs that fail the f-number test execute and are not counted in `achieved`"
+            elif cubic and das_plan is not None and not das_plan.get("hercules_prepared_copy"):
                 out["stream_note"] = ("the probe's cubic stream evaluates the PREPARED segment polynomial (three packed fmas per pair); this frame is on a coarse grid, gathers the "
                                       "four raw taps with two gather instructions per pair and builds the Catmull-Rom cubic per pair (nine more packed operations), and a share "
                                       "of the executed pairs fails the f-number test: `frac` is measured against a lighter stream than the one that ran and counts passing pairs only")
@@ -664,6 +673,16 @@ def binding_resource(config, kernel, gather_bytes, bytes_per_gather, das_s, term
                 out["inner_loop_with_lds"]["frac_at_sustained_clock"] = out["inner_loop_with_lds"]["frac"] * out["inner_loop_with_lds"]["probe_clock_ghz"] / clock
         out["valu_source"] = (f"profiles/{bound_name}: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x SIMDs) of `{entry.get('command')}`, "
                               f"kernel sources {entry.get('kernel_source_sha16')}" + ("" if entry.get("kernel_source_sha16") == kernel_source_hash(kernel) else " (STALE: sources changed since)"))
+        per_cu = (entry.get("per_gather_instruction") or {}).get("elapsed_cycles_per_cu")
+        if per_cu and out.get("peak_bytes_per_clk_per_cu"):
+            # `frac` counts the bytes of terms that PASS the f-number test; a wave issues the gather when any of its lanes passes.  By
+            # executed wave64 gather instructions (the committed PMC pass of this frame: SQ_INSTS_VMEM_RD per CU over the launch's cycles)
+            # the same path is this busy -- the difference is lanes the aperture test masks inside active waves
+            ceiling = 64.0 * min(bytes_per_gather, 16) / out["peak_bytes_per_clk_per_cu"]
+            out["executed_gather_instructions"] = {"elapsed_clk_per_instruction_per_cu": per_cu, "ceiling_clk_per_instruction": ceiling, "frac": ceiling / per_cu,
+                                                   "lanes_passing_frac": out["frac"] * per_cu / ceiling if out.get("frac") else None}
+        if entry.get("wave_cycles"):
+            out["wave_cycles"] = entry["wave_cycles"]
         if kernel != "das_rca_staged_kernel" and entry["valu_busy_frac"] > out.get("frac", 0):
             out["resource_note"] = "VALU issue is the tighter bound for this kernel (valu_busy_frac)"
     except (OSError, KeyError, ValueError, StopIteration):

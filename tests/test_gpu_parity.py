@@ -220,7 +220,7 @@ def test_lds_staged_kernel_uniform_tables(name, shape, bflib, oracle, hooks, cap
     """64 x 16 tiles with x along the receive axis: the transmit delays and phasors of a wave are uniform and come from a global
     table (written per frame by a pre-pass) through scalar loads instead of from LDS.  Same arithmetic: the frame is
     BIT-IDENTICAL to the one the same tile shape gives with the tables in LDS (BEAMFORMER_HIP_STAGED_NOUNIFORM), and both
-    are the oracle's.  "6,4,48": the 48-sample window only this variant has (63 staged elements per wave and pass)."""
+    are the oracle's."""
     acq = cases.make(name)
     ref, pairs, flags = reference(oracle, acq)
     lib = bflib.library()

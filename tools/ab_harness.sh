@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of variant libraries on the harness frames: DAS ms per variant and kind
+# A/B of variant libraries (tools/build_variant.sh) on the harness frames: DAS ms per variant and kind.  usage: bash tools/ab_harness.sh TAG base VARIANT...
 OUT=gpurun_out/r04/ab_$1; shift
 mkdir -p $OUT
 for name in "$@"; do

@@ -28,7 +28,10 @@ def sample():
         m = re.search(r"-?\d+(\.\d+)?", str(v))
         key = k.lower()
         if any(w in key for w in ("sclk", "mclk", "fclk", "socclk", "power", "temperature", "use", "performance", "throttle")):
-            out[k] = float(m.group(0)) if m and "performance" not in key else str(v)
+            if m and "performance" not in key:
+                out[k] = float(m.group(0))
+            else:
+                out[k + " (text)"] = str(v)
     return out
 
 
@@ -48,16 +51,17 @@ def main():
         rows.append(s)
         time.sleep(args.period)
     stdout = child.stdout.read()
+    json.dump({"rows": rows}, open(args.out + ".raw", "w"))          # the samples first: whatever the summary below makes of them
     line = next((l for l in reversed(stdout.splitlines()) if l.startswith("{")), None)
     keys = sorted({k for r in rows for k in r if k != "t" and isinstance(r.get(k), float)})
     # the busy part of the run: samples whose GPU use is at its plateau (or all of them when rocm-smi reports no use figure)
     use_key = next((k for k in keys if "use" in k.lower()), None)
-    busy = [r for r in rows if use_key is None or r.get(use_key, 0) >= 90.0] or rows
+    busy = [r for r in rows if use_key is None or (isinstance(r.get(use_key), float) and r[use_key] >= 90.0)] or rows
     summary = {"command": " ".join(cmd), "samples": len(rows), "busy_samples": len(busy), "idle_before": idle,
-               "busy_mean": {k: sum(r[k] for r in busy if k in r) / max(1, sum(1 for r in busy if k in r)) for k in keys},
-               "busy_min": {k: min((r[k] for r in busy if k in r), default=None) for k in keys},
-               "busy_max": {k: max((r[k] for r in busy if k in r), default=None) for k in keys},
-               "perf_levels_seen": sorted({str(v) for r in rows for k, v in r.items() if "performance" in k.lower()}),
+               "busy_mean": {k: sum(r[k] for r in busy if isinstance(r.get(k), float)) / max(1, sum(1 for r in busy if isinstance(r.get(k), float))) for k in keys},
+               "busy_min": {k: min((r[k] for r in busy if isinstance(r.get(k), float)), default=None) for k in keys},
+               "busy_max": {k: max((r[k] for r in busy if isinstance(r.get(k), float)), default=None) for k in keys},
+               "text_fields_seen": sorted({f"{k}={v}" for r in rows for k, v in r.items() if isinstance(v, str)})[:40],
                "exit_code": child.returncode}
     if line:
         try:

@@ -1,7 +1,7 @@
 """What the kernels of the reference harness's frames wait for (round-3 verdict item 4): one table out of
   * tools/pmc_das.py --config harness:<kind> --groups 0,10,11 (SQ wait / issue / active wave cycles, TCP miss latency),
   * tools/timeline_probe.sh (per-wave s_memrealtime stamps: resident waves over time),
-  * the A/B runs of the walk / split variants (tools/_ab_harness.sh while they existed; DAS ms per variant, one box).
+  * the A/B runs of the walk / split variants (tools/build_variant.sh + tools/ab_harness.sh; DAS ms per variant, one box).
 python3 tools/harness_waits.py gpurun_out/r04 profiles/r04_harness_waits.json"""
 import json
 import os

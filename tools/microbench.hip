@@ -230,7 +230,9 @@ __device__ __forceinline__ f32x2 mb_apod_poly(f32x2 w)
 	r = r * w + mb_splat(0.9999996f);
 	return r;
 }
-template <bool CUBIC>
+/* MODE 0: linear, prepared {sample, difference}; 1: cubic, prepared segment polynomial; 2: cubic out of the four RAW taps (coarse grids: the reference
+ * harness's view plane) -- Catmull-Rom as the kernel's Horner cubic.  CW: with the |s| sum of coherency weighting. */
+template <int MODE, bool CW>
 __global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink, int iters)
 {
 	const float lane = (float)(threadIdx.x & 63);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink
 	for (int i = 0; i < iters; i++) {
 		asm volatile("" : "+s"(d2[0]), "+s"(d2[1]), "+s"(d2[2]), "+s"(d2[3]));
 		asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]));
-		if constexpr (CUBIC) asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+		if constexpr (MODE != 0) asm volatile("" : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
 		f32x2 index[2], apod[2], turns[2];
 		#pragma unroll
 		for (int k = 0; k < 2; k++) {
@@ -265,13 +267,19 @@ __global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink
 			const float ap  = (k & 1) ? apod[k >> 1].y : apod[k >> 1].x;
 			const float frac = __builtin_amdgcn_fractf(idx);
 			int ki; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ki) : "v"(idx));
-			const uint32_t off = (uint32_t)ki * (CUBIC ? 32u : 16u);
+			const uint32_t off = MODE == 2 ? ((uint32_t)ki - 1u) * 8u : (uint32_t)ki * (MODE == 1 ? 32u : 16u);
 			asm volatile("" :: "v"(off));
 			f32x2 sv;
-			if constexpr (CUBIC) {
+			if constexpr (MODE == 1) {
 				sv = f32x2{hi[k].z, hi[k].w} * frac + f32x2{hi[k].x, hi[k].y};
 				sv = sv * frac + f32x2{lo[k].z, lo[k].w};
 				sv = sv * frac + f32x2{lo[k].x, lo[k].y};
+			} else if constexpr (MODE == 2) {
+				const f32x2 s0 = {lo[k].x, lo[k].y}, s1 = {lo[k].z, lo[k].w}, s2 = {hi[k].x, hi[k].y}, s3 = {hi[k].z, hi[k].w};
+				const f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
+				const f32x2 c3 = (T1 + T2) - 2.0f * D;
+				const f32x2 c2 = (D - T1) - c3;
+				sv = s1 + frac * (T1 + frac * (c2 + frac * c3));
 			} else {
 				sv = f32x2{lo[k].x, lo[k].y} + frac * f32x2{lo[k].z, lo[k].w};
 			}
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink
 			const f32x2 cs = f32x2{__builtin_amdgcn_cosf(tr), __builtin_amdgcn_sinf(tr)} * ap;
 			acc1 += sv.x * cs;
 			acc2 += sv.y * cs;
-			mag = __builtin_fmaf(ap, __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x)), mag);
+			if constexpr (CW) mag = __builtin_fmaf(ap, __builtin_amdgcn_sqrtf(__builtin_fmaf(sv.y, sv.y, sv.x * sv.x)), mag);
 		}
 	}
 	uint64_t t1 = memtime(), r1 = memrealtime();
@@ -654,17 +662,17 @@ template <int PARTS> static void term_packed_case(const char *what)
 	}
 }
 
-template <bool CUBIC> static void hercules_case(const char *what, bool first)
+template <int MODE, bool CW> static void hercules_case(const char *what, bool first)
 {
 	const int iters = 20000;                           /* 80k pairs per wave */
 	for (int wps : {4, 7}) {                            /* the kernel holds 7 waves per SIMD (64-66 VGPRs) */
 		int waves_per_block = 4, blocks_per_cu = wps;
 		int blocks = n_cu * blocks_per_cu, waves = blocks * waves_per_block;
-		Result r = run([&] { hipLaunchKernelGGL(hercules_probe<CUBIC>, dim3(blocks), dim3(256), 0, 0, d_stamps, d_sink, iters); }, waves);
+		Result r = run([&] { hipLaunchKernelGGL((hercules_probe<MODE, CW>), dim3(blocks), dim3(256), 0, 0, d_stamps, d_sink, iters); }, waves);
 		double pairs = 4.0 * iters;
 		double wall_cycles = r.wall_ms * 1e-3 * r.clock_ghz * 1e9;
-		emit("%s{\"stream\":\"%s\",\"waves_per_simd\":%d,\"cycles_per_pair_per_simd_wall\":%.3f,\"cycles_per_pair_per_simd_stamps\":%.3f,"
-		     "\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", (first && wps == 4) ? "" : ",\n  ", what, wps, wall_cycles / (pairs * wps), r.cycles_per_wave / (pairs * wps), r.clock_ghz, r.wall_ms);
+		emit("%s{\"stream\":\"%s\",\"interpolation\":\"%s\",\"taps\":\"%s\",\"coherency_weighting\":%s,\"waves_per_simd\":%d,\"cycles_per_pair_per_simd_wall\":%.3f,\"cycles_per_pair_per_simd_stamps\":%.3f,"
+		     "\"clock_ghz\":%.3f,\"wall_ms\":%.3f}", (first && wps == 4) ? "" : ",\n  ", what, MODE == 0 ? "linear" : "cubic", MODE == 2 ? "raw" : "prepared", CW ? "true" : "false", wps, wall_cycles / (pairs * wps), r.cycles_per_wave / (pairs * wps), r.clock_ghz, r.wall_ms);
 	}
 }
 
@@ -814,8 +822,11 @@ int main(int argc, char **argv)
 	emit("],\n");
 
 	emit(" \"hercules_stream\":[\n  ");
-	hercules_case<false>("das_hercules inner loop (IQ, linear interpolation of the prepared {sample, difference} pairs, coherency weighting, per-lane phase reduction): VALU only", true);
-	hercules_case<true>("das_hercules inner loop (IQ, cubic: three-step Horner chain of the prepared segment polynomial, coherency weighting): VALU only", false);
+	hercules_case<0, true>("das_hercules inner loop (IQ, linear interpolation of the prepared {sample, difference} pairs, coherency weighting, per-lane phase reduction): VALU only", true);
+	hercules_case<1, true>("das_hercules inner loop (IQ, cubic: three-step Horner chain of the prepared segment polynomial, coherency weighting): VALU only", false);
+	hercules_case<2, true>("das_hercules inner loop (IQ, cubic out of the four raw taps: Catmull-Rom as a Horner cubic per pair, coherency weighting): VALU only", false);
+	hercules_case<2, false>("das_hercules inner loop (IQ, cubic out of the four raw taps, no coherency weighting: the reference harness's frame): VALU only", false);
+	hercules_case<0, false>("das_hercules inner loop (IQ, linear, prepared pairs, no coherency weighting): VALU only", false);
 	emit("],\n");
 
 	bool first = true;

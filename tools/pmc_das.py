@@ -83,7 +83,7 @@ def main():
         bench += ["--planes", str(args.planes)]
     pick = [int(v) for v in args.groups.split(",") if v] or range(len(GROUPS))
     env = dict(os.environ, TMPDIR="/tmp")
-    counters, dispatches, kernel_names, failed, das_plan = {}, None, set(), [], None
+    counters, dispatches, kernel_names, failed, das_plan, clocks = {}, None, set(), [], None, []
     for gi in pick:
         group = GROUPS[gi]
         d = os.path.join(out, f"g{gi}")
@@ -118,12 +118,18 @@ def main():
                     continue
                 counters[key] = counters.get(key, 0.0) + float(row["Counter_Value"])
                 seen.setdefault(key, set()).add(row["Dispatch_Id"])
+                if key == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):
+                    # shader clock the kernel ran at: busy cycles (summed over the 8 XCDs) over the dispatch's own duration (ns)
+                    ns = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                    if ns > 0:
+                        clocks.append(float(row["Counter_Value"]) / 8.0 / ns)
         if seen:
             dispatches = max(len(v) for v in seen.values())
     summary = {
         "command": " ".join(bench).replace(ROOT + "/", ""), "kernel_filter": args.kernel, "kernels": sorted(kernel_names),
         "dispatches_summed": dispatches, "counters": counters, "failed_groups": failed, "das_plan": das_plan,
         "kernel_source_sha16": kernel_source_hash(),
+        "shader_clock_ghz_per_dispatch": [round(v, 4) for v in clocks],        # (under the profiler: counter collection serialises dispatches)
         "notes": "one rocprofv3 --pmc pass per counter group; values summed over the kernel's dispatches (bench.py runs the "
                  "geometry-only count frame on a separate kernel, excluded, plus one timed frame). SQ_*CYCLES and SQ_ACTIVE/WAIT "
                  "counters are in quad-cycles summed over waves or CUs; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-reports "

@@ -37,8 +37,7 @@ for scale in (float(v) for v in args.scales.split(",")):
     dev = torch.from_numpy(np.ascontiguousarray(acq.rf).view(np.uint8).reshape(-1)).cuda()
     row = {"x_extent_scale": scale, "planes": args.planes, "transmits": A}
     frames = {}
-    # (the third leg: the 48-sample window config 4 itself needs, on a grid that does not need it -- what the longer window costs)
-    for name, env, shape in (("tables_in_lds", "1", None), ("uniform", None, None), ("uniform_48_sample_window", None, "6,4,48")):
+    for name, env, shape in (("tables_in_lds", "1", None), ("uniform", None, None)):
         lib.set_hook("STAGED_NOUNIFORM", env or None)
         lib.set_hook("STAGED_SHAPE", shape or None)
         t = P.HipFrameTimings()

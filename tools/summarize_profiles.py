@@ -89,7 +89,7 @@ def main():
                     "valu_instructions": c.get("SQ_INSTS_VALU", 0) / g, "transcendentals": c.get("SQ_INSTS_VALU_TRANS_F32", 0) / g,
                     "salu_instructions": c.get("SQ_INSTS_SALU", 0) / g, "lds_instructions": c.get("SQ_INSTS_LDS", 0) / g,
                     "valu_busy_cycles_per_simd": c.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / g,
-                    "elapsed_cycles_per_simd": cycles * SIMDS / g}
+                    "elapsed_cycles_per_simd": cycles * SIMDS / g, "elapsed_cycles_per_cu": cycles * 256 / g}
             if "SQ_WAVE_CYCLES" in c:
                 e["mean_resident_waves_per_cu"] = c["SQ_WAVE_CYCLES"] * 4.0 / (cycles * 256)
             if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
