@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	uint32_t zl, tx_, ty_;
 	if (q.depth_major == 3u) {                /* view planes in XCD-balanced bands (bf_kernels.h) */
 		zl = 0;
-		if (!bf_plane_walk(blockIdx.x, q.tiles[0], q.tiles[1], q.band_rows, tx_, ty_)) return;
+		if (!bf_plane_walk<true>(blockIdx.x, q.tiles[0], q.tiles[1], q.band_rows, tx_, ty_)) return;
 	} else if (q.depth_major == 2u) {                /* view planes: rows (= depth) fastest, an XCD's run is a lateral column (das.hip) */
 		ty_ = tile % q.tiles[1];
 		tx_ = (tile / q.tiles[1]) % q.tiles[0];

@@ -36,7 +36,7 @@ if os.path.exists(p):
     out["timeline"] = {k: {kk: v[kk] for kk in ("kernel_span_ms", "mean_resident_waves_per_cu", "wave_duration_ms", "xcd_runs_dry_at_ms", "time_with_fewer_than_half_of_peak_resident_frac")}
                        | {"resident_waves_at_41_points": v["resident_waves_at_200_points"][::5]} for k, v in t["frames"].items()}
 ab = {}
-for d in ("ab_tail", "ab_w64"):
+for d in ("ab_tail", "ab_w64", "ab_tile", "ab_tile_b", "ab_lpt2", "ab_lpt2b"):
     dd = os.path.join(src, d)
     if not os.path.isdir(dd):
         continue
@@ -44,11 +44,28 @@ for d in ("ab_tail", "ab_w64"):
         if f.endswith(".json"):
             name, kind = f[:-5].rsplit("_", 1)
             try:
-                ab.setdefault(name, {})[kind] = json.loads(open(os.path.join(dd, f)).read().strip().splitlines()[-1])["config"]["stage_ms"]["DAS"]
+                ab.setdefault(name if d in ("ab_tail", "ab_w64") else f"{name} ({d[3:]} run)", {})[kind] = json.loads(open(os.path.join(dd, f)).read().strip().splitlines()[-1])["config"]["stage_ms"]["DAS"]
             except Exception:
                 pass
 out["variants_DAS_ms_one_box_each_row_its_own_run"] = ab
+out["l1_access_rate_is_not_the_limit"] = {
+    "why_asked": "the factored kernels show 0.97-0.98 TCP_TOTAL_CACHE_ACCESSES per clock per CU: a one-per-clock unit at its limit?",
+    "probe": "rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE -- tools/bin/microbench, gather_probe<16 bytes, pattern>, window resident in L1 (gpurun_out/r04/clock/mb_pmc.txt)",
+    "contiguous": {"accesses_per_instruction": 22.0, "clk_per_instruction_per_cu": 16.4, "accesses_per_clk_per_cu": 1.35},
+    "das_like (0..8 B between neighbouring lanes)": {"accesses_per_instruction": 18.9, "clk_per_instruction_per_cu": 16.4, "accesses_per_clk_per_cu": 1.15},
+    "random lines": {"accesses_per_instruction": 64.8, "clk_per_instruction_per_cu": 33.0, "accesses_per_clk_per_cu": 1.95},
+    "reading": "the L1 takes up to ~2 accesses per clock; an instruction costs max(16.3 clk, accesses / 2).  At 18-19 accesses per instruction the harness frames pay the 16.3 clk of the address path, not the L1's rate."}
+out["reading"] = ("TPW / FORCES (das_factored_kernel): two pipes share the time -- the vector-memory address path is busy 0.87 of it counted in EXECUTED wave64 gather instructions "
+                  "(16.3 clk each; 0.77 counted in bytes of terms that pass the f-number test: 12 % of the lanes of executing waves are masked by the aperture test) and the VALU 0.77.  A wave is "
+                  "parked on s_waitcnt 41-42 % of its life, issue-stalled 27 %, has an instruction in flight 30-32 %; L1 hit 0.89-0.93, an L1 miss comes back in 216-255 clk (L2 hits), TCP pending stalls 6 %.  "
+                  "The timeline shows where the rest goes: a wave lives 7.5 ms of a 17 ms launch (two generations per slot), so the chip drains for the last 30 % of the launch "
+                  "(resident waves fall 4096 -> 0 roughly linearly) -- but the variants that shorten the tail (deepest bands first; the channel loop split over 2 or 4 waves; one-wave blocks) "
+                  "are no faster (TPW 16.0 -> 16.3-17.5 ms): with fewer waves resident each one runs faster, the pipes are what is shared.  HERCULES: VALU-bound (issue-stalled 45 %, "
+                  "15.6 VALU instructions per gather).  Floor of this formulation on this grid: max(address path, VALU) with both near 0.8-0.87 -- a few per cent from better overlap, "
+                  "not a factor; a different formulation (tile-wide staging) was measured slower on 0.23 mm pixels in round 3 (docs/NOTEBOOK.md 3.1c).")
 out["variants"] = {"base": "as shipped", "lpt": "bands of the plane walk deepest first", "lpt_split2 / lpt_split4 / split4": "channel loop split over 2 / 4 waves of a block (4 x the waves, a quarter of the life each)",
-                   "lpt_w64": "one-wave blocks (tile 64 x 1) instead of four-wave blocks (256 x 1)"}
+                   "lpt_w64": "one-wave blocks (tile 64 x 1) instead of four-wave blocks (256 x 1)",
+                   "shallow_first (lpt2 / lpt2b runs)": "after das_hercules.hip took the deepest-first order: the HERCULES kernel with the old order (base = what ships)",
+                   "tile64x4 / tile128x2": "blocks of 64 x 4 / 128 x 2 voxels (lateral x depth) instead of 256 x 1 (its own box: compare with the `base (tile run)` rows)"}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
