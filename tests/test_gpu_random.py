@@ -242,6 +242,81 @@ def test_random_draws_reach_the_block_staged_kernel():
     assert sum(1 for _, s, g in TILE_DRAWS if s > 0) >= 12 and sum(1 for _, s, g in TILE_DRAWS if g > 0) >= 1, TILE_DRAWS
 
 
+PLANE_DRAWS = []           # (seed, das path, row-end planes) of the draws below
+
+
+def draw_plane(seed):
+    """a VIEW PLANE through row-column / HERCULES / FORCES data, as the reference's harness beamforms one out of every dataset
+    (tests/throughput.c:443-446; math.c:844-885): one voxel along z, depth on voxel y, 56-160 voxels wide so that the aligned-grid HERCULES
+    kernel and the factored kernel's band walk take it; a record that ends inside the image in about half the draws (terms at the ends
+    of the RF rows: the kernels' row-end instantiations), all three interpolations, with and without coherency weighting"""
+    rng = np.random.default_rng(4000 + seed)
+    kind = str(rng.choice(["tpw", "tpw_swapped", "vls", "hercules", "hercules", "forces"]))
+    plane = "xz" if kind == "forces" else str(rng.choice(["xz", "xz", "yz"]))
+    C = int(rng.choice([16, 32]))
+    A = int(rng.choice([8, 16]))
+    samples = int(rng.choice([512, 768, 1024]))
+    k = samples / 4096.0
+    nx, ny = int(rng.choice([56, 64, 96, 128, 160])), int(rng.integers(20, 72))
+    reach = float(rng.uniform(0.75, 1.15))                      # > ~0.95: the deepest rows lie beyond the record
+    width = float(rng.uniform(0.5, 1.1))
+    lo = (-60e-3 * k * width, -60e-3 * k * width, 10e-3 * k)
+    hi = (60e-3 * k * width, 60e-3 * k * width, 165e-3 * k * reach)
+    fs, fd = 20e6, 5e6
+    pitch = 0.25e-3 * max(k, 64.0 / C * k)
+    interp = [I.Linear, I.Cubic, I.Cubic, I.Nearest][int(rng.integers(0, 4))]
+    cw = bool(rng.integers(0, 2))
+    f_number = float(rng.choice([0.5, 0.5, 1.0, 1.5]))
+    canonical = (S.Demodulate, S.Decode, S.DAS)
+    points = (nx, ny, 1)
+    if kind in ("tpw", "tpw_swapped", "vls"):
+        depths = np.full(A, -40e-3 * k * float(rng.uniform(0.5, 2.0))) if kind == "vls" else None
+        return cfg.rca(f"plane{seed}", C, A, samples, points, lo, hi, seed=seed, interp=interp, cw=cw, f_number=f_number, pitch=pitch, fs=fs, fd=fd,
+                       orientation=0x21 if kind == "tpw_swapped" else 0x12, angles=np.linspace(-float(rng.uniform(4, 18)), float(rng.uniform(4, 18)), A),
+                       depths=depths, stages=canonical, plane=plane, kind=K.RCA_VLS if kind == "vls" else K.RCA_TPW)
+    if kind == "hercules":
+        return cfg.hercules(f"plane{seed}", C, A, samples, points, lo, hi, seed=seed, interp=interp, cw=cw, f_number=f_number, pitch=pitch, fs=fs, fd=fd,
+                            stages=canonical, plane=plane)
+    return cfg.forces(f"plane{seed}", C, A, samples, points, lo, hi, seed=seed, interp=interp, cw=cw, f_number=f_number, pitch=pitch, fs=fs, fd=fd,
+                      stages=canonical)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_view_plane(seed, bflib, oracle):
+    """40 random view planes against the oracle: on the automatic path, on the kernel a full-size plane of the kind gets (no channel split;
+    HERCULES: the aligned-grid kernel asked for), and on the general kernel"""
+    acq = draw_plane(seed)
+    ref, pairs, flags = reference(oracle, acq)
+    ok = ~np.isnan(ref)
+    if not ok.any() or np.max(np.abs(ref[ok])) == 0:
+        pytest.skip("the draw produced an empty image")
+    lib = bflib.library()
+    # automatic; without the channel split of small frames (0x10: the kernel a full-size plane gets); HERCULES: the aligned-grid kernel asked for
+    # (6: small frames go to the general kernel's channel split by themselves); the general kernel
+    modes = [0, 0x10] + ([6] if int(acq.bp.acquisition_kind) in (int(K.HERCULES), int(K.UHERCULES)) else []) + [1]
+    seen = set()
+    for mode in modes:
+        lib.beamformer_hip_set_das_path(mode)
+        try:
+            gpu = bflib.beamform(acq.bp, acq.rf, acq.filters)
+        finally:
+            lib.beamformer_hip_set_das_path(0)
+        t = last_timings(bflib)
+        if (int(t.das_path), mode & 0x10) in seen and mode != 6:
+            continue
+        seen.add((int(t.das_path), mode & 0x10))
+        PLANE_DRAWS.append((seed, int(t.das_path), int(t.das_row_end_planes)))
+        compare(gpu, ref, acq, flags)
+
+
+def test_random_view_planes_reach_the_plane_kernels():
+    """the draws above are worth their name only if they run the kernels they aim at"""
+    if len(PLANE_DRAWS) < 30:
+        pytest.skip("needs the draws of this module in the same session")
+    paths = {p for _, p, _ in PLANE_DRAWS}
+    assert int(P.DasPath.Hercules) in paths and int(P.DasPath.Factored) in paths, sorted(PLANE_DRAWS)
+
+
 # ---- row ends (csrc/das_exact.h).  sample_rf's range test is a step: round 3's fast kernels formed the index as a rounded receive term plus
 # a rounded transmit term and kept or dropped a term within an ulp of the end of an RF row differently from the oracle -- one whole tap of
 # difference at a voxel.  These are the draws of round 3's out-of-sample fuzz (tools/auto_fuzz.py 72 600, tools/tile_fuzz.py) that failed

@@ -4,6 +4,8 @@ for a voxel over it the double-precision truth -- never another kernel of the li
   general    draws on the automatic path
   separable  draws on the automatic path, and where the LDS-staged kernel ran, again with every staged term range-checked
   tile       draws with the block-staged factored kernel asked for (flags 0x10 | 0x100)
+  plane      view planes as the reference's harness beamforms them, without the small-frame channel split (0x10: the kernels a full-size plane gets)
+  plane_hercules   the HERCULES-family draws of `plane` with the aligned-grid kernel asked for (6)
 Writes a JSON summary (draws, failures, kernels taken, planes the row-end rule re-routed).
 PYTHONPATH=. python tools/auto_fuzz.py 72 1200 [--json gpurun_out/r04/fuzz.json] [--generators general,separable,tile]"""
 import argparse
@@ -22,10 +24,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("first", type=int)
 ap.add_argument("last", type=int)
 ap.add_argument("--json", default="")
-ap.add_argument("--generators", default="general,separable,tile")
+ap.add_argument("--generators", default="general,separable,tile,plane,plane_hercules")
 args = ap.parse_args()
 L = bflib.library()
-GENERATORS = {"general": (R.draw, 0), "separable": (R.draw_separable, 0), "tile": (R.draw_tile, 0x110)}
+GENERATORS = {"general": (R.draw, 0), "separable": (R.draw_separable, 0), "tile": (R.draw_tile, 0x110), "plane": (R.draw_plane, 0x10), "plane_hercules": (R.draw_plane, 6)}
 summary = {"seeds": [args.first, args.last], "comparison": "tests/test_gpu_parity.py compare(): tolerance of the pipeline, second bar against the oracle's double twin",
            "generators": {}, "failures": []}
 total = failed_total = 0
@@ -36,6 +38,8 @@ for name in args.generators.split(","):
     for seed in range(args.first, args.last):
         try:
             acq = gen(seed)
+            if name == "plane_hercules" and int(acq.bp.acquisition_kind) not in (int(R.K.HERCULES), int(R.K.UHERCULES)):
+                continue
             ref, pairs, flags = reference(oracle, acq)
         except Exception:                               # a draw the generator or the oracle's planner cannot build
             continue
