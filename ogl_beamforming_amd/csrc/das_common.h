@@ -118,6 +118,26 @@ __device__ __forceinline__ T gather(const char *rf, uint32_t byte_offset)
 	return *reinterpret_cast<const T *>(rf + byte_offset);
 }
 
+/* the same load `BYTES` further on: the constant rides in the instruction's offset field (base + zero-extended 32-bit offset + constant),
+ * where `byte_offset + BYTES` in 32 bits would be a VALU addition the compiler may not fold (it can wrap) */
+template <typename T, int BYTES>
+__device__ __forceinline__ T gather_at(const char *rf, uint32_t byte_offset)
+{
+	return *reinterpret_cast<const T *>(rf + (uint64_t)byte_offset + BYTES);
+}
+
+/* Catmull-Rom weights of the taps s0..s3 at t in [0, 1) between s1 and s2 (das.glsl:67-97 multiplied out):
+ *   w0 = -t u^2 / 2,  w3 = -t^2 u / 2,  w1 = u + t u (1 - 3t/2),  w2 = t + t u (3t/2 - 1/2),   u = 1 - t
+ * (w0 + w1 + w2 + w3 = 1; t = 1/2: -1/16, 9/16, 9/16, -1/16).  Nine scalar operations. */
+__device__ __forceinline__ void bf_catmull_rom(float t, float &w0, float &w1, float &w2, float &w3)
+{
+	const float u = 1.0f - t, tu = t * u, a = -0.5f * tu;
+	w0 = a * u;
+	w3 = a * t;
+	w1 = __builtin_fmaf(tu, __builtin_fmaf(-1.5f, t, 1.0f), u);
+	w2 = __builtin_fmaf(tu, __builtin_fmaf(1.5f, t, -0.5f), t);
+}
+
 template <typename M>      /* const float * in any address space */
 __device__ __forceinline__ void m4_point(M m, float x, float y, float z, float &ox, float &oy, float &oz)
 {

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			#pragma unroll
 			for (int k = 0; k < CH; k++) { acc1[k] = f32x2{0.f, 0.f}; acc2[k] = f32x2{0.f, 0.f}; }
 
+			/* (the chunk's first channel is the same in every lane -- the channel split is per wave -- but derives from the thread id: told
+			 * to the compiler, the row offsets of the loop are scalars and a tap's byte offset is one v_lshl_add_u32) */
+			const uint32_t chunk_row = (uint32_t)__builtin_amdgcn_readfirstlane(c0) * (uint32_t)A * (uint32_t)S * ES;
 			for (int a = first_transmit; a < A; a++) {
 				float t_index = transmit_index(a);
 				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 					tc = hw_cos_turns(turns); ts = hw_sin_turns(turns);
 				}
 
-				const uint32_t row0 = ((uint32_t)c0 * (uint32_t)A + (uint32_t)a) * (uint32_t)S * ES;
+				const uint32_t row0 = chunk_row + (uint32_t)a * (uint32_t)S * ES;
 				const uint32_t row_step = (uint32_t)A * (uint32_t)S * ES;
 				if constexpr (PACKED) {
 					/* Written out so that every step is one instruction: index = T + R;
@@ -324,11 +327,14 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 						float index = t_index + R[k].index;
 						frac[k] = hw_fract(index);
 						if constexpr (INTERP == BF_INTERP_LINEAR) {
-							uint32_t ki = (uint32_t)cvt_floor_i32(index);                 /* valid: 0 <= index < S-1 */
-							off[k] = ki < (uint32_t)(S - 1) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+							uint32_t ki = (uint32_t)cvt_floor_i32(index), tap;            /* valid: 0 <= index < S-1 */
+							asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(tap) : "v"(ki), "s"(row0 + (uint32_t)k * row_step));
+							off[k] = ki < (uint32_t)(S - 1) ? tap : p.zero_offset;
 						} else {
-							uint32_t ki = (uint32_t)(cvt_floor_i32(index) - 1);           /* valid: 1 <= index < S-2 */
-							off[k] = ki < (uint32_t)(S - 3) ? row0 + (uint32_t)k * row_step + (ki << 3) : p.zero_offset;
+							uint32_t kf = (uint32_t)cvt_floor_i32(index);                 /* valid: 1 <= index < S-2 */
+							uint32_t tap;                                                 /* (one instruction; the compiler re-associates the C expression into two) */
+							asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(tap) : "v"(kf), "s"(row0 + (uint32_t)k * row_step - ES));
+							off[k] = kf - 1u < (uint32_t)(S - 3) ? tap : p.zero_offset;
 						}
 					}
 					if constexpr (INTERP == BF_INTERP_LINEAR) {
@@ -347,19 +353,17 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 					} else {
 						f32x4 d0[CH], d1[CH];
 						#pragma unroll
-						for (int k = 0; k < CH; k++) { d0[k] = gather<f32x4_a8>(rf, off[k]); d1[k] = gather<f32x4_a8>(rf, off[k] + 16); }
+						for (int k = 0; k < CH; k++) { d0[k] = gather<f32x4_a8>(rf, off[k]); d1[k] = gather_at<f32x4_a8, 16>(rf, off[k]); }
 						BF_ALL_GATHERS_ISSUED();
 						#pragma unroll
 						for (int k = 0; k < CH; k++) {
-							/* Catmull-Rom Hermite (das.glsl:67-97) as a cubic in t by Horner:
-							 * p = s1 + t (T1 + t (c2 + t c3)),  T1 = (s2-s0)/2, T2 = (s3-s1)/2,
-							 * c3 = T1 + T2 - 2 (s2-s1),  c2 = (s2-s1) - T1 - c3 */
+							/* Catmull-Rom Hermite (das.glsl:67-97) as four weights of the taps (bf_catmull_rom, das_common.h: nine scalar
+							 * operations) and one packed multiply + three packed fmas -- 38 clk of issue against the 56 of the Horner form
+							 * in the samples (four subtractions + eleven packed operations) this loop had through round 3 */
 							f32x2 s0 = {d0[k].x, d0[k].y}, s1 = {d0[k].z, d0[k].w}, s2 = {d1[k].x, d1[k].y}, s3 = {d1[k].z, d1[k].w};
-							f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
-							f32x2 c3 = (T1 + T2) - 2.0f * D;
-							f32x2 c2 = (D - T1) - c3;
-							float t  = frac[k];
-							f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
+							float w0, w1, w2, w3;
+							bf_catmull_rom(frac[k], w0, w1, w2, w3);
+							f32x2 sv = w0 * s0 + w1 * s1 + w2 * s2 + w3 * s3;
 							acc1[k] += sv.x * cs;
 							acc2[k] += sv.y * cs;
 							if constexpr (CW) { f32x2 sq = sv * sv; part_abs[k] += hw_sqrt(sq.x + sq.y); }

@@ -349,11 +349,11 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 				if constexpr (POLY) {
 					const char *rowp = CHECK ? rf : rf + (row0 + (uint32_t)(n + k) * inner_stride);
 					d[k].a = gather<f32x4>(rowp, off[k]);
-					d[k].b = gather<f32x4>(rowp, off[k] + 16u);
+					d[k].b = gather_at<f32x4, 16>(rowp, off[k]);
 				} else if constexpr (RAWC) {
 					const char *rowp = CHECK ? rf : rf + (row0 + (uint32_t)(n + k) * inner_stride);
 					d[k].a = gather<f32x4_a8>(rowp, off[k]);
-					d[k].b = gather<f32x4_a8>(rowp, off[k] + 16u);
+					d[k].b = gather_at<f32x4_a8, 16>(rowp, off[k]);
 				} else if constexpr (!CHECK && INTERP == BF_INTERP_LINEAR) {
 					/* the row (wave uniform) rides in the load's scalar base and the lane offset is one full-rate shift: a
 					 * three-operand v_lshl_add_u32 is a half-rate instruction (tools/microbench.hip) */
@@ -372,13 +372,12 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 					sv = sv * t + f32x2{d[k].a.z, d[k].a.w};
 					sv = sv * t + f32x2{d[k].a.x, d[k].a.y};
 				} else if constexpr (RAWC) {
-					/* p = s1 + t (T1 + t (c2 + t c3)),  T1 = (s2 - s0) / 2, T2 = (s3 - s1) / 2, c3 = T1 + T2 - 2 (s2 - s1), c2 = (s2 - s1) - T1 - c3 */
+					/* Catmull-Rom as four weights of the taps (bf_catmull_rom, das_common.h: nine scalar operations + one packed multiply and three
+					 * packed fmas; the Horner form in the samples this had through round 3 was twelve packed operations) */
 					const f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}, s2 = {d[k].b.x, d[k].b.y}, s3 = {d[k].b.z, d[k].b.w};
-					const f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
-					const f32x2 c3 = (T1 + T2) - 2.0f * D;
-					const f32x2 c2 = (D - T1) - c3;
-					const float t = frac[k];
-					sv = s1 + t * (T1 + t * (c2 + t * c3));
+					float w0, w1, w2, w3;
+					bf_catmull_rom(frac[k], w0, w1, w2, w3);
+					sv = w0 * s0 + w1 * s1 + w2 * s2 + w3 * s3;
 				} else if constexpr (INTERP == BF_INTERP_LINEAR) {
 					if constexpr (PD)        { f32x2 s0 = {d[k].a.x, d[k].a.y}, ds = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * ds; }
 					else if constexpr (CPLX) { f32x2 s0 = {d[k].a.x, d[k].a.y}, s1 = {d[k].a.z, d[k].a.w}; sv = s0 + frac[k] * (s1 - s0); }

@@ -501,16 +501,14 @@ __global__ __launch_bounds__(1024, 4) void das_tile_kernel(const BfDasArgs p)
 					}
 					f32x4 d0[4], d1[4];
 					#pragma unroll
-					for (int j = 0; j < 4; j++) { d0[j] = gather<f32x4_a8>(rf, off[j]); d1[j] = gather<f32x4_a8>(rf, off[j] + 16); }
+					for (int j = 0; j < 4; j++) { d0[j] = gather<f32x4_a8>(rf, off[j]); d1[j] = gather_at<f32x4_a8, 16>(rf, off[j]); }
 					__builtin_amdgcn_sched_barrier(0);                            /* all eight issued before the first is consumed (das_factored.hip) */
 					#pragma unroll
 					for (int j = 0; j < 4; j++) {
 						f32x2 s0 = {d0[j].x, d0[j].y}, s1 = {d0[j].z, d0[j].w}, s2 = {d1[j].x, d1[j].y}, s3 = {d1[j].z, d1[j].w};
-						f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
-						f32x2 c3 = (T1 + T2) - 2.0f * D;
-						f32x2 c2 = (D - T1) - c3;
-						float t  = frac[j];
-						f32x2 sv = s1 + t * (T1 + t * (c2 + t * c3));
+						float w0, w1, w2, w3;
+						bf_catmull_rom(frac[j], w0, w1, w2, w3);                     /* (das_factored.hip: tap weights, not a Horner cubic in the samples) */
+						f32x2 sv = w0 * s0 + w1 * s1 + w2 * s2 + w3 * s3;
 						acc[j] += sv.x * cs;
 						acc[j] += sv.y * csr;
 						if constexpr (CW) { f32x2 sq = sv * sv; part_abs[j] += hw_sqrt(sq.x + sq.y); }

@@ -231,7 +231,7 @@ __device__ __forceinline__ f32x2 mb_apod_poly(f32x2 w)
 	return r;
 }
 /* MODE 0: linear, prepared {sample, difference}; 1: cubic, prepared segment polynomial; 2: cubic out of the four RAW taps (coarse grids: the reference
- * harness's view plane) -- Catmull-Rom as the kernel's Horner cubic.  CW: with the |s| sum of coherency weighting. */
+ * harness's view plane) -- Catmull-Rom as the kernel's four tap weights.  CW: with the |s| sum of coherency weighting. */
 template <int MODE, bool CW>
 __global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink, int iters)
 {
@@ -276,10 +276,11 @@ __global__ __launch_bounds__(256) void hercules_probe(Stamp *stamps, float *sink
 				sv = sv * frac + f32x2{lo[k].x, lo[k].y};
 			} else if constexpr (MODE == 2) {
 				const f32x2 s0 = {lo[k].x, lo[k].y}, s1 = {lo[k].z, lo[k].w}, s2 = {hi[k].x, hi[k].y}, s3 = {hi[k].z, hi[k].w};
-				const f32x2 T1 = 0.5f * (s2 - s0), T2 = 0.5f * (s3 - s1), D = s2 - s1;
-				const f32x2 c3 = (T1 + T2) - 2.0f * D;
-				const f32x2 c2 = (D - T1) - c3;
-				sv = s1 + frac * (T1 + frac * (c2 + frac * c3));
+				const float u = 1.0f - frac, tu = frac * u, a_ = -0.5f * tu;          /* bf_catmull_rom (das_common.h) */
+				const float w0 = a_ * u, w3 = a_ * frac;
+				const float w1 = __builtin_fmaf(tu, __builtin_fmaf(-1.5f, frac, 1.0f), u);
+				const float w2 = __builtin_fmaf(tu, __builtin_fmaf(1.5f, frac, -0.5f), frac);
+				sv = w0 * s0 + w1 * s1 + w2 * s2 + w3 * s3;
 			} else {
 				sv = f32x2{lo[k].x, lo[k].y} + frac * f32x2{lo[k].z, lo[k].w};
 			}
@@ -824,7 +825,7 @@ int main(int argc, char **argv)
 	emit(" \"hercules_stream\":[\n  ");
 	hercules_case<0, true>("das_hercules inner loop (IQ, linear interpolation of the prepared {sample, difference} pairs, coherency weighting, per-lane phase reduction): VALU only", true);
 	hercules_case<1, true>("das_hercules inner loop (IQ, cubic: three-step Horner chain of the prepared segment polynomial, coherency weighting): VALU only", false);
-	hercules_case<2, true>("das_hercules inner loop (IQ, cubic out of the four raw taps: Catmull-Rom as a Horner cubic per pair, coherency weighting): VALU only", false);
+	hercules_case<2, true>("das_hercules inner loop (IQ, cubic out of the four raw taps: Catmull-Rom tap weights per pair, coherency weighting): VALU only", false);
 	hercules_case<2, false>("das_hercules inner loop (IQ, cubic out of the four raw taps, no coherency weighting: the reference harness's frame): VALU only", false);
 	hercules_case<0, false>("das_hercules inner loop (IQ, linear, prepared pairs, no coherency weighting): VALU only", false);
 	emit("],\n");
