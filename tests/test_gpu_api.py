@@ -240,6 +240,7 @@ def test_frame_graphs_replay_bit_identical_frames(name, bflib):
     instantiated graph updated in place, bit-identical to direct launches; a parameter change in between
     (replan) is picked up; the stats table still reports the frame."""
     L = bflib.library()
+    L.beamformer_set_global_timeout(0xFFFFFFFF)          # (the library starts with the reference's 0 = try once: whichever test ran before)
     acq = cases.make(name)
     rng = np.random.default_rng(5)
     rfs = [np.ascontiguousarray(acq.rf)]
