@@ -104,7 +104,8 @@ typedef struct {
 	uint32_t inner_count, outer_count;
 	uint32_t inner_coord;     /* transducer coordinate of the inner axis: 0 = x, 1 = y */
 	uint32_t inner_is_transmit;   /* inner loop walks decoded transmit elements (else receive channels) */
-	uint32_t tiles[3];        /* 64-voxel x segments, groups of 4 output rows, z planes of the shard */
+	uint32_t tiles[3];        /* 64-voxel x segments, groups of `rows` output rows, z planes of the shard */
+	uint32_t rows;            /* output rows (= waves) of a block: 4, 8 or 16; they walk the outer elements in step (a barrier per element) */
 	uint32_t depth_major;     /* tile walk: 1 = z fastest, 2 = y fastest (view planes), 3 = balanced bands (bf_plane_walk), 0 = x, y, z */
 	uint32_t band_rows;       /* depth_major == 3: tile rows per band */
 	uint32_t zero_offset;     /* byte offset (from BfDasArgs.rf) of >= 32 zero bytes behind the DAS input */

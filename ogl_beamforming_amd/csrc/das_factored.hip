@@ -117,12 +117,18 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 	uint32_t x = (bx << p.tile_shift[0]) + lx;
 	uint32_t y = (by << p.tile_shift[1]) + ly;
 	uint32_t zl = (bz << p.tile_shift[2]) + lz;
-	bool inside = x < p.size[0] && y < p.size[1] && zl < p.z_count;
+	const bool inside = x < p.size[0] && y < p.size[1] && zl < p.z_count;
+	/* every lane takes part in the loops (lanes beyond the grid repeat its last voxel and store nothing), and a wave wholly beyond the grid
+	 * skips the work but not the barriers: the waves of a block walk the channel chunks in step (below) */
+	const bool wave_active = __builtin_amdgcn_ballot_w64(inside) != 0ull;
+	x  = x  < p.size[0] ? x  : p.size[0] - 1u;
+	y  = y  < p.size[1] ? y  : p.size[1] - 1u;
+	zl = zl < p.z_count ? zl : p.z_count - 1u;
 
 	sample_t<CPLX> coherent = zero_sample<CPLX>();
 	float          incoherent = 0.f;
 
-	if (inside) {
+	{
 		uint32_t z = p.z_first + zl;
 		float px = (float)x / fmaxf(1.0f, (float)p.size[0] - 1.0f);       /* das.glsl:374-376 */
 		float py = (float)y / fmaxf(1.0f, (float)p.size[1] - 1.0f);
@@ -223,7 +229,13 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			}
 		}
 
-		for (int c0 = ch_begin; c0 < ch_end; c0 += CH) {
+		for (int c_rel = 0; c_rel < per_split; c_rel += CH) {          /* (the same number of turns in every wave of a block: the barrier) */
+			const int c0 = ch_begin + c_rel;
+			/* the waves of a block -- neighbours along x at one depth -- start every chunk together: left alone they drift apart over the
+			 * 64 chunks x 128 transmits of a frame and stop sharing the lines they pull through L1.  Same-box A/B on the reference
+			 * harness's plane: FORCES 16.88 -> 15.89 ms, VLS 16.86 -> 16.22, TPW 15.11 -> 15.35 */
+			__syncthreads();
+			if (!wave_active || c0 >= ch_end) continue;
 			ChannelFactor<CPLX, CW> R[CH];
 			bool any = false;
 			#pragma unroll

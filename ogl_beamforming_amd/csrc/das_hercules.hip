@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
 	}
 }
 
-/* Grid: q.tiles[0] * q.tiles[1] * q.tiles[2] blocks of 256 threads; a block is 4 waves = 4 output rows
+/* Grid: q.tiles[0] * q.tiles[1] * q.tiles[2] blocks of 64 * q.rows threads; a block is q.rows waves = q.rows output rows
  * (y) x 64 voxels along x of one z plane. */
 /* PL ("phase local", IQ only): the demodulation phase of a pair is sin / cos of turns = turns_per_sample x index, which the
  * hardware takes in revolutions within +-256.  Absolute indices reach thousands, so the phase has to be reduced: by a v_fract per
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void hercules_table_kernel(const BfDasArgs p, 
 /* ROW_ENDS: the instantiation for launches in which a pair can come within reach of an end of its RF row (BfDasArgs::row_ends, a host
  * bound: das_select.cpp); the other one carries none of that code -- its loops and its register allocation are round 3's. */
 template <int INTERP, bool CPLX, bool CW, bool PL, bool PD, bool ROW_ENDS>
-__global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
+__global__ __launch_bounds__(1024) void das_hercules_kernel(const BfDasArgs p, const BfHerculesArgs q)
 {
 	constexpr bool EDGES = ROW_ENDS && INTERP != BF_INTERP_NEAREST;     /* (nearest flips at every half-integer: budgeted per voxel by the tests) */
 	static_assert(!PD || (CPLX && INTERP != BF_INTERP_NEAREST), "prepared data: linear or cubic interpolation of complex samples");
@@ -216,11 +216,12 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 
 	const uint32_t lane = threadIdx.x & 63u;
 	/* the wave's output row: wave uniform, told to the compiler so that table reads become scalar loads */
-	const uint32_t y = __builtin_amdgcn_readfirstlane(ty_ * 4u + (threadIdx.x >> 6));
-	if (y >= p.size[1]) return;
+	/* (a wave whose row lies beyond the grid repeats the last row and stores nothing: every wave of the block reaches the barriers below) */
+	const uint32_t y_real = __builtin_amdgcn_readfirstlane(ty_ * q.rows + (threadIdx.x >> 6));
+	const uint32_t y = y_real < p.size[1] ? y_real : p.size[1] - 1u;
 	const uint32_t x_real = tx_ * 64u + lane;
-	const bool     inside = x_real < p.size[0];
-	const uint32_t x = inside ? x_real : p.size[0] - 1u;           /* idle lanes repeat the last voxel, store nothing */
+	const bool     inside = x_real < p.size[0] && y_real < p.size[1];
+	const uint32_t x = x_real < p.size[0] ? x_real : p.size[0] - 1u;           /* idle lanes repeat the last voxel, store nothing */
 
 	float wx, wy, wz, xx, xy, xz;
 	voxel_to_xdc(p, x, y, z, wx, wy, wz, xx, xy, xz);
@@ -258,6 +259,10 @@ __global__ __launch_bounds__(256) void das_hercules_kernel(const BfDasArgs p, co
 	[[maybe_unused]] unsigned long long edge_outer[4] = {0, 0, 0, 0};       /* the outer elements (bit m; at most 256) whose checked loop met such a pair: scalars */
 
 	for (int m = 0; m < n_outer; m++) {
+		/* the waves of a block -- adjacent output rows, whose RF windows share their cache lines -- walk the outer elements IN STEP: left to
+		 * themselves they drift apart over the 128-256 elements and every wave pulls its own copy of the lines through L1.  Same-box A/B
+		 * (das_select.cpp kHerculesRows): config 5 2896 -> 2638 ms with 8 rows, the reference harness's HERCULES plane 18.46 -> 17.47 ms */
+		__syncthreads();
 		float outer_element = (!q.inner_is_transmit && p.sparse) ? (float)p.sparse_elements[m] : (float)m;
 		float od  = outer_lateral - outer_element * outer_pitch;
 		float od2 = od * od * s2;
@@ -490,8 +495,8 @@ static hipError_t launch_herc(const BfDasArgs *a, const BfHerculesArgs *q, hipSt
 	}
 	uint32_t total = q->tiles[0] * q->tiles[1] * q->tiles[2];
 	uint32_t grid  = q->depth_major == 3u ? bf_plane_walk_blocks(q->tiles[0], q->tiles[1], q->band_rows) : ((total + 7u) / 8u) * 8u;
-	if (a->row_ends && INTERP != BF_INTERP_NEAREST) hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD, true>), dim3(grid), dim3(256), 0, s, *a, *q);
-	else                                            hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD, false>), dim3(grid), dim3(256), 0, s, *a, *q);
+	if (a->row_ends && INTERP != BF_INTERP_NEAREST) hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD, true>), dim3(grid), dim3(64u * q->rows), 0, s, *a, *q);
+	else                                            hipLaunchKernelGGL((das_hercules_kernel<INTERP, CPLX, CW, PL, PD, false>), dim3(grid), dim3(64u * q->rows), 0, s, *a, *q);
 	return hipGetLastError();
 }
 

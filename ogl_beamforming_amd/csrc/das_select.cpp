@@ -417,6 +417,11 @@ static bool plan_staged(const BfDasArgs &a, const std::vector<BfTransmit> &tx, c
 	return true;
 }
 
+/* output rows (waves) per block of das_hercules.hip: they walk the outer elements in step.  Same-box A/B (gpurun_out/r04/ab_hbar2, round 4),
+ * no barrier and 4 rows -> barrier and 4 / 8 / 16 rows: config 5 2896 -> 2705 / 2638 / 2888 ms, the reference harness's plane 18.46 -> 17.74 /
+ * 17.47 / 19.43 ms, config 3 7.16 -> 7.18 / 7.26 / 7.55 ms */
+static const uint32_t kHerculesRows = 8u;
+
 /* Can this HERCULES-family frame use the aligned fast path (das_hercules.hip)?  The kernel lays
  * the 64 lanes of a wave along the output's x axis and reads the squared lateral distance along
  * the OTHER array axis from a per-output-row table, so one transducer lateral coordinate has to
@@ -458,7 +463,8 @@ static bool plan_hercules(const BfDasArgs &a, const std::vector<BfTransmit> &tx,
 	q.outer_count       = q.inner_is_transmit ? C : transmits;
 	q.table_pitch       = (q.inner_count + 8u + 3u) & ~3u;      /* the kernel prefetches one batch of 4 past the end */
 	q.tiles[0] = (a.size[0] + 63u) / 64u;
-	q.tiles[1] = (a.size[1] + 3u) / 4u;
+	q.rows     = kHerculesRows;
+	q.tiles[1] = (a.size[1] + q.rows - 1u) / q.rows;
 	q.tiles[2] = zcount;
 	{
 		/* the axis along which the transducer-space depth changes fastest (as choose_tile finds it) */
