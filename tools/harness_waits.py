@@ -63,6 +63,23 @@ out["reading"] = ("TPW / FORCES (das_factored_kernel): two pipes share the time 
                   "are no faster (TPW 16.0 -> 16.3-17.5 ms): with fewer waves resident each one runs faster, the pipes are what is shared.  HERCULES: VALU-bound (issue-stalled 45 %, "
                   "15.6 VALU instructions per gather).  Floor of this formulation on this grid: max(address path, VALU) with both near 0.8-0.87 -- a few per cent from better overlap, "
                   "not a factor; a different formulation (tile-wide staging) was measured slower on 0.23 mm pixels in round 3 (docs/NOTEBOOK.md 3.1c).")
+# what the counters say after the round's two changes to these kernels (tap-weight cubic; waves of a block in step): the committed PMC summary
+try:
+    bound = json.load(open(os.path.join(os.path.dirname(dst), "r04_das_bound.json")))
+    traffic = json.load(open(os.path.join(os.path.dirname(dst), "das_traffic.json")))
+    after = {}
+    for key in ("harness:tpw", "harness:hercules", "harness:forces"):
+        for kernel, e in bound.get(key, {}).items():
+            if isinstance(e, dict) and "valu_busy_frac" in e:
+                after[key] = {"kernel": kernel, "valu_busy_frac": e["valu_busy_frac"], "ta_busy_frac": e.get("ta_busy_frac"), "l1_hit_rate": e.get("l1_hit_rate"),
+                              "l2_hit_rate": e.get("l2_hit_rate"), "wave_cycles": e.get("wave_cycles"), "l1_miss_latency_cycles": e.get("l1_miss_latency_cycles"),
+                              "hbm_GB_per_launch": (traffic.get(key, {}).get(kernel, {}).get("hbm_bytes_per_launch") or 0) / 1e9,
+                              "kernel_source_sha16": e.get("kernel_source_sha16")}
+    out["after_tap_weights_and_waves_in_step"] = {"frames": after, "before": "the `frames` table above (L1 hit 0.93 / 0.93 / 0.89, L2 hit 0.71 / 0.45 / 0.61, HBM-side 22.7 / 40.9 / 48.0 GB per launch for TPW / HERCULES / FORCES)",
+        "reading": "a barrier per outer element (HERCULES, 8 rows per block) / per channel chunk (factored kernel) keeps the waves of a block on the same RF rows at the same time: "
+                   "the lines one wave pulls serve its neighbours (L1 hit up), the block asks L2 once (L2 hit up), HBM-side bytes fall 2-8 x"}
+except (OSError, ValueError, KeyError):
+    pass
 out["variants"] = {"base": "as shipped", "lpt": "bands of the plane walk deepest first", "lpt_split2 / lpt_split4 / split4": "channel loop split over 2 / 4 waves of a block (4 x the waves, a quarter of the life each)",
                    "lpt_w64": "one-wave blocks (tile 64 x 1) instead of four-wave blocks (256 x 1)",
                    "shallow_first (lpt2 / lpt2b runs)": "after das_hercules.hip took the deepest-first order: the HERCULES kernel with the old order (base = what ships)",
