@@ -268,12 +268,21 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 			}
 			/* ... and, for such a chunk, the extremes of the lane's receive terms over its channels: per transmit ONE wave-level test of
 			 * [r_lo, r_hi] + T against the row's ends decides whether any term of that transmit needs the per-term test at all */
-			[[maybe_unused]] float r_lo = __builtin_inff(), r_hi = -__builtin_inff();
+			/* (as bounds on T itself -- T in (hi_a, hi_b): the interval [r_lo, r_hi] + T reaches the row's far end; (lo_a, lo_b): its near end --
+			 * widened by a second margin for the roundings of the bounds: two compares per transmit, and the near end only in chunks where
+			 * the smallest transmit term can get there at all) */
+			[[maybe_unused]] float hi_a = __builtin_inff(), hi_b = -__builtin_inff(), lo_a = __builtin_inff(), lo_b = -__builtin_inff();
+			[[maybe_unused]] bool near_end_too = false;
 			if constexpr (EDGES) {
 				if (edges) {
+					float r_lo = __builtin_inff(), r_hi = -__builtin_inff();
 					#pragma unroll
 					for (int k = 0; k < CH; k++)
 						if (R[k].index > -1.0e8f) { r_lo = fminf(r_lo, R[k].index); r_hi = fmaxf(r_hi, R[k].index); }
+					const float e_hi = bfx::edge_hi<INTERP>(S), e_lo = bfx::edge_lo<INTERP>(), m2 = 2.0f * edge_margin;
+					hi_a = (e_hi - m2) - r_hi; hi_b = (e_hi + m2) - r_lo;
+					lo_a = (e_lo - m2) - r_hi; lo_b = (e_lo + m2) - r_lo;
+					near_end_too = __builtin_amdgcn_ballot_w64(t_lo < lo_b) != 0ull;
 				}
 			}
 			sample_t<CPLX> part[CH];
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(1024) void das_factored_kernel(const BfDasArgs p)
 				float t_index = transmit_index(a);
 				asm volatile("" : "+v"(t_index));           /* not fused into the per-channel adds: every kernel variant rounds the same way */
 				if constexpr (EDGES) {
-					if (edges && __builtin_amdgcn_ballot_w64(straddles(r_lo + t_index, r_hi + t_index)) != 0ull) {
+					if (edges && __builtin_amdgcn_ballot_w64((t_index > hi_a && t_index < hi_b) || (near_end_too && t_index > lo_a && t_index < lo_b)) != 0ull) {
 						/* ---- row ends (rare): a term of this transmit within the margin of an end of its row is evaluated from the voxel's
 						 * integer coordinates with the shader's own index, and the voxel's sums are CORRECTED by the difference to what the
 						 * loop below decides and adds for it with its own index (das_exact.h: edge_correct) */
