@@ -417,7 +417,10 @@ __global__ __launch_bounds__(TRANSPOSE ? 1024 : 256) void filter_kernel(const Bf
 	if (out_sample < a.sample_count / D) {                            /* filter.glsl:115 */
 		f32x2 result = {0.f, 0.f};
 		const float *x = w + 2 * (size_t)(D * lane);
+		/* (unrolled: the taps' LDS reads and coefficient loads of eight turns are issued together and waited for once -- scalar loads and LDS
+		 * reads share one counter, so a turn of its own waits out both latencies 36 times per output; the sums keep their order) */
 		if (a.complex_filter && complex_sample) {
+			#pragma unroll 8
 			for (uint32_t j = 0; j < L; j++) {
 				float hr = a.coefficients[2 * j], hi = a.coefficients[2 * j + 1];
 				float xr = x[2 * j], xi = x[2 * j + 1];
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(TRANSPOSE ? 1024 : 256) void filter_kernel(const Bf
 			}
 		} else {
 			const uint32_t hs = a.complex_filter ? 2 : 1;
+			#pragma unroll 8
 			for (uint32_t j = 0; j < L; j++) {
 				float h = a.coefficients[hs * j];
 				result.x += x[2 * j]     * h;
