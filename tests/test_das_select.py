@@ -211,3 +211,23 @@ def test_full_size_configurations_stay_clear_of_row_ends_and_the_harness_planes_
         acq = cfg.harness(kind)
         d = lib.describe_das(acq.bp, acq.filters)[4]
         assert int(d.row_ends) == 1 and int(d.row_end_planes) == 0, kind
+
+
+def test_random_view_planes_select_the_plane_kernels():
+    """the view-plane generator of tests/test_gpu_random.py (the reference harness's shape at test size) is aimed at the HERCULES aligned-grid
+    kernel and at the factored kernel: the selection rules say so without a device (small frames: with the channel split switched off,
+    flag 0x10, as the GPU test and the fuzz ask for them)"""
+    from tests import test_gpu_random as R
+    L = lib.library()
+    taken = {}
+    L.beamformer_hip_set_das_path(0x10)
+    try:
+        for seed in range(24):
+            acq = R.draw_plane(seed)
+            path, kernel, _, _, d = lib.describe_das(acq.bp, acq.filters)
+            hercules = int(acq.bp.acquisition_kind) in (int(P.AcquisitionKind.HERCULES), int(P.AcquisitionKind.UHERCULES))
+            taken.setdefault(hercules, set()).add(path)
+    finally:
+        L.beamformer_hip_set_das_path(0)
+    assert taken[True] == {int(P.DasPath.Hercules)}, taken
+    assert int(P.DasPath.Factored) in taken[False] and int(P.DasPath.Hercules) not in taken[False], taken
